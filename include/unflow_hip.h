@@ -1,0 +1,242 @@
+/*
+ * libunflow_hip.so — C ABI of the MI355X-native UnFlow training-step kernels.
+ *
+ * This is the drop-in boundary for the reference's operator layer
+ * (src/e2eflow/ops.py:69-107 and the host launchers declared in
+ * ops/correlation_op.cc:22-36, ops/backward_warp_op.cc:22-31,
+ * ops/forward_warp_op.cc:23-30, ops/downsample_op.cc:21-23), widened — as the
+ * north star asks — to the conv/deconv stacks (slim.conv2d / conv2d_transpose in
+ * src/e2eflow/core/flownet.py), image_warp (core/image_warp.py) and the loss
+ * terms (core/losses.py) that the reference leaves to TensorFlow.
+ *
+ * Conventions
+ *  - All tensors are device pointers to fp32 (the reference's ops are
+ *    `float`-only: REGISTER_OP(... ": float") in every ops/[name]_op.cc).
+ *  - The caller allocates every output and workspace; the library never
+ *    allocates, frees or synchronises (TF's allocate_output replaced by
+ *    caller-owned buffers).  Every entry takes a hipStream_t (as void*) and is
+ *    fully asynchronous and re-entrant (no globals).
+ *  - Return value: 0 on success, a negative UNFLOW_ERR_* otherwise; on error
+ *    nothing is launched (mirrors OP_REQUIRES -> InvalidArgument).
+ *  - Layouts at the op boundary are the reference's: correlation NCHW
+ *    (correlation_op.cc:53-56,64), warps / downsample NHWC with flow channel
+ *    0 = x/u, 1 = y/v (backward_warp_op.cu.cc:26-28).  The *_nhwc entry points
+ *    and the conv/loss entry points are channels-last with an explicit channel
+ *    stride ("ld") so that producers write straight into channel slices of a
+ *    consumer's concat buffer.
+ */
+#ifndef UNFLOW_HIP_H_
+#define UNFLOW_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* unflow_stream_t; /* hipStream_t */
+
+#define UNFLOW_OK 0
+#define UNFLOW_ERR_NULL (-1)          /* null pointer argument                                   */
+#define UNFLOW_ERR_EMPTY_OUTPUT (-2)  /* correlation_op.cc:60-61 "Invalid correlation settings"   */
+#define UNFLOW_ERR_EVEN_KERNEL (-3)   /* correlation_op.h:16-17  "kernel_size must be odd"         */
+#define UNFLOW_ERR_NOT_DIVISIBLE (-4) /* downsample_op.cc:37-40                                    */
+#define UNFLOW_ERR_SHAPE (-5)         /* correlation_op.cc:47-48 "Input shapes have to be the same" and other shape errors */
+#define UNFLOW_ERR_UNSUPPORTED (-7)   /* configuration outside what the kernels implement          */
+#define UNFLOW_ERR_LAUNCH (-8)        /* hipGetLastError() after launch                            */
+#define UNFLOW_ERR_WORKSPACE (-9)     /* workspace too small                                       */
+
+const char* unflow_status_string(int status);
+int unflow_version(void);
+
+/* ===================================================================== */
+/* Correlation — replaces Correlation()/CorrelationGrad()                 */
+/* (ops/correlation_op.cc:22-36; kernels ops/correlation_op.cu.cc:30-248) */
+/* ===================================================================== */
+
+/* out3 = {out_channels, out_height, out_width}; geometry of correlation_op.h:36-51. */
+int unflow_correlation_out_shape(int H, int W, int kernel_size, int max_displacement, int pad,
+                                 int stride_1, int stride_2, int* out3);
+
+/* Bytes of scratch the NCHW entry points need (channels-last staging copies). */
+size_t unflow_correlation_workspace_bytes(int B, int C, int H, int W, int kernel_size,
+                                          int max_displacement, int pad, int stride_1, int stride_2);
+
+/* NCHW in, NCHW out (output 0 of the reference op; padded_0/1 are not materialised). */
+int unflow_correlation_fwd(const float* in0, const float* in1, float* out, int B, int C, int H, int W,
+                           int kernel_size, int max_displacement, int pad, int stride_1, int stride_2,
+                           void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+
+/* CorrelationGrad (ops.py:94-104): (dOut, in0, in1) -> (grad0, grad1), all NCHW. */
+int unflow_correlation_bwd(const float* dout, const float* in0, const float* in1, float* grad0, float* grad1,
+                           int B, int C, int H, int W, int kernel_size, int max_displacement, int pad,
+                           int stride_1, int stride_2, void* workspace, size_t workspace_bytes,
+                           unflow_stream_t stream);
+
+/* Channels-last form used inside the step.  in0/in1: [B,H,W,ld_in] (C channels used);
+ * sample n of in0 is paired with sample (n + pair_shift) % B of in1 (pair_shift = B/2 with
+ * in0 == in1 runs both flow directions of a [im1-features; im2-features] batch in one launch).
+ * out: [B,oh,ow,ld_out], oc channels written. */
+int unflow_correlation_nhwc_fwd(const float* in0, const float* in1, int ld_in, int pair_shift, float* out,
+                                int ld_out, int B, int C, int H, int W, int kernel_size, int max_displacement,
+                                int pad, int stride_1, int stride_2, unflow_stream_t stream);
+
+/* grad0[n] = d/d in0[n]; grad1[m] = d/d in1[m] with m = (n + pair_shift) % B.
+ * If accumulate_g1_into_g0 != 0 (requires in0 == in1 storage), both are summed into grad0
+ * (grad1 may be NULL): the gradient wrt the shared feature tensor. */
+int unflow_correlation_nhwc_bwd(const float* dout, int ld_dout, const float* in0, const float* in1, int ld_in,
+                                int pair_shift, float* grad0, float* grad1, int ld_grad,
+                                int accumulate_g1_into_g0, int B, int C, int H, int W, int kernel_size,
+                                int max_displacement, int pad, int stride_1, int stride_2, unflow_stream_t stream);
+
+/* ===================================================================== */
+/* Warps / downsample — replace BackwardWarp(), BackwardWarpGrad(),        */
+/* ForwardWarp(), ForwardWarpGrad(), Downsample()                          */
+/* ===================================================================== */
+
+/* ops/backward_warp_op.cu.cc:14-68: zero outside the image, floorf(float(x)+u). */
+int unflow_backward_warp_fwd(const float* images, const float* flows, float* out, int B, int H, int W, int C,
+                             unflow_stream_t stream);
+/* ops/backward_warp_op.cu.cc:70-138: gradient wrt flows only (ops.py:80-84). */
+int unflow_backward_warp_bwd(const float* dout, const float* images, const float* flows, float* dflows,
+                             int B, int H, int W, int C, unflow_stream_t stream);
+/* (x0,y0) integer tap corner per pixel, [B,H,W,2] int32 — for bit-exact index checks. */
+int unflow_backward_warp_indices(const float* flows, int* xy0, int B, int H, int W, unflow_stream_t stream);
+
+/* src/e2eflow/core/image_warp.py:4-76: clamp-to-edge, x + int(floor(u)); what the training graph uses.
+ * im: [B_im,H,W,ld_im] (C channels used); output sample n reads image sample (n + pair_shift) % B. */
+int unflow_image_warp_fwd(const float* im, int ld_im, const float* flow, float flow_scale, float* out,
+                          int* idx4 /* optional [B,H,W,4] gather indices, may be NULL */, int pair_shift,
+                          int B, int H, int W, int C, unflow_stream_t stream);
+/* TF autodiff of that graph: d_im (scatter-add; may be NULL; must be zero-filled by the caller or
+ * hold a running sum) and d_flow (multiplied by flow_scale, the derivative of flow*flow_scale). */
+int unflow_image_warp_bwd(const float* dout, const float* im, int ld_im, const float* flow, float flow_scale,
+                          float* d_im, float* d_flow, int accumulate_d_flow, int pair_shift, int B, int H, int W,
+                          int C, unflow_stream_t stream);
+
+/* ops/forward_warp_op.cu.cc:16-65.  deterministic == 0: float-atomic scatter like the reference
+ * (summation order varies run to run).  deterministic != 0: the same scatter accumulated in 2^40-scaled
+ * 64-bit integers (order-independent, bit-reproducible); needs workspace >= 8*B*H*W bytes. */
+int unflow_forward_warp_fwd(const float* flows, float* out, int B, int H, int W, int deterministic,
+                            void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+int unflow_forward_warp_bwd(const float* dout, const float* flows, float* dflows, int B, int H, int W,
+                            unflow_stream_t stream);
+/* {x_lo,x_hi,y_lo,y_hi} splat footprint per pixel ([B,H,W,4] int32; -1 when rejected). */
+int unflow_forward_warp_ranges(const float* flows, int* ranges, int B, int H, int W, unflow_stream_t stream);
+
+/* ops/downsample_op.cu.cc:15-49 (box mean); H,W must be divisible by scale (downsample_op.cc:37-40). */
+int unflow_downsample_fwd(const float* images, float* out, int B, int H, int W, int C, int scale,
+                          unflow_stream_t stream);
+
+/* ===================================================================== */
+/* conv / deconv stacks — slim.conv2d / slim.conv2d_transpose of           */
+/* src/e2eflow/core/flownet.py:89-237, channels-last, TF 'SAME' padding.   */
+/* Channel counts of the gathered operand must be multiples of 4 (pad the  */
+/* buffers; padded weights stay zero).                                     */
+/* ===================================================================== */
+
+/* y[b,oy,ox,0:Cout] = act(bias + sum_{ky,kx,ci} x[b,oy*s-pt+ky, ox*s-pl+kx, ci] * w[ky,kx,ci,co])
+ * x: [B,H,W,ldx] (Cin used), w: HWIO [k,k,Cin,Cout], y: [B,ceil(H/s),ceil(W/s),ldy].
+ * leaky != 0 applies max(0.1*v, v) (flownet.py:84-86). bias may be NULL. */
+int unflow_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B,
+                      int H, int W, int Cin, int Cout, int k, int stride, int leaky, void* workspace,
+                      size_t workspace_bytes, unflow_stream_t stream);
+
+/* dx[.,0:Cin] (+)= conv-transpose of dz with w.  Epilogue: if accumulate, adds the existing dx first;
+ * then, for channels c in [act_lo, act_hi), multiplies by leaky'(act_src[., c]) (1 if >0 else 0.1),
+ * turning d(output) of the producing layer into d(pre-activation).  act_src may be NULL. */
+int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W,
+                           int Cin, int Cout, int k, int stride, int accumulate, const float* act_src,
+                           int ld_act, int act_lo, int act_hi, void* workspace, size_t workspace_bytes,
+                           unflow_stream_t stream);
+
+/* dw[k,k,Cin,Cout] = sum over sites; dbias[Cout] (may be NULL) = column sums of dz.  Deterministic
+ * (split partials in workspace, fixed-order reduce). */
+int unflow_conv2d_bwd_filter(const float* x, int ldx, const float* dz, int lddz, float* dw, float* dbias, int B,
+                             int H, int W, int Cin, int Cout, int k, int stride, void* workspace,
+                             size_t workspace_bytes, unflow_stream_t stream);
+
+/* slim.conv2d_transpose(k=4, stride=2, SAME): y is [B,2H,2W,ldy]; w: [4,4,Cout,Cin] (TF layout). */
+int unflow_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                                int B, int H, int W, int Cin, int Cout, int leaky, void* workspace,
+                                size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_transpose_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H,
+                                     int W, int Cin, int Cout, int accumulate, const float* act_src, int ld_act,
+                                     int act_lo, int act_hi, void* workspace, size_t workspace_bytes,
+                                     unflow_stream_t stream);
+int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const float* dz, int lddz, float* dw, float* dbias,
+                                       int B, int H, int W, int Cin, int Cout, void* workspace,
+                                       size_t workspace_bytes, unflow_stream_t stream);
+
+/* Workspace upper bound for any conv/deconv entry above with these dimensions. */
+size_t unflow_conv_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
+
+/* dz[., c] = dy[., c] * leaky'(y[., c]) in place over a [npix, C] slice (stand-alone form of the epilogue). */
+int unflow_leaky_bwd_inplace(float* dy, int lddy, const float* y, int ldy, long npix, int C, unflow_stream_t stream);
+
+/* ===================================================================== */
+/* loss terms — src/e2eflow/core/losses.py, fused per pyramid level.        */
+/* A "directed batch" holds both flow directions: samples [0,B) forward,    */
+/* [B,2B) backward; image sample n is paired with (n + B) % 2B.             */
+/* ===================================================================== */
+
+/* gray[b,y,x] = 255 * (0.2989 R + 0.5870 G + 0.1140 B)  (losses.py:94, tf.image.rgb_to_grayscale). */
+int unflow_rgb_to_gray255(const float* im, int ld_im, float* gray, long npix, unflow_stream_t stream);
+
+/* image_warp of a 3-channel image followed by the grayscale above, fused (losses.py:22-23,94);
+ * taps are re-derived in the backward pass. out_gray: [N,H,W]. */
+int unflow_warp_gray_fwd(const float* im, int ld_im, const float* flow, float flow_scale, float* out_gray,
+                         int pair_shift, int N, int H, int W, unflow_stream_t stream);
+/* d_flow (+)= flow_scale * d(gray_warped)/d(flow) * d_gray. */
+int unflow_warp_gray_bwd(const float* d_gray, const float* im, int ld_im, const float* flow, float flow_scale,
+                         float* d_flow, int accumulate, int pair_shift, int N, int H, int W,
+                         unflow_stream_t stream);
+
+/* ternary_loss (losses.py:90-122) on gray images: per pixel soft-Hamming distance of the census
+ * transforms, Charbonnier (alpha .45, eps 1e-3), masked by mask*interior(max_distance), summed into
+ * loss_acc[0] scaled by `weight`/(normalizer).  dist_out [N,H,W] keeps the per-pixel distance for
+ * the backward pass.  mask: [N_mask,H,W] with sample n using mask[n % N_mask]. */
+int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask, float* dist_out,
+                       float* loss_acc, float weight, float normalizer, int max_distance, int N, int H, int W,
+                       unflow_stream_t stream);
+/* d_gray2w = d(weight * loss)/d(gray2w)  (gather form, no atomics). */
+int unflow_ternary_bwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
+                       const float* dist, float* d_gray2w, float weight, float normalizer, int max_distance,
+                       int N, int H, int W, unflow_stream_t stream);
+
+/* second_order_loss (losses.py:258-295) on flow*flow_scale; loss_acc[0] += weight * sum/normalizer;
+ * d_flow (+)= gradient wrt the raw flow (includes flow_scale).  Either output may be NULL. */
+int unflow_second_order_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow,
+                                int accumulate, float weight, float normalizer, int N, int H, int W,
+                                unflow_stream_t stream);
+
+/* ===================================================================== */
+/* step plumbing                                                           */
+/* ===================================================================== */
+
+/* net input: out[n,y,x,0:3] = im[n,y,x,:]/255 - mean[c]/255, out[...,3] = 0 ([N,H,W,4]);
+ * loss image: out01[n,y,x,0:3] = im/255 (unsupervised.py:29-32,69-70). out01 may be NULL. */
+int unflow_prepare_images(const float* im_u8range, float* net_in4, float* out01, const float* mean3, long npix,
+                          unflow_stream_t stream);
+
+/* tf.image.resize_bilinear (TF1 legacy, align_corners=False) * scale (unsupervised.py:103-104). */
+int unflow_resize_bilinear_tf1(const float* in, float* out, int B, int H, int W, int C, int out_h, int out_w,
+                               float scale, unflow_stream_t stream);
+
+/* Fused L2-regularised TF-form Adam over a flat parameter vector (train.py:151-152; flownet.py:176):
+ * g = grad*grad_scale + (i < n_regularized ? l2_scale * p : 0);
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t * m / (sqrt(v) + eps). */
+int unflow_adam_step(float* p, const float* grad, float* m, float* v, long n, long n_regularized, float grad_scale,
+                     float l2_scale, float lr_t, float beta1, float beta2, float eps, unflow_stream_t stream);
+
+/* loss_acc[0] += scale * 0.5 * sum(p[0:n]^2)  (tf.nn.l2_loss via slim.l2_regularizer). */
+int unflow_l2_loss(const float* p, long n, float scale, float* loss_acc, unflow_stream_t stream);
+
+/* sum/mean helpers for metrics: out[0] = sum(|f1-f2|_2 * mask), out[1] = sum(mask)  (flow_util.py:98-103). */
+int unflow_flow_error_sums(const float* f1, const float* f2, const float* mask /* may be NULL = ones */,
+                           float* out2, long npix, unflow_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNFLOW_HIP_H_ */

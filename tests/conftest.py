@@ -1,0 +1,34 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kats():
+    with open(os.path.join(ROOT, "tests", "golden", "ref_kats.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import ops_ref
+    ops_ref.build()
+    return ops_ref
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,212 @@
+"""-m gpu: the four custom ops + image_warp through the C ABI vs the CPU oracle (oracle/ops_ref.c)
+and the reference's own known-answer vectors (tests/golden/ref_kats.json).
+
+Tolerances: integer outputs (warp indices, splat footprints) bit-exact; fp32 values rtol/atol 1e-5
+(summation order differs from the 32-lane order of the CUDA kernel); gradients 1e-4."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a, dev):
+    return torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+
+
+def close(a, b, tol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+# ---------------------------------------------------------------- reference KATs through the HIP ops
+def test_kat_correlation(kats, dev):
+    from unflow_amd import ops
+    for name in ("correlation_trivial", "correlation_batch"):
+        k = kats[name]
+        out = ops.correlation(t(k["first"], dev), t(k["second"], dev), **k["attrs"])
+        close(out, np.array(k["expected"], np.float32), 1e-6)
+
+
+def test_kat_warps(kats, dev):
+    from unflow_amd import ops
+    from unflow_amd.core.image_warp import image_warp
+    for name in ("warp_move", "warp_interpolate", "backward_warp_batches"):
+        k = kats[name]
+        im = t(np.array(k["image"])[..., None], dev)
+        fl = t(k["flow"], dev)
+        close(ops.backward_warp(im, fl)[..., 0], np.array(k["expected"], np.float32), 1e-6)
+    for name in ("warp_move", "warp_interpolate", "image_warp_batches"):
+        k = kats[name]
+        im = t(np.array(k["image"])[..., None], dev)
+        fl = t(k["flow"], dev)
+        close(image_warp(im, fl)[..., 0], np.array(k["expected"], np.float32), 1e-6)
+
+
+def test_kat_downsample_forward_warp(kats, dev):
+    from unflow_amd import ops
+    k = kats["downsample"]
+    close(ops.downsample(t(np.array(k["image"])[..., None], dev), k["scale"])[..., 0], np.array(k["expected"]), 0)
+    z = torch.zeros(1, 20, 20, 2, device=dev)
+    for det in (True, False):
+        v = ops.forward_warp(z, deterministic=det)[0, 10, 10, 0].item()
+        assert abs(v - kats["forward_warp_zero_flow_interior"]["expected"]) < 1e-5
+
+
+def test_error_statuses(dev):
+    from unflow_amd import ops, _lib
+    a = torch.zeros(1, 4, 8, 8, device=dev)
+    with pytest.raises(_lib.UnflowError, match="kernel_size must be odd"):
+        ops.correlation(a, a, kernel_size=2)
+    with pytest.raises(_lib.UnflowError, match="Input shapes have to be the same"):
+        ops.correlation(a, torch.zeros(1, 4, 8, 9, device=dev))
+    with pytest.raises(_lib.UnflowError, match="Invalid correlation settings"):
+        ops.correlation(a, a, max_displacement=20, pad=0)
+    with pytest.raises(_lib.UnflowError, match="divisible by scale"):
+        ops.downsample(torch.zeros(1, 6, 8, 3, device=dev), 4)
+    with pytest.raises(TypeError):
+        ops.downsample(torch.zeros(1, 8, 8, 3), 2)  # CPU tensor: no CPU path exists
+
+
+# ---------------------------------------------------------------- correlation vs oracle
+CORR_CASES = [
+    # B, C, H, W, attrs
+    (2, 16, 12, 14, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=2)),
+    (1, 8, 9, 11, dict(kernel_size=3, max_displacement=2, pad=3, stride_1=1, stride_2=1)),
+    (2, 5, 10, 9, dict(kernel_size=3, max_displacement=4, pad=4, stride_1=2, stride_2=2)),
+    (1, 32, 16, 24, dict(kernel_size=1, max_displacement=6, pad=6, stride_1=1, stride_2=1)),
+    (2, 64, 8, 16, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),
+    (1, 12, 7, 9, dict(kernel_size=1, max_displacement=3, pad=5, stride_1=1, stride_2=1)),
+]
+
+
+@pytest.mark.parametrize("case", CORR_CASES)
+def test_correlation_vs_oracle(case, dev, oracle_lib):
+    from unflow_amd import ops
+    B, C, H, W, attrs = case
+    rs = np.random.RandomState(zlib.crc32(str(case).encode()))
+    a = rs.randn(B, C, H, W).astype(np.float32)
+    b = rs.randn(B, C, H, W).astype(np.float32)
+    ref = oracle_lib.correlation(a, b, **attrs)
+    ta, tb = t(a, dev).requires_grad_(), t(b, dev).requires_grad_()
+    out = ops.correlation(ta, tb, **attrs)
+    assert tuple(out.shape) == ref.shape
+    close(out, ref, 1e-5)
+    go = rs.randn(*ref.shape).astype(np.float32)
+    out.backward(t(go, dev))
+    g0, g1 = oracle_lib.correlation_grad(go, a, b, **attrs)
+    close(ta.grad, g0, 1e-4)
+    close(tb.grad, g1, 1e-4)
+
+
+def test_correlation_flownetc_shape_full(dev, oracle_lib):
+    """FlowNetC configuration (flownet.py:221-222) at the real feature-map size, one sample."""
+    from unflow_amd import ops
+    rs = np.random.RandomState(7)
+    a = rs.randn(1, 256, 48, 64).astype(np.float32)
+    b = rs.randn(1, 256, 48, 64).astype(np.float32)
+    attrs = dict(pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
+    ref = oracle_lib.correlation(a, b, **attrs)
+    ta, tb = t(a, dev).requires_grad_(), t(b, dev).requires_grad_()
+    out = ops.correlation(ta, tb, **attrs)
+    assert tuple(out.shape) == (1, 441, 48, 64)
+    close(out, ref, 2e-5)
+    go = rs.randn(*ref.shape).astype(np.float32)
+    out.backward(t(go, dev))
+    g0, g1 = oracle_lib.correlation_grad(go, a, b, **attrs)
+    close(ta.grad, g0, 2e-4)
+    close(tb.grad, g1, 2e-4)
+
+
+# ---------------------------------------------------------------- warps vs oracle
+def _flows(rs, B, H, W, kind):
+    if kind == "normal":
+        return (rs.randn(B, H, W, 2) * 4).astype(np.float32)
+    if kind == "zero":
+        return np.zeros((B, H, W, 2), np.float32)
+    if kind == "oob":
+        return (rs.choice([-50.0, 50.0], size=(B, H, W, 2)) + rs.randn(B, H, W, 2)).astype(np.float32)
+    if kind == "tiny":   # x+u crosses an integer only in fp32: op and image_warp index formulas differ here
+        return (rs.choice([-1e-8, 1e-8, -1.0 + 1e-8, 0.99999994], size=(B, H, W, 2))).astype(np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["normal", "zero", "oob", "tiny"])
+@pytest.mark.parametrize("C", [1, 3])
+def test_backward_warp_vs_oracle(kind, C, dev, oracle_lib):
+    from unflow_amd import ops
+    rs = np.random.RandomState(11)
+    B, H, W = 2, 17, 23
+    im = rs.rand(B, H, W, C).astype(np.float32)
+    fl = _flows(rs, B, H, W, kind)
+    tim, tfl = t(im, dev), t(fl, dev).requires_grad_()
+    out = ops.backward_warp(tim, tfl)
+    close(out, oracle_lib.backward_warp(im, fl), 1e-6)
+    assert np.array_equal(ops.backward_warp_indices(tfl.detach()).cpu().numpy(), oracle_lib.backward_warp_indices(fl))
+    go = rs.randn(B, H, W, C).astype(np.float32)
+    out.backward(t(go, dev))
+    close(tfl.grad, oracle_lib.backward_warp_grad(go, im, fl), 1e-5)
+
+
+@pytest.mark.parametrize("kind", ["normal", "zero", "oob", "tiny"])
+@pytest.mark.parametrize("C", [2, 3])
+def test_image_warp_vs_oracle(kind, C, dev, oracle_lib):
+    from unflow_amd.core.image_warp import image_warp, image_warp_indices
+    rs = np.random.RandomState(13)
+    B, H, W = 2, 17, 23
+    im = rs.rand(B, H, W, C).astype(np.float32)
+    fl = _flows(rs, B, H, W, kind)
+    tim, tfl = t(im, dev).requires_grad_(), t(fl, dev).requires_grad_()
+    out = image_warp(tim, tfl)
+    ref, idx = oracle_lib.image_warp(im, fl, return_indices=True)
+    close(out, ref, 1e-6)
+    assert np.array_equal(image_warp_indices(tim.detach(), tfl.detach()).cpu().numpy(), idx)   # bit-exact gather indices
+    go = rs.randn(B, H, W, C).astype(np.float32)
+    out.backward(t(go, dev))
+    d_im, d_fl = oracle_lib.image_warp_grad(go, im, fl)
+    close(tim.grad, d_im, 1e-5)
+    close(tfl.grad, d_fl, 1e-5)
+
+
+@pytest.mark.parametrize("kind", ["normal", "zero", "oob"])
+def test_forward_warp_vs_oracle(kind, dev, oracle_lib):
+    from unflow_amd import ops
+    rs = np.random.RandomState(17)
+    B, H, W = 2, 19, 21
+    fl = _flows(rs, B, H, W, kind)
+    tfl = t(fl, dev).requires_grad_()
+    ref = oracle_lib.forward_warp(fl)
+    out = ops.forward_warp(tfl, deterministic=True)
+    close(out, ref, 1e-5)
+    out2 = ops.forward_warp(tfl.detach(), deterministic=True)
+    assert torch.equal(out.detach(), out2)           # deterministic mode is bit-reproducible
+    close(ops.forward_warp(tfl.detach(), deterministic=False), ref, 1e-5)
+    assert np.array_equal(ops.forward_warp_ranges(tfl.detach()).cpu().numpy(), oracle_lib.forward_warp_ranges(fl))
+    go = rs.randn(B, H, W, 1).astype(np.float32)
+    out.backward(t(go, dev))
+    close(tfl.grad, oracle_lib.forward_warp_grad(go, fl), 1e-5)
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+def test_downsample_vs_oracle(scale, dev, oracle_lib):
+    from unflow_amd import ops
+    rs = np.random.RandomState(19)
+    im = rs.rand(3, 16, 24, 3).astype(np.float32)
+    out = ops.downsample(t(im, dev), scale)
+    assert np.array_equal(out.cpu().numpy(), oracle_lib.downsample(im, scale))   # same order of adds -> bit-exact
+
+
+def test_warp_linearity_full_size(dev):
+    """Size-independent property at the benchmark size: warps are linear in the image."""
+    from unflow_amd.core.image_warp import image_warp
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = torch.rand(4, 384, 512, 3, generator=g).to(dev)
+    b = torch.rand(4, 384, 512, 3, generator=g).to(dev)
+    fl = (torch.randn(4, 384, 512, 2, generator=g) * 4).to(dev)
+    lhs = image_warp(2.0 * a + b, fl)
+    rhs = 2.0 * image_warp(a, fl) + image_warp(b, fl)
+    assert (lhs - rhs).abs().max().item() < 1e-5
+    ident = image_warp(a, torch.zeros_like(fl))
+    assert torch.equal(ident, a)     # zero flow is the identity, bit-exact

@@ -1,0 +1,68 @@
+"""ctypes binding of libunflow_hip.so (include/unflow_hip.h).  Fails loudly when the HIP library is
+missing: there is NO CPU fallback in the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libunflow_hip.so")
+
+STATUS_TEXT = {
+    -1: "null pointer argument",
+    -2: "Invalid correlation settings",                      # correlation_op.cc:60-61
+    -3: "kernel_size must be odd",                           # correlation_op.h:16-17
+    -4: "Input height and width must be divisible by scale",  # downsample_op.cc:37-40
+    -5: "Input shapes have to be the same",                  # correlation_op.cc:47-48
+    -7: "unsupported configuration",
+    -8: "HIP launch failed",
+    -9: "workspace too small",
+}
+
+
+class UnflowError(ValueError):
+    def __init__(self, status, where=""):
+        self.status = status
+        super().__init__("%s%s (status %d)" % (where + ": " if where else "", STATUS_TEXT.get(status, "error"), status))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libunflow_hip.so not found at %s — build it with `python -m unflow_amd.build` "
+                "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.unflow_status_string.restype = ctypes.c_char_p
+        _lib.unflow_correlation_workspace_bytes.restype = ctypes.c_size_t
+        _lib.unflow_conv_workspace_bytes.restype = ctypes.c_size_t
+    return _lib
+
+
+def check(status, where=""):
+    if status != 0:
+        raise UnflowError(status, where)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def cf(x):
+    return ctypes.c_float(float(x))
+
+
+def cl(x):
+    return ctypes.c_long(int(x))
+
+
+def csz(x):
+    return ctypes.c_size_t(int(x))
+
+
+def stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,1140 @@
+// conv / conv_transpose stacks of FlowNetC/S (src/e2eflow/core/flownet.py:89-237) as fp32 MFMA
+// implicit GEMMs for gfx950, channels-last.
+//
+// One "gather GEMM" kernel covers conv fwd, conv dgrad, deconv fwd and deconv dgrad:
+//   D[site, n] = sum_{tap} sum_{c} SRC[b, yg*sm + dy(tap), xg*sm + dx(tap), c] * W(tap, c, n)
+// with the rows (sites) a regular grid, out-of-image taps contributing zero (TF 'SAME'), and the
+// stride-2 transposed cases split into the 4 output-parity classes (each class is a dense
+// stride-1 gather with its own tap subset) — no zero-insertion, no im2col buffer, no col2im.
+// One "wgrad" kernel covers conv and deconv filter gradients:
+//   dW[(tap,a), b] = sum_{site} SRC[gather(site, tap), a] * DST[site, b]
+// K is the flattened (tap, channel) axis walked in 16-byte quads, so Cin = 4 (the padded RGB
+// input) packs 8 taps into one K-tile instead of wasting 7/8 of it.
+//
+// Tiling: 256 threads = 4 waves; v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles, 157 TF peak);
+// A and B tiles staged through LDS (double buffered, one barrier per K-tile of 32), layouts chosen
+// so every ds_read_b32 of an MFMA operand is bank-conflict free:
+//   K-contiguous global operand  -> LDS [row][33]   (lane i reads row i: stride 33 -> 32 banks)
+//   row-contiguous global operand-> LDS [k][rows]   (lane i reads consecutive dwords)
+// HBM side: 16-byte loads, 128 B contiguous per pixel-row of a tile (channels-last).
+// Deep layers (M = 384..6144 sites) use split-K so the launch covers the 256 CUs; partials go to a
+// caller workspace and a fixed-order reduce applies the epilogue (deterministic, no float atomics).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 1;
+
+struct TapClass {
+  int nty, ntx;  // taps of this class
+  int dy0, dx0;  // source offset of tap (0,0); tap (ty,tx) -> dy0 + ty*dstep
+  int ky0, kx0;  // weight index of tap (0,0);  -> ky0 + ty*kstep
+  int py, px;    // destination parity offset
+};
+
+struct GatherParams {
+  const float* src;
+  const float* w;
+  const float* bias;
+  float* dst;
+  float* partial;  // split-K partials [nsplit][dst pixels][N] (nsplit > 1)
+  const float* act_src;
+  int lds, ldd, ld_act, act_lo, act_hi;
+  int B, Hg, Wg, Hs, Ws, sm;
+  int dstep, kstep, KW;
+  int Cs, N;
+  int Hd, Wd, so;
+  int ncls, nsplit;
+  int leaky, accumulate;
+  unsigned cs_magic;  // ceil(2^32 / Cs)
+  TapClass cls[4];
+};
+
+__device__ __forceinline__ unsigned fast_div(unsigned a, unsigned magic) { return __umulhi(a, magic); }
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int BM, int BN, int WM, int WN, bool B_NK>
+__global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  constexpr int A_ELEMS = BM * LDK;
+  constexpr int B_ELEMS = B_NK ? BN * LDK : BK * BN;
+  constexpr int AR = BM / 32;                       // A rows per thread
+  constexpr int BR = B_NK ? BN / 32 : (BK * BN / 4) / 256;  // B rows (or k-rows) per thread
+  constexpr int BQ = BN / 4;                        // quads per B k-row (KN layout)
+  constexpr int BKSTEP = 256 / BQ;                  // k-row step between a thread's loads (KN layout)
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+  int* pix = reinterpret_cast<int*>(smem + 2 * A_ELEMS + 2 * B_ELEMS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int cls_id = blockIdx.z % p.ncls, split = blockIdx.z / p.ncls;
+  const TapClass tc = p.cls[cls_id];
+  const int M = p.B * p.Hg * p.Wg;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ntaps = tc.nty * tc.ntx;
+  const int Cq = p.Cs >> 2;
+  const int Ktot = ntaps * p.Cs;
+  const int KT = (Ktot + BK - 1) / BK;
+  // split-K range of K-tiles
+  const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
+  const int kt0 = split * kt_per;
+  const int kt1 = min(KT, kt0 + kt_per);
+
+  // ---- per-thread A row decode (fixed for the whole K loop)
+  const int kq = tid & 7;
+  int a_y[AR], a_x[AR], a_b[AR];
+#pragma unroll
+  for (int i = 0; i < AR; i++) {
+    const int m = m0 + (tid >> 3) + 32 * i;
+    if (m < M) {
+      const int xg = m % p.Wg, t = m / p.Wg;
+      const int yg = t % p.Hg, b = t / p.Hg;
+      a_y[i] = yg * p.sm;
+      a_x[i] = xg * p.sm;
+      a_b[i] = b * p.Hs * p.Ws;
+    } else {
+      a_y[i] = -(1 << 28);  // forces out-of-bounds
+      a_x[i] = 0;
+      a_b[i] = 0;
+    }
+  }
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int v = -1;
+    if (m < M) {
+      const int xg = m % p.Wg, t = m / p.Wg;
+      const int yg = t % p.Hg, b = t / p.Hg;
+      v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
+    }
+    pix[tid] = v;
+  }
+
+  // ---- K walker for the quad column this thread loads (A, and B when K-contiguous)
+  int q_tap, q_c4, q_ty, q_tx;
+  {
+    const unsigned q = (unsigned)kt0 * 8u + (unsigned)kq;
+    q_tap = (int)(q / (unsigned)Cq);
+    q_c4 = (int)(q - (unsigned)q_tap * (unsigned)Cq);
+    q_ty = q_tap / tc.ntx;
+    q_tx = q_tap - q_ty * tc.ntx;
+  }
+
+  float4 ra[AR], rb[BR];
+
+  auto load_tile = [&](int kt) {
+    // A: gathered source rows
+    const bool kvalid = q_tap < ntaps;
+    const int dy = tc.dy0 + q_ty * p.dstep, dx = tc.dx0 + q_tx * p.dstep;
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+      const int y = a_y[i] + dy, x = a_x[i] + dx;
+      const bool inb = kvalid && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+      ra[i] = inb ? ldg4(p.src + (size_t)(a_b[i] + y * p.Ws + x) * p.lds + q_c4 * 4) : make_float4(0, 0, 0, 0);
+    }
+    if constexpr (B_NK) {
+      const int widx = (tc.ky0 + q_ty * p.kstep) * p.KW + tc.kx0 + q_tx * p.kstep;
+#pragma unroll
+      for (int i = 0; i < BR; i++) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        rb[i] = (kvalid && n < p.N) ? ldg4(p.w + ((size_t)widx * p.N + n) * p.Cs + q_c4 * 4) : make_float4(0, 0, 0, 0);
+      }
+    } else {
+      const int nq = tid % BQ;
+      const int n = n0 + nq * 4;
+#pragma unroll
+      for (int i = 0; i < BR; i++) {
+        const unsigned kk = (unsigned)kt * BK + (unsigned)(tid / BQ) + (unsigned)(BKSTEP * i);
+        const unsigned tap = fast_div(kk, p.cs_magic);
+        const unsigned c = kk - tap * (unsigned)p.Cs;
+        const unsigned ty = tap / (unsigned)tc.ntx, tx = tap - ty * (unsigned)tc.ntx;
+        const int widx = (tc.ky0 + (int)ty * p.kstep) * p.KW + tc.kx0 + (int)tx * p.kstep;
+        rb[i] = ((int)kk < Ktot && n < p.N) ? ldg4(p.w + ((size_t)widx * p.Cs + c) * p.N + n) : make_float4(0, 0, 0, 0);
+      }
+    }
+    // advance the quad walker by one K-tile (8 quads)
+    q_c4 += 8;
+    while (q_c4 >= Cq) {
+      q_c4 -= Cq;
+      q_tap++;
+      if (++q_tx == tc.ntx) { q_tx = 0; q_ty++; }
+    }
+  };
+
+  auto store_tile = [&](int stage) {
+    float* a = As + stage * A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+      float* d = a + ((tid >> 3) + 32 * i) * LDK + kq * 4;
+      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+    }
+    float* bsm = Bs + stage * B_ELEMS;
+    if constexpr (B_NK) {
+#pragma unroll
+      for (int i = 0; i < BR; i++) {
+        float* d = bsm + ((tid >> 3) + 32 * i) * LDK + kq * 4;
+        d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BR; i++)
+        *reinterpret_cast<float4*>(bsm + ((tid / BQ) + BKSTEP * i) * BN + (tid % BQ) * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int stage = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+    const float* a = As + stage * A_ELEMS + (wm * WM + l31) * LDK + lh;
+    const float* b = B_NK ? Bs + stage * B_ELEMS + (wn * WN + l31) * LDK + lh
+                          : Bs + stage * B_ELEMS + lh * BN + wn * WN + l31;
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) av[i] = a[i * 32 * LDK + 2 * s];
+#pragma unroll
+      for (int j = 0; j < TN; j++) bv[j] = B_NK ? b[j * 32 * LDK + 2 * s] : b[2 * s * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool to_partial = p.nsplit > 1;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int px = pix[row];
+      if (px < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        if (to_partial) {
+          p.partial[((size_t)split * ((size_t)p.B * p.Hd * p.Wd) + px) * p.N + n] = v;
+        } else {
+          if (p.bias) v += p.bias[n];
+          if (p.leaky) v = leaky_relu(v);
+          float* d = p.dst + (size_t)px * p.ldd + n;
+          if (p.accumulate) v += *d;
+          if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
+          *d = v;
+        }
+      }
+    }
+}
+
+// Fixed-order sum of the split-K partials + the epilogue.
+__global__ void splitk_reduce_epilogue_kernel(const GatherParams p) {
+  const size_t npix = (size_t)p.B * p.Hd * p.Wd;
+  const size_t total = npix * p.N;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = e / p.N;
+    const int n = (int)(e - px * p.N);
+    float v = 0.f;
+    for (int s = 0; s < p.nsplit; s++) v += p.partial[(size_t)s * total + e];
+    if (p.bias) v += p.bias[n];
+    if (p.leaky) v = leaky_relu(v);
+    float* d = p.dst + px * p.ldd + n;
+    if (p.accumulate) v += *d;
+    if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[px * p.ld_act + n]);
+    *d = v;
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradParams {
+  const float* src;  // gathered operand [B,Hs,Ws,lds], channels a
+  const float* dst;  // dense operand   [B,Hg,Wg,ldd], channels b
+  float* out;        // dW [(tap,a)][b] (ld = Cb) when nsplit == 1
+  float* partial;    // [nsplit][Mp][Cb] otherwise
+  int lds, ldd;
+  int B, Hg, Wg, Hs, Ws, sm;
+  int KH, KW, dy0, dx0;  // tap (ky,kx) -> offset dy0 + ky
+  int Ca, Cb;
+  int nsplit;
+  unsigned ca_magic;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN;
+  constexpr int AQ = BM / 4, BQ = BN / 4;
+  constexpr int AR = (BK * AQ) / 256, BR = (BK * BQ) / 256;
+  constexpr int ASTEP = 256 / AQ, BSTEP = 256 / BQ;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int S = p.B * p.Hg * p.Wg;  // reduction length (sites)
+  const int KT = (S + BK - 1) / BK;
+  const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
+  const int kt0 = blockIdx.z * kt_per, kt1 = min(KT, kt0 + kt_per);
+
+  // this thread's (tap, a) quad — fixed
+  const int mm = m0 + (tid % AQ) * 4;
+  const bool m_ok = mm < Mp;
+  const unsigned tap = fast_div((unsigned)mm, p.ca_magic);
+  const int a_ch = mm - (int)tap * p.Ca;
+  const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
+  const int dy = p.dy0 + ky, dx = p.dx0 + kx;
+  const int nb = n0 + (tid % BQ) * 4;
+  const bool n_ok = nb < p.Cb;
+
+  float4 ra[AR], rb[BR];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+      const int s = kt * BK + tid / AQ + ASTEP * i;
+      bool ok = m_ok && s < S;
+      size_t off = 0;
+      if (ok) {
+        const int xg = s % p.Wg, t = s / p.Wg;
+        const int yg = t % p.Hg, b = t / p.Hg;
+        const int y = yg * p.sm + dy, x = xg * p.sm + dx;
+        ok = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+        off = ((size_t)(b * p.Hs + y) * p.Ws + x) * p.lds + a_ch;
+      }
+      ra[i] = ok ? ldg4(p.src + off) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; i++) {
+      const int s = kt * BK + tid / BQ + BSTEP * i;
+      rb[i] = (n_ok && s < S) ? ldg4(p.dst + (size_t)s * p.ldd + nb) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < AR; i++)
+      *reinterpret_cast<float4*>(As + stage * A_ELEMS + (tid / AQ + ASTEP * i) * BM + (tid % AQ) * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; i++)
+      *reinterpret_cast<float4*>(Bs + stage * B_ELEMS + (tid / BQ + BSTEP * i) * BN + (tid % BQ) * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int stage = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+    const float* a = As + stage * A_ELEMS + lh * BM + wm * WM + l31;
+    const float* b = Bs + stage * B_ELEMS + lh * BN + wn * WN + l31;
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) av[i] = a[2 * s * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; j++) bv[j] = b[2 * s * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(stage ^ 1);
+    __syncthreads();
+  }
+
+  float* o = p.nsplit > 1 ? p.partial + (size_t)blockIdx.z * Mp * p.Cb : p.out;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= Mp) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n < p.Cb) o[(size_t)m * p.Cb + n] = acc[i][j][r];
+      }
+    }
+}
+
+// out[e] = sum_s partial[s][e], fixed order.
+__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n, int nsplit) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < nsplit; s++) v += partial[(size_t)s * n + e];
+    out[e] = v;
+  }
+}
+
+// Column sums of a [npix, C] slice (bias gradients): block = 64 columns x 4 row-lanes.
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, long npix, int C,
+                                      float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long rows_per = (npix + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * rows_per, r1 = min(npix, r0 + rows_per);
+  float s = 0.f;
+  if (col < C)
+    for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + col];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    partial[(size_t)blockIdx.y * C + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ skinny kernels (Cout <= 4: flow heads)
+struct SkinnyParams {
+  const float* x; int ldx;
+  const float* w;       // [k,k,Cin,CO]
+  const float* bias;
+  float* y; int ldy;
+  int B, H, W, Cin, k, pt, pl;  // stride 1 'SAME'
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void skinny_conv_fwd_kernel(const SkinnyParams p) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long npix = (long)p.B * p.H * p.W;
+  const int Cq = p.Cin >> 2, nq = p.k * p.k * Cq;
+  for (long pxl = wave; pxl < npix; pxl += nwaves) {
+    const int ox = (int)(pxl % p.W), oy = (int)((pxl / p.W) % p.H);
+    const long b = pxl / ((long)p.W * p.H);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; c++) acc[c] = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const int tap = q / Cq, c4 = q - tap * Cq;
+      const int ky = tap / p.k, kx = tap - ky * p.k;
+      const int iy = oy - p.pt + ky, ix = ox - p.pl + kx;
+      if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+      const float4 xv = ldg4(p.x + ((b * p.H + iy) * p.W + ix) * p.ldx + c4 * 4);
+      const float* wp = p.w + ((size_t)tap * p.Cin + c4 * 4) * CO;
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < CO; c++) acc[c] += xs[j] * wp[j * CO + c];
+    }
+#pragma unroll
+    for (int c = 0; c < CO; c++) acc[c] = wave_sum(acc[c]);
+    if (lane == 0)
+#pragma unroll
+      for (int c = 0; c < CO; c++) p.y[pxl * p.ldy + c] = acc[c] + (p.bias ? p.bias[c] : 0.f);
+  }
+}
+
+struct SkinnyBwdParams {
+  const float* dz; int lddz;   // [B,H,W,lddz], CO channels
+  const float* w;              // [k,k,Cin,CO]
+  float* dx; int lddx;
+  const float* act_src; int ld_act, act_lo, act_hi;
+  int accumulate;
+  int B, H, W, Cin, k, pt, pl;
+};
+
+// dx[pix, ci] (+)= sum_tap sum_co dz[pix + pad - tap, co] * w[tap, ci, co]; thread = (pixel, ci-quad).
+template <int CO>
+__global__ __launch_bounds__(256) void skinny_conv_dgrad_kernel(const SkinnyBwdParams p) {
+  const int Cq = p.Cin >> 2;
+  const long total = (long)p.B * p.H * p.W * Cq;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long pxl = e / Cq;
+    const int c4 = (int)(e - pxl * Cq);
+    const int ix = (int)(pxl % p.W), iy = (int)((pxl / p.W) % p.H);
+    const long b = pxl / ((long)p.W * p.H);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < p.k; ky++) {
+      const int oy = iy + p.pt - ky;
+      if ((unsigned)oy >= (unsigned)p.H) continue;
+      for (int kx = 0; kx < p.k; kx++) {
+        const int ox = ix + p.pl - kx;
+        if ((unsigned)ox >= (unsigned)p.W) continue;
+        const float* dzp = p.dz + ((b * p.H + oy) * p.W + ox) * p.lddz;
+        const float* wp = p.w + ((size_t)(ky * p.k + kx) * p.Cin + c4 * 4) * CO;
+#pragma unroll
+        for (int c = 0; c < CO; c++) {
+          const float g = dzp[c];
+#pragma unroll
+          for (int j = 0; j < 4; j++) a[j] += g * wp[j * CO + c];
+        }
+      }
+    }
+    float* d = p.dx + pxl * p.lddx + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float v = a[j];
+      const int n = c4 * 4 + j;
+      if (p.accumulate) v += d[j];
+      if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[pxl * p.ld_act + n]);
+      d[j] = v;
+    }
+  }
+}
+
+// dw[tap, ci, co] partials: wave = 64 ci-quads, loops over a chunk of INPUT pixels, each pixel's
+// x quad is read once and scattered into all k*k taps (k == 3 only).
+struct SkinnyWgradParams {
+  const float* x; int ldx;
+  const float* dz; int lddz;
+  float* partial;  // [nchunk][9][Cin][CO]
+  int B, H, W, Cin, pt, pl;
+};
+
+template <int CO>
+__global__ __launch_bounds__(64) void skinny_conv_wgrad3_kernel(const SkinnyWgradParams p) {
+  const int Cq = p.Cin >> 2;
+  const int c4 = blockIdx.x * 64 + threadIdx.x;
+  const long npix = (long)p.B * p.H * p.W;
+  const long per = (npix + gridDim.y - 1) / gridDim.y;
+  const long p0 = blockIdx.y * per, p1 = min(npix, p0 + per);
+  float acc[9][4][CO];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int c = 0; c < CO; c++) acc[t][j][c] = 0.f;
+  const bool active = c4 < Cq;
+  for (long pxl = p0; pxl < p1; pxl++) {
+    const int ix = (int)(pxl % p.W), iy = (int)((pxl / p.W) % p.H);
+    const long b = pxl / ((long)p.W * p.H);
+    float4 xv = make_float4(0, 0, 0, 0);
+    if (active) xv = ldg4(p.x + pxl * p.ldx + c4 * 4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int oy = iy + p.pt - ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int ox = ix + p.pl - kx;
+        if ((unsigned)oy < (unsigned)p.H && (unsigned)ox < (unsigned)p.W) {  // wave-uniform
+          const float* dzp = p.dz + ((b * p.H + oy) * p.W + ox) * p.lddz;
+#pragma unroll
+          for (int c = 0; c < CO; c++) {
+            const float g = dzp[c];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[ky * 3 + kx][j][c] += xs[j] * g;
+          }
+        }
+      }
+    }
+  }
+  if (active) {
+    float* o = p.partial + (size_t)blockIdx.y * 9 * p.Cin * CO;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int c = 0; c < CO; c++) o[((size_t)t * p.Cin + c4 * 4 + j) * CO + c] = acc[t][j][c];
+  }
+}
+
+// ------------------------------------------------------------------ tiny deconv (flowN_upM: 2 -> 2 channels, k4 s2)
+// y[b,oy,ox,co] = bias + sum over the <=4 valid taps: oy = 2*iy + ky - 1.
+template <int CI, int CO>
+__global__ void tiny_deconv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                       const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int H,
+                                       int W) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long n = (long)B * OH * OW;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % OW), oy = (int)((e / OW) % OH);
+    const long b = e / ((long)OW * OH);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; c++) acc[c] = bias ? bias[c] : 0.f;
+    for (int ky = (oy + 1) & 1; ky < 4; ky += 2) {
+      const int iy = (oy + 1 - ky) >> 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = (ox + 1) & 1; kx < 4; kx += 2) {
+        const int ix = (ox + 1 - kx) >> 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float* xp = x + ((b * H + iy) * W + ix) * ldx;
+        const float* wp = w + (ky * 4 + kx) * CO * CI;
+#pragma unroll
+        for (int co = 0; co < CO; co++)
+#pragma unroll
+          for (int ci = 0; ci < CI; ci++) acc[co] += xp[ci] * wp[co * CI + ci];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; c++) y[e * ldy + c] = acc[c];
+  }
+}
+
+template <int CI, int CO>
+__global__ void tiny_deconv_dgrad_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ w,
+                                         float* __restrict__ dx, int lddx, int accumulate, int B, int H, int W) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long n = (long)B * H * W;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(e % W), iy = (int)((e / W) % H);
+    const long b = e / ((long)W * H);
+    float acc[CI];
+#pragma unroll
+    for (int c = 0; c < CI; c++) acc[c] = 0.f;
+    for (int ky = 0; ky < 4; ky++) {
+      const int oy = 2 * iy + ky - 1;
+      if ((unsigned)oy >= (unsigned)OH) continue;
+      for (int kx = 0; kx < 4; kx++) {
+        const int ox = 2 * ix + kx - 1;
+        if ((unsigned)ox >= (unsigned)OW) continue;
+        const float* gp = dz + ((b * OH + oy) * OW + ox) * lddz;
+        const float* wp = w + (ky * 4 + kx) * CO * CI;
+#pragma unroll
+        for (int co = 0; co < CO; co++)
+#pragma unroll
+          for (int ci = 0; ci < CI; ci++) acc[ci] += gp[co] * wp[co * CI + ci];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CI; c++) {
+      float* d = dx + e * lddx + c;
+      *d = accumulate ? *d + acc[c] : acc[c];
+    }
+  }
+}
+
+// dw[ky,kx,co,ci] partial sums per block -> partial[block][16*CO*CI]
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ dz, int lddz,
+                                                                float* __restrict__ partial, int B, int H, int W) {
+  __shared__ float red[4];
+  const int OH = 2 * H, OW = 2 * W;
+  const long n = (long)B * H * W;
+  float acc[16][CO][CI];
+#pragma unroll
+  for (int t = 0; t < 16; t++)
+#pragma unroll
+    for (int a = 0; a < CO; a++)
+#pragma unroll
+      for (int c = 0; c < CI; c++) acc[t][a][c] = 0.f;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(e % W), iy = (int)((e / W) % H);
+    const long b = e / ((long)W * H);
+    float xv[CI];
+#pragma unroll
+    for (int c = 0; c < CI; c++) xv[c] = x[e * ldx + c];
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++) {
+      const int oy = 2 * iy + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 4; kx++) {
+        const int ox = 2 * ix + kx - 1;
+        if ((unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW) {
+          const float* gp = dz + ((b * OH + oy) * OW + ox) * lddz;
+#pragma unroll
+          for (int co = 0; co < CO; co++)
+#pragma unroll
+            for (int ci = 0; ci < CI; ci++) acc[ky * 4 + kx][co][ci] += gp[co] * xv[ci];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; t++)
+#pragma unroll
+    for (int a = 0; a < CO; a++)
+#pragma unroll
+      for (int c = 0; c < CI; c++) {
+        const float s = block_sum(acc[t][a][c], red);
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 16 * CO * CI + (t * CO + a) * CI + c] = s;
+      }
+}
+
+__global__ void leaky_bwd_inplace_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                         long npix, int C) {
+  const long n = npix * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const long px = e / C;
+    const int c = (int)(e - px * C);
+    dy[px * lddy + c] *= leaky_grad_from_out(y[px * ldy + c]);
+  }
+}
+
+// ------------------------------------------------------------------ host side
+inline void same_pads(int in, int k, int s, int* before, int* out) {
+  const int o = (in + s - 1) / s;
+  int total = (o - 1) * s + k - in;
+  if (total < 0) total = 0;
+  *before = total / 2;
+  *out = o;
+}
+
+inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+
+// ---- geometry builders (shared by the launchers and the workspace query)
+inline void build_conv_fwd(GatherParams& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
+  p.dstep = 1; p.kstep = 1; p.KW = k; p.Cs = Cin; p.N = Cout;
+  p.Hd = Ho; p.Wd = Wo; p.so = 1; p.ncls = 1;
+  p.cls[0] = TapClass{k, k, -pt, -pl, 0, 0, 0, 0};
+}
+
+inline int build_conv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  p.B = B; p.Hs = Ho; p.Ws = Wo; p.sm = 1;
+  p.dstep = -1; p.KW = k; p.Cs = Cout; p.N = Cin;
+  p.Hd = H; p.Wd = W;
+  if (stride == 1) {
+    p.Hg = H; p.Wg = W; p.so = 1; p.ncls = 1; p.kstep = 1;
+    p.cls[0] = TapClass{k, k, pt, pl, 0, 0, 0, 0};
+    return UNFLOW_OK;
+  }
+  // input pixel (2*yg+py): contributing taps ky == (py+pt) mod 2, source row yg + (py+pt-ky)/2
+  if (H % 2 != 0 || W % 2 != 0) return UNFLOW_ERR_UNSUPPORTED;
+  p.Hg = H / 2; p.Wg = W / 2; p.so = 2; p.ncls = 4; p.kstep = 2;
+  for (int c = 0; c < 4; c++) {
+    const int py = c >> 1, px = c & 1;
+    const int ky0 = (py + pt) & 1, kx0 = (px + pl) & 1;
+    const int nty = ky0 < k ? (k - ky0 + 1) / 2 : 0, ntx = kx0 < k ? (k - kx0 + 1) / 2 : 0;
+    if (nty == 0 || ntx == 0) return UNFLOW_ERR_UNSUPPORTED;
+    p.cls[c] = TapClass{nty, ntx, (py + pt - ky0) / 2, (px + pl - kx0) / 2, ky0, kx0, py, px};
+  }
+  return UNFLOW_OK;
+}
+
+// conv_transpose k4 s2 'SAME': oy = 2*iy + ky - 1
+inline void build_deconv_fwd(GatherParams& p, int B, int H, int W, int Cin, int Cout) {
+  p.B = B; p.Hg = H; p.Wg = W; p.Hs = H; p.Ws = W; p.sm = 1;
+  p.dstep = -1; p.kstep = 2; p.KW = 4; p.Cs = Cin; p.N = Cout;
+  p.Hd = 2 * H; p.Wd = 2 * W; p.so = 2; p.ncls = 4;
+  for (int c = 0; c < 4; c++) {
+    const int py = c >> 1, px = c & 1;
+    const int ky0 = (py + 1) & 1, kx0 = (px + 1) & 1;
+    p.cls[c] = TapClass{2, 2, (py + 1 - ky0) / 2, (px + 1 - kx0) / 2, ky0, kx0, py, px};
+  }
+}
+
+inline void build_deconv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int Cout) {
+  p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
+  p.dstep = 1; p.kstep = 1; p.KW = 4; p.Cs = Cout; p.N = Cin;
+  p.Hd = H; p.Wd = W; p.so = 1; p.ncls = 1;
+  p.cls[0] = TapClass{4, 4, -1, -1, 0, 0, 0, 0};
+}
+
+inline void build_conv_wgrad(WgradParams& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
+  p.KH = k; p.KW = k; p.dy0 = -pt; p.dx0 = -pl; p.Ca = Cin; p.Cb = Cout;
+}
+
+// dW[ky,kx,co,ci] = sum_{input sites} dz[2iy+ky-1, 2ix+kx-1, co] * x[iy,ix,ci]
+inline void build_deconv_wgrad(WgradParams& p, int B, int H, int W, int Cin, int Cout) {
+  p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
+  p.KH = 4; p.KW = 4; p.dy0 = -1; p.dx0 = -1; p.Ca = Cout; p.Cb = Cin;
+}
+
+// ---- planners
+struct GatherPlan {
+  int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
+  int nsplit;
+};
+
+inline GatherPlan plan_gather(const GatherParams& p) {
+  GatherPlan pl;
+  const long M = (long)p.B * p.Hg * p.Wg;
+  if (p.N <= 32) pl.cfg = 2;
+  else if (p.N <= 64) pl.cfg = 1;
+  else pl.cfg = 0;
+  if (pl.cfg == 0 && ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls < 192) pl.cfg = 2;  // small: more, smaller tiles
+  const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
+  const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
+  int maxtaps = 0;
+  for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
+  const int KT = (maxtaps * p.Cs + BK - 1) / BK;
+  int ns = 1;
+  if (blocks < 512) {
+    ns = (int)((768 + blocks - 1) / blocks);
+    const int max_by_k = KT / 8 > 0 ? KT / 8 : 1;  // keep >= 8 K-tiles per split
+    if (ns > max_by_k) ns = max_by_k;
+    if (ns > 16) ns = 16;
+    if (ns < 1) ns = 1;
+  }
+  pl.nsplit = ns;
+  return pl;
+}
+
+inline size_t gather_partial_bytes(const GatherParams& p, int nsplit) {
+  return nsplit > 1 ? (size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
+}
+
+inline int plan_wgrad(const WgradParams& p) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int bn = p.Cb <= 64 ? 64 : 128;
+  const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
+  const long S = (long)p.B * p.Hg * p.Wg;
+  const int KT = (int)((S + BK - 1) / BK);
+  int ns = 1;
+  if (blocks < 512) {
+    ns = (int)((1024 + blocks - 1) / blocks);
+    const int max_by_k = KT / 4 > 0 ? KT / 4 : 1;
+    if (ns > max_by_k) ns = max_by_k;
+    if (ns > 256) ns = 256;
+  }
+  return ns;
+}
+
+inline size_t wgrad_partial_bytes(const WgradParams& p, int nsplit) {
+  return nsplit > 1 ? (size_t)nsplit * p.KH * p.KW * p.Ca * p.Cb * sizeof(float) : 0;
+}
+
+constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)256 * C * sizeof(float) + 512; }
+
+// ---- launchers
+template <int BM, int BN, int WM, int WN, bool B_NK>
+int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
+  const int M = p.B * p.Hg * p.Wg;
+  constexpr int A_ELEMS = BM * LDK;
+  constexpr int B_ELEMS = B_NK ? BN * LDK : BK * BN;
+  const size_t smem = (2 * A_ELEMS + 2 * B_ELEMS) * sizeof(float) + BM * sizeof(int);
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
+  igemm_gather_kernel<BM, BN, WM, WN, B_NK><<<grid, 256, smem, st>>>(p);
+  return launch_status();
+}
+
+template <bool B_NK>
+int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
+  p.cs_magic = magic_u32((unsigned)p.Cs);
+  const GatherPlan pl = plan_gather(p);
+  p.nsplit = pl.nsplit;
+  p.partial = nullptr;
+  if (p.nsplit > 1) {
+    if (!ws || ws_bytes < gather_partial_bytes(p, p.nsplit)) p.nsplit = 1;  // no scratch: un-split (slower, same result up to fp32 order)
+    else p.partial = reinterpret_cast<float*>(ws);
+  }
+  int code;
+  switch (pl.cfg) {
+    case 0: code = launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st); break;
+    case 1: code = launch_gather_cfg<128, 64, 64, 32, B_NK>(p, st); break;
+    default: code = launch_gather_cfg<64, 64, 32, 32, B_NK>(p, st); break;
+  }
+  if (code != UNFLOW_OK) return code;
+  if (p.nsplit > 1) {
+    const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
+    splitk_reduce_epilogue_kernel<<<stream_grid((long)total), 256, 0, st>>>(p);
+    return launch_status();
+  }
+  return UNFLOW_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_wgrad_cfg(const WgradParams& p, hipStream_t st) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const size_t smem = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM, BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
+  igemm_wgrad_kernel<BM, BN, WM, WN><<<grid, 256, smem, st>>>(p);
+  return launch_status();
+}
+
+// returns bytes of workspace consumed through *used
+int run_wgrad(WgradParams& p, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
+  p.ca_magic = magic_u32((unsigned)p.Ca);
+  const size_t wsize = (size_t)p.KH * p.KW * p.Ca * p.Cb;
+  int ns = plan_wgrad(p);
+  if (ns > 1 && (!ws || ws_bytes < wgrad_partial_bytes(p, ns))) {
+    ns = ws ? (int)(ws_bytes / (wsize * sizeof(float))) : 1;
+    if (ns < 1) ns = 1;
+  }
+  p.nsplit = ns;
+  p.partial = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
+  *used = wgrad_partial_bytes(p, ns);
+  const int code = p.Cb <= 64 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st) : launch_wgrad_cfg<128, 128, 64, 64>(p, st);
+  if (code != UNFLOW_OK) return code;
+  if (ns > 1) {
+    sum_partials_kernel<<<stream_grid((long)wsize), 256, 0, st>>>(p.partial, p.out, wsize, ns);
+    return launch_status();
+  }
+  return UNFLOW_OK;
+}
+
+// bias gradient: column sums of dz [npix, C]; scratch placed after `ws_used` bytes of the workspace.
+int run_colsum(const float* dz, int ld, long npix, int C, float* out, void* ws, size_t ws_bytes, size_t ws_used,
+               hipStream_t st) {
+  int chunks = (int)min((long)256, max((long)1, npix / 64));
+  float* part = nullptr;
+  const size_t need = (size_t)chunks * C * sizeof(float);
+  const size_t off = (ws_used + 255) & ~(size_t)255;
+  if (ws && ws_bytes >= off + need) part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + off);
+  else chunks = 1;
+  dim3 grid(cdiv(C, 64), chunks);
+  colsum_partial_kernel<<<grid, 256, 0, st>>>(dz, ld, npix, C, chunks == 1 ? out : part);
+  if (chunks > 1) sum_partials_kernel<<<stream_grid(C), 256, 0, st>>>(part, out, (size_t)C, chunks);
+  return launch_status();
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+UNFLOW_API size_t unflow_conv_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  // Exact requirement of the fwd / bwd_data / bwd_filter entry points of a conv2d with these dims
+  // (and, for k == 4 && stride == 2, of the conv2d_transpose whose OUTPUT is [B,H,W,Cout]).
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return 0;
+  size_t need = 4096;
+  const int cmax = max(Cin, Cout);
+  if (Cout <= 4 || Cin < 4) {
+    // skinny kernels: wgrad partials [<=256][k*k*Cin*Cout]
+    need = max(need, (size_t)256 * k * k * max(Cin, 4) * max(Cout, 2) * sizeof(float));
+  } else {
+    GatherParams g{};
+    build_conv_fwd(g, B, H, W, Cin, Cout, k, stride);
+    need = max(need, gather_partial_bytes(g, plan_gather(g).nsplit));
+    GatherParams d{};
+    if ((stride == 1 || stride == 2) && build_conv_dgrad(d, B, H, W, Cin, Cout, k, stride) == UNFLOW_OK)
+      need = max(need, gather_partial_bytes(d, plan_gather(d).nsplit));
+    WgradParams w{};
+    build_conv_wgrad(w, B, H, W, Cin, Cout, k, stride);
+    need = max(need, wgrad_partial_bytes(w, plan_wgrad(w)));
+    if (k == 4 && stride == 2 && H % 2 == 0 && W % 2 == 0) {
+      GatherParams tf{};
+      build_deconv_fwd(tf, B, H / 2, W / 2, Cin, Cout);
+      need = max(need, gather_partial_bytes(tf, plan_gather(tf).nsplit));
+      GatherParams td{};
+      build_deconv_dgrad(td, B, H / 2, W / 2, Cin, Cout);
+      need = max(need, gather_partial_bytes(td, plan_gather(td).nsplit));
+      WgradParams tw{};
+      build_deconv_wgrad(tw, B, H / 2, W / 2, Cin, Cout);
+      need = max(need, wgrad_partial_bytes(tw, plan_wgrad(tw)));
+    }
+  }
+  return need + COLSUM_SCRATCH_BYTES(cmax) + 1024;
+}
+
+UNFLOW_API int unflow_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B,
+                                 int H, int W, int Cin, int Cout, int k, int stride, int leaky, void* workspace,
+                                 size_t workspace_bytes, unflow_stream_t stream) {
+  if (!x || !w || !y) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
+  if (Cin % 4 != 0 || ldx % 4 != 0 || ldx < Cin || ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  if (Cout <= 4) {
+    if (stride != 1 || leaky) return UNFLOW_ERR_UNSUPPORTED;
+    int pt, pl, Ho, Wo;
+    same_pads(H, k, 1, &pt, &Ho);
+    same_pads(W, k, 1, &pl, &Wo);
+    SkinnyParams p{x, ldx, w, bias, y, ldy, B, H, W, Cin, k, pt, pl};
+    const long waves = (long)B * H * W;
+    const int grid = (int)min((long)4096, (waves + 3) / 4);
+    if (Cout == 2) skinny_conv_fwd_kernel<2><<<grid, 256, 0, st>>>(p);
+    else if (Cout == 1) skinny_conv_fwd_kernel<1><<<grid, 256, 0, st>>>(p);
+    else if (Cout == 4) skinny_conv_fwd_kernel<4><<<grid, 256, 0, st>>>(p);
+    else return UNFLOW_ERR_UNSUPPORTED;
+    return launch_status();
+  }
+  if (Cout % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
+  GatherParams p{};
+  build_conv_fwd(p, B, H, W, Cin, Cout, k, stride);
+  p.src = x; p.w = w; p.bias = bias; p.dst = y; p.act_src = nullptr;
+  p.lds = ldx; p.ldd = ldy; p.leaky = leaky; p.accumulate = 0;
+  return run_gather<false>(p, workspace, workspace_bytes, st);
+}
+
+UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H,
+                                      int W, int Cin, int Cout, int k, int stride, int accumulate,
+                                      const float* act_src, int ld_act, int act_lo, int act_hi, void* workspace,
+                                      size_t workspace_bytes, unflow_stream_t stream) {
+  if (!dz || !w || !dx) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || (stride != 1 && stride != 2)) return UNFLOW_ERR_SHAPE;
+  if (Cin % 4 != 0 || lddx < Cin || lddz < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  if (Cout <= 4) {
+    if (stride != 1) return UNFLOW_ERR_UNSUPPORTED;
+    int pt, pl, Ho, Wo;
+    same_pads(H, k, 1, &pt, &Ho);
+    same_pads(W, k, 1, &pl, &Wo);
+    SkinnyBwdParams p{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, k, pt, pl};
+    const long total = (long)B * H * W * (Cin / 4);
+    if (Cout == 2) skinny_conv_dgrad_kernel<2><<<stream_grid(total), 256, 0, st>>>(p);
+    else if (Cout == 1) skinny_conv_dgrad_kernel<1><<<stream_grid(total), 256, 0, st>>>(p);
+    else if (Cout == 4) skinny_conv_dgrad_kernel<4><<<stream_grid(total), 256, 0, st>>>(p);
+    else return UNFLOW_ERR_UNSUPPORTED;
+    return launch_status();
+  }
+  if (Cout % 4 != 0 || lddz % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
+  GatherParams p{};
+  const int bc = build_conv_dgrad(p, B, H, W, Cin, Cout, k, stride);
+  if (bc != UNFLOW_OK) return bc;
+  p.src = dz; p.w = w; p.bias = nullptr; p.dst = dx; p.act_src = act_src;
+  p.lds = lddz; p.ldd = lddx; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
+  p.leaky = 0; p.accumulate = accumulate;
+  return run_gather<true>(p, workspace, workspace_bytes, st);
+}
+
+UNFLOW_API int unflow_conv2d_bwd_filter(const float* x, int ldx, const float* dz, int lddz, float* dw, float* dbias,
+                                        int B, int H, int W, int Cin, int Cout, int k, int stride, void* workspace,
+                                        size_t workspace_bytes, unflow_stream_t stream) {
+  if (!x || !dz || !dw) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
+  if (Cin % 4 != 0 || ldx % 4 != 0 || ldx < Cin || lddz < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  hipStream_t st = as_stream(stream);
+  size_t used = 0;
+  if (Cout <= 4) {
+    if (stride != 1 || k != 3 || Cout != 2) return UNFLOW_ERR_UNSUPPORTED;
+    const long npix = (long)B * H * W;
+    const int chunks = (int)min((long)256, max((long)1, npix / 32));
+    const size_t wsz = (size_t)9 * Cin * Cout;
+    if (!workspace || workspace_bytes < (size_t)chunks * wsz * sizeof(float)) return UNFLOW_ERR_WORKSPACE;
+    SkinnyWgradParams p{x, ldx, dz, lddz, reinterpret_cast<float*>(workspace), B, H, W, Cin, pt, pl};
+    dim3 grid(cdiv(Cin / 4, 64), chunks);
+    skinny_conv_wgrad3_kernel<2><<<grid, 64, 0, st>>>(p);
+    sum_partials_kernel<<<stream_grid((long)wsz), 256, 0, st>>>(p.partial, dw, wsz, chunks);
+    used = (size_t)chunks * wsz * sizeof(float);
+  } else {
+    if (Cout % 4 != 0 || lddz % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
+    WgradParams p{};
+    build_conv_wgrad(p, B, H, W, Cin, Cout, k, stride);
+    p.src = x; p.dst = dz; p.out = dw; p.lds = ldx; p.ldd = lddz;
+    const int code = run_wgrad(p, workspace, workspace_bytes, &used, st);
+    if (code != UNFLOW_OK) return code;
+  }
+  if (dbias) return run_colsum(dz, lddz, (long)B * Ho * Wo, Cout, dbias, workspace, workspace_bytes, used, st);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
+                                           int ldy, int B, int H, int W, int Cin, int Cout, int leaky, void* workspace,
+                                           size_t workspace_bytes, unflow_stream_t stream) {
+  if (!x || !w || !y) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  if (Cin == 2 && Cout == 2) {
+    if (leaky) return UNFLOW_ERR_UNSUPPORTED;
+    tiny_deconv_fwd_kernel<2, 2><<<stream_grid((long)B * 4 * H * W), 256, 0, st>>>(x, ldx, w, bias, y, ldy, B, H, W);
+    return launch_status();
+  }
+  if (Cin % 4 != 0 || ldx % 4 != 0 || ldx < Cin || ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  GatherParams p{};
+  build_deconv_fwd(p, B, H, W, Cin, Cout);
+  p.src = x; p.w = w; p.bias = bias; p.dst = y; p.act_src = nullptr;
+  p.lds = ldx; p.ldd = ldy; p.leaky = leaky; p.accumulate = 0;
+  return run_gather<true>(p, workspace, workspace_bytes, st);
+}
+
+UNFLOW_API int unflow_conv2d_transpose_bwd_data(const float* dz, int lddz, const float* w, float* dx, int lddx, int B,
+                                                int H, int W, int Cin, int Cout, int accumulate, const float* act_src,
+                                                int ld_act, int act_lo, int act_hi, void* workspace,
+                                                size_t workspace_bytes, unflow_stream_t stream) {
+  if (!dz || !w || !dx) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  if (Cin == 2 && Cout == 2) {
+    if (act_src) return UNFLOW_ERR_UNSUPPORTED;
+    tiny_deconv_dgrad_kernel<2, 2><<<stream_grid((long)B * H * W), 256, 0, st>>>(dz, lddz, w, dx, lddx, accumulate, B, H, W);
+    return launch_status();
+  }
+  if (Cout % 4 != 0 || Cin % 4 != 0 || lddz % 4 != 0 || lddz < Cout || lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
+  GatherParams p{};
+  build_deconv_dgrad(p, B, H, W, Cin, Cout);
+  p.src = dz; p.w = w; p.bias = nullptr; p.dst = dx; p.act_src = act_src;
+  p.lds = lddz; p.ldd = lddx; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
+  p.leaky = 0; p.accumulate = accumulate;
+  return run_gather<false>(p, workspace, workspace_bytes, st);
+}
+
+UNFLOW_API int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const float* dz, int lddz, float* dw,
+                                                  float* dbias, int B, int H, int W, int Cin, int Cout, void* workspace,
+                                                  size_t workspace_bytes, unflow_stream_t stream) {
+  if (!x || !dz || !dw) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  size_t used = 0;
+  if (Cin == 2 && Cout == 2) {
+    const int blocks = (int)min((long)128, ((long)B * H * W + 255) / 256);
+    if (!workspace || workspace_bytes < (size_t)blocks * 64 * sizeof(float)) return UNFLOW_ERR_WORKSPACE;
+    float* part = reinterpret_cast<float*>(workspace);
+    tiny_deconv_wgrad_kernel<2, 2><<<blocks, 256, 0, st>>>(x, ldx, dz, lddz, part, B, H, W);
+    sum_partials_kernel<<<1, 64, 0, st>>>(part, dw, 64, blocks);
+    used = (size_t)blocks * 64 * sizeof(float);
+  } else {
+    if (Cout % 4 != 0 || Cin % 4 != 0 || lddz % 4 != 0 || ldx % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
+    WgradParams p{};
+    build_deconv_wgrad(p, B, H, W, Cin, Cout);
+    p.src = dz; p.dst = x; p.out = dw; p.lds = lddz; p.ldd = ldx;
+    const int code = run_wgrad(p, workspace, workspace_bytes, &used, st);
+    if (code != UNFLOW_OK) return code;
+  }
+  if (dbias) return run_colsum(dz, lddz, (long)B * 4 * H * W, Cout, dbias, workspace, workspace_bytes, used, st);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_leaky_bwd_inplace(float* dy, int lddy, const float* y, int ldy, long npix, int C,
+                                        unflow_stream_t stream) {
+  if (!dy || !y) return UNFLOW_ERR_NULL;
+  if (npix <= 0 || C <= 0) return UNFLOW_OK;
+  leaky_bwd_inplace_kernel<<<stream_grid(npix * C), 256, 0, as_stream(stream)>>>(dy, lddy, y, ldy, npix, C);
+  return launch_status();
+}

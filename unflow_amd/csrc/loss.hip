@@ -1,0 +1,302 @@
+// Proxy-loss kernels of the unsupervised step (src/e2eflow/core/losses.py), fused per pyramid level.
+// The reference builds each term from ~15-60 small TF ops (identity-filter conv2d to extract census
+// patches, gathers, pads, pows ...); here each term is one stencil kernel forward and one gather-form
+// kernel backward (no atomics on gradients, no [B,H,W,49] patch tensor).
+//
+// "Directed batch": N = 2B samples, [0,B) forward flow (first = im1, second = im2), [B,2B) backward;
+// the second image of sample n is image (n + pair_shift) % N.
+#include "common.h"
+
+#define CHARB_ALPHA 0.45f
+#define CHARB_EPS 0.001f
+
+// ------------------------------------------------------------------ grayscale
+// tf.image.rgb_to_grayscale weights, then * 255 (losses.py:94).
+__device__ __forceinline__ float gray255(float r, float g, float b) {
+  return ((r * 0.2989f + g * 0.5870f) + b * 0.1140f) * 255.0f;
+}
+
+__global__ void rgb_to_gray255_kernel(const float* __restrict__ im, int ld, float* __restrict__ gray, long npix) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x)
+    gray[i] = gray255(im[i * ld], im[i * ld + 1], im[i * ld + 2]);
+}
+
+UNFLOW_API int unflow_rgb_to_gray255(const float* im, int ld_im, float* gray, long npix, unflow_stream_t stream) {
+  if (!im || !gray) return UNFLOW_ERR_NULL;
+  if (npix <= 0) return UNFLOW_OK;
+  rgb_to_gray255_kernel<<<stream_grid(npix), 256, 0, as_stream(stream)>>>(im, ld_im, gray, npix);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ image_warp (image_warp.py:4-76) + gray, fused
+struct Taps {
+  long ia, ib, ic, id;
+  float xw, yw, wa, wb, wc, wd;
+};
+
+__device__ __forceinline__ Taps iw_taps(int px, int py, float u, float v, int H, int W) {
+  Taps t;
+  const float fu = floorf(u), fv = floorf(v);
+  t.xw = u - fu;
+  t.yw = v - fv;
+  t.wa = (1.f - t.xw) * (1.f - t.yw);
+  t.wb = (1.f - t.xw) * t.yw;
+  t.wc = t.xw * (1.f - t.yw);
+  t.wd = t.xw * t.yw;
+  const int xi = px + (int)fu, yi = py + (int)fv;
+  const int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
+  const int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
+  t.ia = (long)y0 * W + x0;
+  t.ib = (long)y1 * W + x0;
+  t.ic = (long)y0 * W + x1;
+  t.id = (long)y1 * W + x1;
+  return t;
+}
+
+__global__ void warp_gray_fwd_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow,
+                                     float fscale, float* __restrict__ out, int shift, int N, int H, int W) {
+  const long npx = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    const long sb = (long)((n + shift) % N) * H * W;
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
+    const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
+                *pd = im + (sb + t.id) * ld;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = ((t.wa * pa[k] + t.wb * pb[k]) + t.wc * pc[k]) + t.wd * pd[k];
+    out[i] = gray255(c[0], c[1], c[2]);
+  }
+}
+
+__global__ void warp_gray_bwd_kernel(const float* __restrict__ dgray, const float* __restrict__ im, int ld,
+                                     const float* __restrict__ flow, float fscale, float* __restrict__ dflow, int acc,
+                                     int shift, int N, int H, int W) {
+  const long npx = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    const long sb = (long)((n + shift) % N) * H * W;
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
+    const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
+                *pd = im + (sb + t.id) * ld;
+    const float g = dgray[i] * 255.0f;
+    const float gw[3] = {g * 0.2989f, g * 0.5870f, g * 0.1140f};
+    float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      ga += gw[k] * pa[k];
+      gb += gw[k] * pb[k];
+      gc += gw[k] * pc[k];
+      gd += gw[k] * pd[k];
+    }
+    float du = ((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw) * fscale;
+    float dv = ((gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw) * fscale;
+    float2* o = reinterpret_cast<float2*>(dflow) + i;
+    if (acc) {
+      const float2 e = *o;
+      du += e.x;
+      dv += e.y;
+    }
+    *o = make_float2(du, dv);
+  }
+}
+
+UNFLOW_API int unflow_warp_gray_fwd(const float* im, int ld_im, const float* flow, float flow_scale, float* out_gray,
+                                    int pair_shift, int N, int H, int W, unflow_stream_t stream) {
+  if (!im || !flow || !out_gray) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || ld_im < 3) return UNFLOW_ERR_SHAPE;
+  warp_gray_fwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale,
+                                                                                    out_gray, pair_shift, N, H, W);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_warp_gray_bwd(const float* d_gray, const float* im, int ld_im, const float* flow,
+                                    float flow_scale, float* d_flow, int accumulate, int pair_shift, int N, int H,
+                                    int W, unflow_stream_t stream) {
+  if (!d_gray || !im || !flow || !d_flow) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || ld_im < 3) return UNFLOW_ERR_SHAPE;
+  warp_gray_bwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      d_gray, im, ld_im, flow, flow_scale, d_flow, accumulate, pair_shift, N, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ ternary / census loss (losses.py:90-122)
+// t(z) = z / sqrt(0.81 + z^2);  soft Hamming term h(d) = d^2 / (0.1 + d^2), d = t1 - t2.
+__device__ __forceinline__ float census_t(float z) { return z / sqrtf(0.81f + z * z); }
+
+__global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          const float* __restrict__ mask, int n_mask,
+                                                          float* __restrict__ dist_out, float* __restrict__ loss_acc,
+                                                          float scale, int D, int N, int H, int W) {
+  __shared__ float red[4];
+  const long npx = (long)N * H * W;
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long n = i / ((long)W * H);
+    const float* a = g1 + n * H * W;
+    const float* b = g2 + n * H * W;
+    const float c1 = a[(long)y * W + x], c2 = b[(long)y * W + x];
+    float dist = 0.f;
+    // channel order of the identity-filter conv: dy outer, dx inner (losses.py:101-104); SAME zero padding
+    for (int dy = -D; dy <= D; dy++)
+      for (int dx = -D; dx <= D; dx++) {
+        const int yy = y + dy, xx = x + dx;
+        const bool inb = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const float v1 = inb ? a[(long)yy * W + xx] : 0.f, v2 = inb ? b[(long)yy * W + xx] : 0.f;
+        const float d = census_t(v1 - c1) - census_t(v2 - c2);
+        const float d2 = d * d;
+        dist += d2 / (0.1f + d2);
+      }
+    dist_out[i] = dist;
+    const bool interior = y >= D && y < H - D && x >= D && x < W - D;
+    if (interior) {
+      const float m = mask[(n % n_mask) * (long)H * W + (long)y * W + x];
+      local += m * powf(dist * dist + CHARB_EPS * CHARB_EPS, CHARB_ALPHA);
+    }
+  }
+  const float t = block_sum(local, red);
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
+}
+
+// dL/d(dist) at a pixel (0 outside the interior mask)
+__device__ __forceinline__ float ternary_wgt(const float* __restrict__ dist, const float* __restrict__ mask_n, int y,
+                                             int x, int D, int H, int W, float scale) {
+  if (!(y >= D && y < H - D && x >= D && x < W - D)) return 0.f;
+  const float d = dist[(long)y * W + x];
+  const float m = mask_n[(long)y * W + x];
+  return scale * m * CHARB_ALPHA * powf(d * d + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * d;
+}
+
+// Gather form: d/dG2(q) = sum_e f(q, q+e) * (Wt(q+e) + Wt(q)), see DESIGN.md (census backward).
+__global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          const float* __restrict__ mask, int n_mask,
+                                                          const float* __restrict__ dist, float* __restrict__ dg2,
+                                                          float scale, int D, int N, int H, int W) {
+  const long npx = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long n = i / ((long)W * H);
+    const float* a = g1 + n * H * W;
+    const float* b = g2 + n * H * W;
+    const float* dn = dist + n * H * W;
+    const float* mk = mask + (n % n_mask) * (long)H * W;
+    const float q1 = a[(long)y * W + x], q2 = b[(long)y * W + x];
+    const float wq = ternary_wgt(dn, mk, y, x, D, H, W, scale);
+    float grad = 0.f;
+    for (int dy = -D; dy <= D; dy++)
+      for (int dx = -D; dx <= D; dx++) {
+        const int yy = y + dy, xx = x + dx;
+        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+        const float wr = ternary_wgt(dn, mk, yy, xx, D, H, W, scale);
+        const float ws = wr + wq;
+        if (ws == 0.f) continue;
+        // r = q+e as centre with neighbour q: z = G(q) - G(r)
+        const float z1 = q1 - a[(long)yy * W + xx], z2 = q2 - b[(long)yy * W + xx];
+        const float d = census_t(z1) - census_t(z2);
+        const float den = 0.1f + d * d;
+        const float dh = 2.f * d * 0.1f / (den * den);           // dh/dd
+        const float s2 = 0.81f + z2 * z2;
+        const float dt2 = 0.81f / (s2 * sqrtf(s2));             // dt/dz at z2
+        grad += -dh * dt2 * ws;                                  // dd/dt2 = -1, dz2/dG2(q) = +1
+      }
+    dg2[i] = grad;
+  }
+}
+
+UNFLOW_API int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
+                                  float* dist_out, float* loss_acc, float weight, float normalizer, int max_distance,
+                                  int N, int H, int W, unflow_stream_t stream) {
+  if (!gray1 || !gray2w || !mask || !dist_out) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || n_mask <= 0 || max_distance < 0) return UNFLOW_ERR_SHAPE;
+  ternary_fwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      gray1, gray2w, mask, n_mask, dist_out, loss_acc, weight / normalizer, max_distance, N, H, W);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_ternary_bwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
+                                  const float* dist, float* d_gray2w, float weight, float normalizer,
+                                  int max_distance, int N, int H, int W, unflow_stream_t stream) {
+  if (!gray1 || !gray2w || !mask || !dist || !d_gray2w) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || n_mask <= 0 || max_distance < 0) return UNFLOW_ERR_SHAPE;
+  ternary_bwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      gray1, gray2w, mask, n_mask, dist, d_gray2w, weight / normalizer, max_distance, N, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ second-order smoothness (losses.py:258-295)
+// 4 stencils per flow channel: delta_k(p) = f(p+a_k) + f(p-a_k) - 2 f(p), a = (0,1),(1,0),(1,1),(1,-1) [dy,dx];
+// masks (create_mask, :260-263) zero exactly the pixels whose stencil would leave the image.
+// Charbonnier on each, normaliser N_dir*H*W*4 per channel (charbonnier_loss :311-312).
+__device__ __forceinline__ float charb(float x) { return powf(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA); }
+__device__ __forceinline__ float charb_grad(float x) {
+  return CHARB_ALPHA * powf(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * x;
+}
+
+__global__ __launch_bounds__(256) void second_order_kernel(const float* __restrict__ flow, float fs,
+                                                           float* __restrict__ loss_acc, float* __restrict__ dflow,
+                                                           int acc, float scale, int N, int H, int W) {
+  __shared__ float red[4];
+  const long npx = (long)N * H * W;
+  const int ady[4] = {0, 1, 1, 1}, adx[4] = {1, 0, 1, -1};
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long n = i / ((long)W * H);
+    const float2* f = reinterpret_cast<const float2*>(flow) + n * H * W;
+    float gu = 0.f, gv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int dy = ady[k], dx = adx[k];
+      // delta at centre c = q + j*a for j = -1,0,1 is valid iff c +- a are inside the image
+      float2 v[5];
+#pragma unroll
+      for (int j = -2; j <= 2; j++) {
+        const int yy = y + j * dy, xx = x + j * dx;
+        const bool inb = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        float2 t = inb ? f[(long)yy * W + xx] : make_float2(0.f, 0.f);
+        v[j + 2] = make_float2(t.x * fs, t.y * fs);
+      }
+#pragma unroll
+      for (int j = -1; j <= 1; j++) {
+        const int cy = y + j * dy, cx = x + j * dx;
+        const bool valid = (unsigned)(cy - dy) < (unsigned)H && (unsigned)(cy + dy) < (unsigned)H &&
+                           (unsigned)(cx - dx) < (unsigned)W && (unsigned)(cx + dx) < (unsigned)W &&
+                           (unsigned)cy < (unsigned)H && (unsigned)cx < (unsigned)W;
+        if (!valid) continue;
+        const float du = (v[j + 3].x + v[j + 1].x) - 2.f * v[j + 2].x;
+        const float dv = (v[j + 3].y + v[j + 1].y) - 2.f * v[j + 2].y;
+        const float coef = j == 0 ? -2.f : 1.f;
+        gu += coef * charb_grad(du);
+        gv += coef * charb_grad(dv);
+        if (j == 0) local += charb(du) + charb(dv);
+      }
+    }
+    if (dflow) {
+      float2* o = reinterpret_cast<float2*>(dflow) + i;
+      float a = gu * scale * fs, b = gv * scale * fs;
+      if (acc) {
+        const float2 e = *o;
+        a += e.x;
+        b += e.y;
+      }
+      *o = make_float2(a, b);
+    }
+  }
+  const float t = block_sum(local, red);
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
+}
+
+UNFLOW_API int unflow_second_order_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow,
+                                           int accumulate, float weight, float normalizer, int N, int H, int W,
+                                           unflow_stream_t stream) {
+  if (!flow) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0) return UNFLOW_ERR_SHAPE;
+  second_order_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      flow, flow_scale, loss_acc, d_flow, accumulate, weight / normalizer, N, H, W);
+  return launch_status();
+}

@@ -1,0 +1,393 @@
+// Warps and downsample for gfx950 (HBM-bound gathers; one thread per pixel or per output
+// element, coalesced along the channels-last axis).
+//
+//   backward_warp  <- ops/backward_warp_op.cu.cc:14-138   (zero padding, floorf(float(x)+u))
+//   image_warp     <- src/e2eflow/core/image_warp.py:4-76 (clamp, x + int(floor(u)), dual gradient)
+//   forward_warp   <- ops/forward_warp_op.cu.cc:16-125    (gaussian splat, +-4 px)
+//   downsample     <- ops/downsample_op.cu.cc:15-49       (box mean)
+#include "common.h"
+
+// ------------------------------------------------------------------ backward_warp
+struct BwTaps {
+  int x0, y0;
+  float wl, wr, wt, wb;
+};
+
+__device__ __forceinline__ BwTaps bw_sample(int px, int py, float u, float v) {
+  BwTaps t;
+  const float sx = (float)px + u, sy = (float)py + v;  // fp32 sum, then floor (ref :27-31)
+  t.x0 = (int)floorf(sx);
+  t.y0 = (int)floorf(sy);
+  t.wr = sx - (float)t.x0;
+  t.wl = (float)(t.x0 + 1) - sx;
+  t.wb = sy - (float)t.y0;
+  t.wt = (float)(t.y0 + 1) - sy;
+  return t;
+}
+
+__global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
+                                         float* __restrict__ out, int B, int H, int W, int C) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const long b = i / ((long)W * H);
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const BwTaps t = bw_sample(px, py, f.x, f.y);
+    const float* base = img + b * H * W * C;
+    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    const long otl = ((long)t.y0 * W + t.x0) * C;
+    for (int c = 0; c < C; c++) {
+      float s = 0.f;
+      // each product is rounded before the add (CUDA compiles `sum += a*b*c` of the reference with
+      // fma contraction possible; tolerance covers it)
+      if (xl && yt) s += t.wl * t.wt * base[otl + c];
+      if (xr && yt) s += t.wr * t.wt * base[otl + C + c];
+      if (xl && yb) s += t.wl * t.wb * base[otl + (long)W * C + c];
+      if (xr && yb) s += t.wr * t.wb * base[otl + (long)W * C + C + c];
+      out[i * C + c] = s;
+    }
+  }
+}
+
+__global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ img,
+                                         const float* __restrict__ flow, float* __restrict__ dflow, int B,
+                                         int H, int W, int C) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const long b = i / ((long)W * H);
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const BwTaps t = bw_sample(px, py, f.x, f.y);
+    const float* base = img + b * H * W * C;
+    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    const long otl = ((long)t.y0 * W + t.x0) * C;
+    float du = 0.f, dv = 0.f;
+    for (int c = 0; c < C; c++) {
+      const float din = dout[i * C + c];
+      float q;
+      if (xl && yt) { q = base[otl + c] * din; du -= t.wt * q; dv -= t.wl * q; }
+      if (xr && yt) { q = base[otl + C + c] * din; du += t.wt * q; dv -= t.wr * q; }
+      if (xl && yb) { q = base[otl + (long)W * C + c] * din; du -= t.wb * q; dv += t.wl * q; }
+      if (xr && yb) { q = base[otl + (long)W * C + C + c] * din; du += t.wb * q; dv += t.wr * q; }
+    }
+    reinterpret_cast<float2*>(dflow)[i] = make_float2(du, dv);
+  }
+}
+
+__global__ void backward_warp_indices_kernel(const float* __restrict__ flow, int* __restrict__ xy0, int B, int H,
+                                             int W) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const BwTaps t = bw_sample((int)(i % W), (int)((i / W) % H), f.x, f.y);
+    reinterpret_cast<int2*>(xy0)[i] = make_int2(t.x0, t.y0);
+  }
+}
+
+UNFLOW_API int unflow_backward_warp_fwd(const float* images, const float* flows, float* out, int B, int H, int W,
+                                        int C, unflow_stream_t stream) {
+  if (!images || !flows || !out) return UNFLOW_ERR_NULL;
+  if (B < 0 || H < 0 || W < 0 || C < 0) return UNFLOW_ERR_SHAPE;
+  const long npx = (long)B * H * W;
+  if (npx == 0 || C == 0) return UNFLOW_OK;  // ref: `if (total_count == 0) return;`
+  backward_warp_fwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(images, flows, out, B, H, W, C);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_backward_warp_bwd(const float* dout, const float* images, const float* flows, float* dflows,
+                                        int B, int H, int W, int C, unflow_stream_t stream) {
+  if (!dout || !images || !flows || !dflows) return UNFLOW_ERR_NULL;
+  if (B < 0 || H < 0 || W < 0 || C < 0) return UNFLOW_ERR_SHAPE;
+  const long npx = (long)B * H * W;
+  if (npx == 0) return UNFLOW_OK;
+  backward_warp_bwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, images, flows, dflows, B, H, W, C);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_backward_warp_indices(const float* flows, int* xy0, int B, int H, int W,
+                                            unflow_stream_t stream) {
+  if (!flows || !xy0) return UNFLOW_ERR_NULL;
+  const long npx = (long)B * H * W;
+  if (npx == 0) return UNFLOW_OK;
+  backward_warp_indices_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(flows, xy0, B, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ image_warp
+struct IwTaps {
+  long ia, ib, ic, id;  // pixel indices within the batch (sample-relative, in pixels)
+  float xw, yw, wa, wb, wc, wd;
+};
+
+__device__ __forceinline__ IwTaps iw_sample(int px, int py, float u, float v, int H, int W) {
+  IwTaps t;
+  const float fu = floorf(u), fv = floorf(v);
+  t.xw = u - fu;
+  t.yw = v - fv;
+  t.wa = (1.f - t.xw) * (1.f - t.yw);
+  t.wb = (1.f - t.xw) * t.yw;
+  t.wc = t.xw * (1.f - t.yw);
+  t.wd = t.xw * t.yw;
+  const int xi = px + (int)fu, yi = py + (int)fv;
+  const int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
+  const int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
+  t.ia = (long)y0 * W + x0;
+  t.ib = (long)y1 * W + x0;
+  t.ic = (long)y0 * W + x1;
+  t.id = (long)y1 * W + x1;
+  return t;
+}
+
+__global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, const float* __restrict__ flow,
+                                      float fscale, float* __restrict__ out, int* __restrict__ idx4, int shift,
+                                      int B, int H, int W, int C) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const int b = (int)(i / ((long)W * H));
+    const int bs = (b + shift) % B;
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const IwTaps t = iw_sample(px, py, f.x * fscale, f.y * fscale, H, W);
+    const long sbase = (long)bs * H * W;
+    if (idx4) {
+      reinterpret_cast<int4*>(idx4)[i] =
+          make_int4((int)(sbase + t.ia), (int)(sbase + t.ib), (int)(sbase + t.ic), (int)(sbase + t.id));
+    }
+    const float* pa = im + (sbase + t.ia) * ld_im;
+    const float* pb = im + (sbase + t.ib) * ld_im;
+    const float* pc = im + (sbase + t.ic) * ld_im;
+    const float* pd = im + (sbase + t.id) * ld_im;
+    for (int c = 0; c < C; c++)
+      out[i * C + c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
+  }
+}
+
+__global__ void image_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ im, int ld_im,
+                                      const float* __restrict__ flow, float fscale, float* __restrict__ d_im,
+                                      float* __restrict__ d_flow, int acc_flow, int shift, int B, int H, int W,
+                                      int C) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const int b = (int)(i / ((long)W * H));
+    const int bs = (b + shift) % B;
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const IwTaps t = iw_sample(px, py, f.x * fscale, f.y * fscale, H, W);
+    const long sbase = (long)bs * H * W;
+    const long oa = (sbase + t.ia) * ld_im, ob = (sbase + t.ib) * ld_im, oc = (sbase + t.ic) * ld_im,
+               od = (sbase + t.id) * ld_im;
+    float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+    for (int c = 0; c < C; c++) {
+      const float g = dout[i * C + c];
+      ga += g * im[oa + c];
+      gb += g * im[ob + c];
+      gc += g * im[oc + c];
+      gd += g * im[od + c];
+      if (d_im) {  // gather-gradient = scatter-add (clamped duplicates accumulate)
+        atomicAdd(d_im + oa + c, t.wa * g);
+        atomicAdd(d_im + ob + c, t.wb * g);
+        atomicAdd(d_im + oc + c, t.wc * g);
+        atomicAdd(d_im + od + c, t.wd * g);
+      }
+    }
+    float du = ((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw) * fscale;
+    float dv = ((gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw) * fscale;
+    float2* o = reinterpret_cast<float2*>(d_flow) + i;
+    if (acc_flow) {
+      const float2 e = *o;
+      du += e.x;
+      dv += e.y;
+    }
+    *o = make_float2(du, dv);
+  }
+}
+
+UNFLOW_API int unflow_image_warp_fwd(const float* im, int ld_im, const float* flow, float flow_scale, float* out,
+                                     int* idx4, int pair_shift, int B, int H, int W, int C,
+                                     unflow_stream_t stream) {
+  if (!im || !flow || !out) return UNFLOW_ERR_NULL;
+  if (B < 0 || H < 0 || W < 0 || C < 0 || ld_im < C) return UNFLOW_ERR_SHAPE;
+  const long npx = (long)B * H * W;
+  if (npx == 0 || C == 0) return UNFLOW_OK;
+  image_warp_fwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, out, idx4,
+                                                                         pair_shift, B, H, W, C);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_image_warp_bwd(const float* dout, const float* im, int ld_im, const float* flow,
+                                     float flow_scale, float* d_im, float* d_flow, int accumulate_d_flow,
+                                     int pair_shift, int B, int H, int W, int C, unflow_stream_t stream) {
+  if (!dout || !im || !flow || !d_flow) return UNFLOW_ERR_NULL;
+  if (B < 0 || H < 0 || W < 0 || C < 0 || ld_im < C) return UNFLOW_ERR_SHAPE;
+  const long npx = (long)B * H * W;
+  if (npx == 0) return UNFLOW_OK;
+  image_warp_bwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(
+      dout, im, ld_im, flow, flow_scale, d_im, d_flow, accumulate_d_flow, pair_shift, B, H, W, C);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ forward_warp
+struct FwFoot {
+  bool ok;
+  int x_lo, x_hi, y_lo, y_hi;
+  float tx, ty;
+};
+
+__device__ __forceinline__ FwFoot fw_footprint(int px, int py, float u, float v, int W, int H) {
+  FwFoot f;
+  const float k = 4.f;  // ceilf(2 + 2)
+  f.tx = (float)px + u;
+  f.ty = (float)py + v;
+  f.ok = floorf(f.tx - k) < (float)W && floorf(f.tx + k) >= 0.f && floorf(f.ty - k) < (float)H &&
+         floorf(f.ty + k) >= 0.f;
+  f.x_lo = f.tx - k > 0.f ? (int)floorf(f.tx - k) : 0;
+  f.y_lo = f.ty - k > 0.f ? (int)floorf(f.ty - k) : 0;
+  f.x_hi = f.tx + k < (float)W ? (int)floorf(f.tx + k) : W - 1;
+  f.y_hi = f.ty + k < (float)H ? (int)floorf(f.ty + k) : H - 1;
+  return f;
+}
+
+__device__ __forceinline__ float splat_weight(float dx, float dy) {
+  return expf(-(dx * dx + dy * dy) / 2.0f);  // gauss_divisor = 2*std^2 = 2 (ref :53-56)
+}
+
+// Reference-style scatter: one thread per source pixel, float atomics (order nondeterministic).
+__global__ void forward_warp_scatter_kernel(const float* __restrict__ flow, float* __restrict__ out, int B, int H,
+                                            int W) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ((long)W * H);
+    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
+    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
+    if (!f.ok) continue;
+    for (int nx = f.x_lo; nx <= f.x_hi; nx++)
+      for (int ny = f.y_lo; ny <= f.y_hi; ny++)
+        atomicAdd(out + (b * H + ny) * W + nx, splat_weight((float)nx - f.tx, (float)ny - f.ty));
+  }
+}
+
+// Deterministic variant: the same scatter, but each weight is added as a 2^40-scaled 64-bit integer
+// (integer atomics commute, so the sum is independent of arrival order and bit-reproducible);
+// a second pass converts to float.  Per-term quantisation 2^-41 — far below fp32 resolution of the sum.
+#define FW_FIXED_SCALE 1099511627776.0 /* 2^40 */
+__global__ void forward_warp_scatter_fixed_kernel(const float* __restrict__ flow,
+                                                  unsigned long long* __restrict__ acc, int B, int H, int W) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ((long)W * H);
+    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
+    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
+    if (!f.ok) continue;
+    for (int nx = f.x_lo; nx <= f.x_hi; nx++)
+      for (int ny = f.y_lo; ny <= f.y_hi; ny++) {
+        const double w = (double)splat_weight((float)nx - f.tx, (float)ny - f.ty);
+        atomicAdd(acc + (b * H + ny) * W + nx, (unsigned long long)(w * FW_FIXED_SCALE + 0.5));
+      }
+  }
+}
+
+__global__ void forward_warp_fixed_to_float_kernel(const unsigned long long* __restrict__ acc,
+                                                   float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = (float)((double)acc[i] * (1.0 / FW_FIXED_SCALE));
+}
+
+__global__ void forward_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ flow,
+                                        float* __restrict__ dflow, int B, int H, int W) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ((long)W * H);
+    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
+    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
+    float du = 0.f, dv = 0.f;
+    if (f.ok)
+      for (int nx = f.x_lo; nx <= f.x_hi; nx++)
+        for (int ny = f.y_lo; ny <= f.y_hi; ny++) {
+          const float dx = (float)nx - f.tx, dy = (float)ny - f.ty;
+          const float factor = 2.f * dout[(b * H + ny) * W + nx] * splat_weight(dx, dy) / 2.0f;
+          du += factor * dx;
+          dv += factor * dy;
+        }
+    reinterpret_cast<float2*>(dflow)[i] = make_float2(du, dv);
+  }
+}
+
+__global__ void forward_warp_ranges_kernel(const float* __restrict__ flow, int* __restrict__ ranges, int B, int H,
+                                           int W) {
+  const long npx = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
+    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
+    reinterpret_cast<int4*>(ranges)[i] = f.ok ? make_int4(f.x_lo, f.x_hi, f.y_lo, f.y_hi) : make_int4(-1, -1, -1, -1);
+  }
+}
+
+UNFLOW_API int unflow_forward_warp_fwd(const float* flows, float* out, int B, int H, int W, int deterministic,
+                                       void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
+  if (!flows || !out) return UNFLOW_ERR_NULL;
+  if (B < 0 || H < 0 || W < 0) return UNFLOW_ERR_SHAPE;
+  const long npx = (long)B * H * W;
+  if (npx == 0) return UNFLOW_OK;
+  if (deterministic) {
+    if (!workspace) return UNFLOW_ERR_NULL;
+    if (workspace_bytes < sizeof(unsigned long long) * (size_t)npx) return UNFLOW_ERR_WORKSPACE;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
+    if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * npx, as_stream(stream)) != hipSuccess)
+      return UNFLOW_ERR_LAUNCH;
+    forward_warp_scatter_fixed_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(flows, acc, B, H, W);
+    forward_warp_fixed_to_float_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(acc, out, npx);
+  } else {
+    if (hipMemsetAsync(out, 0, sizeof(float) * npx, as_stream(stream)) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+    forward_warp_scatter_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(flows, out, B, H, W);
+  }
+  return launch_status();
+}
+
+UNFLOW_API int unflow_forward_warp_bwd(const float* dout, const float* flows, float* dflows, int B, int H, int W,
+                                       unflow_stream_t stream) {
+  if (!dout || !flows || !dflows) return UNFLOW_ERR_NULL;
+  const long npx = (long)B * H * W;
+  if (npx == 0) return UNFLOW_OK;
+  forward_warp_bwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, flows, dflows, B, H, W);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_forward_warp_ranges(const float* flows, int* ranges, int B, int H, int W,
+                                          unflow_stream_t stream) {
+  if (!flows || !ranges) return UNFLOW_ERR_NULL;
+  const long npx = (long)B * H * W;
+  if (npx == 0) return UNFLOW_OK;
+  forward_warp_ranges_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(flows, ranges, B, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ downsample
+// One thread per output element; consecutive threads = consecutive channels then x (coalesced).
+__global__ void downsample_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H, int W, int C,
+                                  int scale) {
+  const int oh = H / scale, ow = W / scale;
+  const long n = (long)B * oh * ow * C;
+  const float inv = (float)(scale * scale);
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int ox = (int)((e / C) % ow), oy = (int)((e / C / ow) % oh);
+    const long b = e / ((long)C * ow * oh);
+    float s = 0.f;
+    for (int yy = oy * scale; yy < (oy + 1) * scale; yy++)
+      for (int xx = ox * scale; xx < (ox + 1) * scale; xx++) s += img[((b * H + yy) * W + xx) * C + c];
+    out[e] = s / inv;
+  }
+}
+
+UNFLOW_API int unflow_downsample_fwd(const float* images, float* out, int B, int H, int W, int C, int scale,
+                                     unflow_stream_t stream) {
+  if (!images || !out) return UNFLOW_ERR_NULL;
+  if (B < 0 || H < 0 || W < 0 || C < 0) return UNFLOW_ERR_SHAPE;
+  if (scale <= 0 || H % scale != 0 || W % scale != 0) return UNFLOW_ERR_NOT_DIVISIBLE;
+  const long n = (long)B * (H / scale) * (W / scale) * C;
+  if (n == 0) return UNFLOW_OK;
+  downsample_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(images, out, B, H, W, C, scale);
+  return launch_status();
+}

@@ -1,0 +1,169 @@
+// Step plumbing around the network: input normalisation (unsupervised.py:29-32,69-70), TF1
+// resize_bilinear (unsupervised.py:103-104), L2 regulariser (flownet.py:176 via tf.nn.l2_loss),
+// fused TF-form Adam (train.py:151-152) and the EPE sums (flow_util.py:98-103).  All HBM-bound
+// streaming kernels: 16-byte accesses, grid-stride, >= 2048 workgroups when the data allows.
+#include "common.h"
+
+UNFLOW_API const char* unflow_status_string(int status) {
+  switch (status) {
+    case UNFLOW_OK: return "ok";
+    case UNFLOW_ERR_NULL: return "null pointer argument";
+    case UNFLOW_ERR_EMPTY_OUTPUT: return "Invalid correlation settings";
+    case UNFLOW_ERR_EVEN_KERNEL: return "kernel_size must be odd";
+    case UNFLOW_ERR_NOT_DIVISIBLE: return "Input height and width must be divisible by scale";
+    case UNFLOW_ERR_SHAPE: return "Input shapes have to be the same";
+    case UNFLOW_ERR_UNSUPPORTED: return "unsupported configuration";
+    case UNFLOW_ERR_LAUNCH: return "HIP launch failed";
+    case UNFLOW_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown status";
+  }
+}
+
+UNFLOW_API int unflow_version(void) { return 100; }
+
+__global__ void prepare_images_kernel(const float* __restrict__ im, float* __restrict__ net4,
+                                      float* __restrict__ out01, float m0, float m1, float m2, long npix) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float r = im[3 * i] / 255.0f, g = im[3 * i + 1] / 255.0f, b = im[3 * i + 2] / 255.0f;
+    reinterpret_cast<float4*>(net4)[i] = make_float4(r - m0, g - m1, b - m2, 0.f);
+    if (out01) {
+      out01[3 * i] = r;
+      out01[3 * i + 1] = g;
+      out01[3 * i + 2] = b;
+    }
+  }
+}
+
+UNFLOW_API int unflow_prepare_images(const float* im_u8range, float* net_in4, float* out01, const float* mean3,
+                                     long npix, unflow_stream_t stream) {
+  if (!im_u8range || !net_in4 || !mean3) return UNFLOW_ERR_NULL;
+  if (npix <= 0) return UNFLOW_OK;
+  // mean3 is a HOST pointer to the three channel means in [0,255] (core/input.py:45); mean/255 in fp32
+  const float m0 = mean3[0] / 255.0f, m1 = mean3[1] / 255.0f, m2 = mean3[2] / 255.0f;
+  prepare_images_kernel<<<stream_grid(npix), 256, 0, as_stream(stream)>>>(im_u8range, net_in4, out01, m0, m1, m2, npix);
+  return launch_status();
+}
+
+// TF1 legacy bilinear: src = dst * (in/out); lo = floor(src); hi = min(lo+1, in-1); lerp x then y.
+__global__ void resize_bilinear_tf1_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                           int C, int OH, int OW, float sy, float sx, float scale) {
+  const long n = (long)B * OH * OW * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int ox = (int)((e / C) % OW), oy = (int)((e / C / OW) % OH);
+    const long b = e / ((long)C * OW * OH);
+    const float fy = (float)oy * sy, fx = (float)ox * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* base = in + b * H * W * C + c;
+    const float tl = base[((long)y0 * W + x0) * C], tr = base[((long)y0 * W + x1) * C];
+    const float bl = base[((long)y1 * W + x0) * C], br = base[((long)y1 * W + x1) * C];
+    const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+    out[e] = (top + (bot - top) * ly) * scale;
+  }
+}
+
+UNFLOW_API int unflow_resize_bilinear_tf1(const float* in, float* out, int B, int H, int W, int C, int out_h,
+                                          int out_w, float scale, unflow_stream_t stream) {
+  if (!in || !out) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || out_h <= 0 || out_w <= 0) return UNFLOW_ERR_SHAPE;
+  const long n = (long)B * out_h * out_w * C;
+  resize_bilinear_tf1_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(
+      in, out, B, H, W, C, out_h, out_w, (float)H / (float)out_h, (float)W / (float)out_w, scale);
+  return launch_status();
+}
+
+// Fused Adam (TF form, epsilon outside the bias correction) + L2-regulariser gradient.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, long n_reg, float gscale, float l2, float lr_t, float b1,
+                            float b2, float eps) {
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x;
+    const float* ga = &gg.x;
+    float* ma = &mm.x;
+    float* va = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const long idx = 4 * i + j;
+      float gr = ga[j] * gscale;
+      if (idx < n_reg) gr += l2 * pa[j];
+      ma[j] = b1 * ma[j] + (1.f - b1) * gr;
+      va[j] = b2 * va[j] + (1.f - b2) * (gr * gr);
+      pa[j] = pa[j] - lr_t * ma[j] / (sqrtf(va[j]) + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail
+  const long t0 = n4 << 2;
+  for (long idx = t0 + blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    float gr = g[idx] * gscale;
+    if (idx < n_reg) gr += l2 * p[idx];
+    const float mn = b1 * m[idx] + (1.f - b1) * gr;
+    const float vn = b2 * v[idx] + (1.f - b2) * (gr * gr);
+    m[idx] = mn;
+    v[idx] = vn;
+    p[idx] = p[idx] - lr_t * mn / (sqrtf(vn) + eps);
+  }
+}
+
+UNFLOW_API int unflow_adam_step(float* p, const float* grad, float* m, float* v, long n, long n_regularized,
+                                float grad_scale, float l2_scale, float lr_t, float beta1, float beta2, float eps,
+                                unflow_stream_t stream) {
+  if (!p || !grad || !m || !v) return UNFLOW_ERR_NULL;
+  if (n <= 0) return UNFLOW_OK;
+  adam_kernel<<<stream_grid(n / 4 + 1), 256, 0, as_stream(stream)>>>(p, grad, m, v, n, n_regularized, grad_scale,
+                                                                      l2_scale, lr_t, beta1, beta2, eps);
+  return launch_status();
+}
+
+// loss_acc[0] += scale * 0.5 * sum(p^2).  Single-block-ordered: per-block partials are combined by
+// one atomicAdd per block (order varies run to run at the last bits; deterministic variant = 1 block).
+__global__ void l2_loss_kernel(const float* __restrict__ p, long n, float scale, float* __restrict__ acc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += p[i] * p[i];
+  const float t = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(acc, t * 0.5f * scale);
+}
+
+UNFLOW_API int unflow_l2_loss(const float* p, long n, float scale, float* loss_acc, unflow_stream_t stream) {
+  if (!p || !loss_acc) return UNFLOW_ERR_NULL;
+  if (n <= 0) return UNFLOW_OK;
+  l2_loss_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(p, n, scale, loss_acc);
+  return launch_status();
+}
+
+__global__ void flow_error_sums_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                       const float* __restrict__ mask, float* __restrict__ out2, long npix) {
+  __shared__ float red[4];
+  float s = 0.f, ms = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float2 a = reinterpret_cast<const float2*>(f1)[i], b = reinterpret_cast<const float2*>(f2)[i];
+    const float mk = mask ? mask[i] : 1.f;
+    const float dx = a.x - b.x, dy = a.y - b.y;
+    s += sqrtf(dx * dx + dy * dy) * mk;
+    ms += mk;
+  }
+  const float t = block_sum(s, red);
+  const float tm = block_sum(ms, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(out2, t);
+    atomicAdd(out2 + 1, tm);
+  }
+}
+
+UNFLOW_API int unflow_flow_error_sums(const float* f1, const float* f2, const float* mask, float* out2, long npix,
+                                      unflow_stream_t stream) {
+  if (!f1 || !f2 || !out2) return UNFLOW_ERR_NULL;
+  if (hipMemsetAsync(out2, 0, 2 * sizeof(float), as_stream(stream)) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  if (npix <= 0) return UNFLOW_OK;
+  flow_error_sums_kernel<<<stream_grid(npix), 256, 0, as_stream(stream)>>>(f1, f2, mask, out2, npix);
+  return launch_status();
+}
