@@ -1,0 +1,417 @@
+"""Static-plan training-step engine for FlowNetC (and FlowNetS) on one MI355X.
+
+Replaces, for the hot path, what TensorFlow's executor does for the reference graph built by
+  core/flownet.py:14-237  (network, shared weights for both images and both flow directions)
+  core/unsupervised.py:27-164 (normalisation, image/mask pyramid, per-level losses, L2 term)
+  core/train.py:147-185 (Adam, single-GPU minimize)
+with an explicit launch list over libunflow_hip.so:
+
+  * one "directed batch" of N = 2B samples: samples [0,B) are (im1 -> im2), [B,2B) are (im2 -> im1), so the
+    feature towers, both flownet_c passes and both loss directions of the reference run as ONE
+    pass over N samples with the reference's weight sharing; the filter gradients then sum over both
+    directions exactly like TF's gradient aggregation over reused variables;
+  * channels-last activations; every concat of flownet.py is a channel slice of a preallocated buffer
+    (producers write into it, consumers read with a channel stride) — no concat, no transposes;
+  * channel counts padded to multiples of 4 at the END of the concat (473->476, 1026->1028, 770->772,
+    386->388, 194->196, RGB 3->4): the padded activations are zero and never written, the padded weight
+    rows are zero and receive exactly zero gradient, so the maths is unchanged;
+  * backward is an explicit reverse launch list; gradient accumulation into multi-consumer tensors
+    and the leaky-ReLU derivative are fused into the dgrad epilogues (accumulate / act range);
+  * parameters, gradients and Adam moments live in four flat fp32 buffers (weights first, then
+    biases) so L2 + Adam is one fused kernel and the data-parallel all-reduce is over one buffer.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream, cf, cl
+from ..ops import workspace
+from . import layers as L
+
+FLOW_SCALE = 5.0                                   # flownet.py:11
+CHANNEL_MEAN = [104.920005, 110.1753, 114.785955]  # core/input.py:45
+LAYER_WEIGHTS = [12.7, 4.35, 3.9, 3.4, 1.1]        # unsupervised.py:87
+LAYER_PATCH_DISTANCES = [3, 2, 2, 1, 1]            # unsupervised.py:88
+L2_SCALE = 0.0004                                  # flownet.py:176
+LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']  # unsupervised.py:15
+IMPLEMENTED_LOSSES = ('ternary', 'smooth_2nd')
+
+DEFAULT_PARAMS = dict(flownet='C', pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0)
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class Layer:
+    __slots__ = ('name', 'kind', 'k', 'cin', 'cout', 'stride', 'act', 'cin_p', 'w', 'b', 'dw', 'db')
+
+    def __init__(self, name, kind, k, cin, cout, stride, act):
+        self.name, self.kind, self.k, self.cin, self.cout, self.stride, self.act = name, kind, k, cin, cout, stride, act
+        self.cin_p = cin if (kind == 'deconv' and cin == 2) else pad4(cin)
+
+    def wshape(self):
+        if self.kind == 'conv':
+            return (self.k, self.k, self.cin_p, self.cout)   # HWIO
+        return (self.k, self.k, self.cout, self.cin_p)       # conv2d_transpose: [k,k,out,in]
+
+
+def flownet_c_layers():
+    """Variables of flownet_c_features + flownet_c in the reference's creation order (flownet.py:195-237,89-131)."""
+    f, c = 'flownet_c_features/', 'flownet_c/'
+    return [
+        Layer(f + 'conv1', 'conv', 7, 3, 64, 2, True), Layer(f + 'conv2', 'conv', 5, 64, 128, 2, True),
+        Layer(f + 'conv3', 'conv', 5, 128, 256, 2, True),
+        Layer(c + 'conv_redir', 'conv', 1, 256, 32, 1, True), Layer(c + 'conv3_1', 'conv', 3, 473, 256, 1, True),
+        Layer(c + 'conv4', 'conv', 3, 256, 512, 2, True), Layer(c + 'conv4_1', 'conv', 3, 512, 512, 1, True),
+        Layer(c + 'conv5', 'conv', 3, 512, 512, 2, True), Layer(c + 'conv5_1', 'conv', 3, 512, 512, 1, True),
+        Layer(c + 'conv6', 'conv', 3, 512, 1024, 2, True), Layer(c + 'conv6_1', 'conv', 3, 1024, 1024, 1, True),
+        Layer(c + 'flow6', 'conv', 3, 1024, 2, 1, False),
+        Layer(c + 'deconv5', 'deconv', 4, 1024, 512, 2, True), Layer(c + 'flow6_up5', 'deconv', 4, 2, 2, 2, False),
+        Layer(c + 'flow5', 'conv', 3, 1026, 2, 1, False),
+        Layer(c + 'deconv4', 'deconv', 4, 1026, 256, 2, True), Layer(c + 'flow5_up4', 'deconv', 4, 2, 2, 2, False),
+        Layer(c + 'flow4', 'conv', 3, 770, 2, 1, False),
+        Layer(c + 'deconv3', 'deconv', 4, 770, 128, 2, True), Layer(c + 'flow4_up3', 'deconv', 4, 2, 2, 2, False),
+        Layer(c + 'flow3', 'conv', 3, 386, 2, 1, False),
+        Layer(c + 'deconv2', 'deconv', 4, 386, 64, 2, True), Layer(c + 'flow3_up2', 'deconv', 4, 2, 2, 2, False),
+        Layer(c + 'flow2', 'conv', 3, 194, 2, 1, False),
+    ]
+
+
+class FlowNetCEngine:
+    """FlowNetC bidirectional forward / loss / backward / Adam on one GPU, fixed (B, H, W)."""
+
+    def __init__(self, batch, height, width, params=None, device=None, seed=0):
+        assert height % 64 == 0 and width % 64 == 0, "FlowNetC needs H, W divisible by 64"
+        self.params = dict(DEFAULT_PARAMS) if params is None else dict(params)
+        for l in LOSSES:
+            if self.params.get(l + '_weight') and l not in IMPLEMENTED_LOSSES:
+                raise NotImplementedError("loss term '%s' is not implemented in the HIP step yet" % l)
+        if self.params.get('mask_occlusion'):
+            raise NotImplementedError("mask_occlusion is not implemented in the HIP step yet")
+        if self.params.get('flownet', 'C') != 'C':
+            raise NotImplementedError("only flownet='C' is wired into the engine")
+        self.B, self.H, self.W = batch, height, width
+        self.N = 2 * batch
+        self.dev = torch.device('cuda:0') if device is None else device
+        self.layers = flownet_c_layers()
+        self.by_name = {l.name.split('/')[-1]: l for l in self.layers}
+        self._alloc_params()
+        self._alloc_activations()
+        self._build_masks()
+        self.step_count = 0
+        if seed is not None:
+            self.init_params(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self):
+        nw = sum(int(torch.Size(l.wshape()).numel()) for l in self.layers)
+        nb = sum(l.cout for l in self.layers)
+        self.n_weights, self.n_params = nw, nw + nb
+        z = lambda: torch.zeros(self.n_params, dtype=torch.float32, device=self.dev)
+        self.P, self.G, self.M, self.V = z(), z(), z(), z()
+        off = 0
+        for l in self.layers:
+            n = int(torch.Size(l.wshape()).numel())
+            l.w = self.P[off:off + n].view(l.wshape())
+            l.dw = self.G[off:off + n].view(l.wshape())
+            off += n
+        for l in self.layers:
+            l.b = self.P[off:off + l.cout]
+            l.db = self.G[off:off + l.cout]
+            off += l.cout
+
+    def init_params(self, seed=0):
+        """layers.variance_scaling_initializer() (flownet.py:177): truncated normal, stddev sqrt(1.3*2/fan_in);
+        zero biases.  Drawn on the host in the reference's variable order so the oracle can share them."""
+        from_tf = OrderedDict()
+        gen = torch.Generator().manual_seed(seed)
+        for l in self.layers:
+            shape = (l.k, l.k, l.cin, l.cout) if l.kind == 'conv' else (l.k, l.k, l.cout, l.cin)
+            fan_in = l.k * l.k * (l.cin if l.kind == 'conv' else l.cout)
+            std = math.sqrt(1.3 * 2.0 / fan_in)
+            t = torch.empty(shape, dtype=torch.float32)
+            torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=gen)
+            from_tf[l.name + '/weights'] = t
+            from_tf[l.name + '/biases'] = torch.zeros(l.cout)
+        self.load_tf_params(from_tf)
+        return from_tf
+
+    def load_tf_params(self, tf_params):
+        """tf_params: {'<scope>/<layer>/weights': HWIO (conv) or [k,k,out,in] (deconv), '.../biases'} on any device."""
+        self.P.zero_()
+        for l in self.layers:
+            w = tf_params[l.name + '/weights'].to(self.dev, torch.float32)
+            if l.kind == 'conv':
+                l.w[:, :, :l.cin, :] = w
+            else:
+                l.w[:, :, :, :l.cin] = w
+            l.b.copy_(tf_params[l.name + '/biases'].to(self.dev, torch.float32))
+
+    def _export(self, wattr, battr):
+        out = OrderedDict()
+        for l in self.layers:
+            w = getattr(l, wattr)
+            out[l.name + '/weights'] = (w[:, :, :l.cin, :] if l.kind == 'conv' else w[:, :, :, :l.cin]).detach().cpu().clone()
+            out[l.name + '/biases'] = getattr(l, battr).detach().cpu().clone()
+        return out
+
+    def export_tf_params(self):
+        return self._export('w', 'b')
+
+    def export_tf_grads(self):
+        """Gradients of the data loss (the L2-regulariser gradient 0.0004*w is fused into adam_step)."""
+        return self._export('dw', 'db')
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_activations(self):
+        N, H, W, dev = self.N, self.H, self.W, self.dev
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        a = self.act = {}
+        a['x0'] = z(N, H, W, 4)
+        a['im01'] = z(N, H, W, 3)
+        a['c1'] = z(N, H // 2, W // 2, 64)
+        a['cat2'] = z(N, H // 4, W // 4, 196)
+        a['c3'] = z(N, H // 8, W // 8, 256)
+        a['catc'] = z(N, H // 8, W // 8, 476)
+        a['cat3'] = z(N, H // 8, W // 8, 388)
+        a['c4'] = z(N, H // 16, W // 16, 512)
+        a['cat4'] = z(N, H // 16, W // 16, 772)
+        a['c5'] = z(N, H // 32, W // 32, 512)
+        a['cat5'] = z(N, H // 32, W // 32, 1028)
+        a['c6'] = z(N, H // 64, W // 64, 1024)
+        a['c6_1'] = z(N, H // 64, W // 64, 1024)
+        for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):
+            a['flow%d' % lvl] = z(N, H // d, W // d, 2)
+        self.grad = {k: torch.zeros_like(v) for k, v in a.items() if k not in ('x0', 'im01')}
+        # loss-side pyramid
+        self.lv = []
+        for i, d in enumerate((4, 8, 16, 32, 64)):
+            h, w = H // d, W // d
+            self.lv.append(dict(h=h, w=w, im=z(N, h, w, 3), gray1=z(N, h, w), gray2w=z(N, h, w), dist=z(N, h, w),
+                                dgray=z(N, h, w), flow=a['flow%d' % (i + 2)], gflow=self.grad['flow%d' % (i + 2)]))
+        self.loss_acc = z(1)
+        self.raw = z(N, H, W, 3)
+        self.final_flow = z(N, H, W, 2)
+        self.mean_host = (_lib.ctypes.c_float * 3)(*CHANNEL_MEAN)
+        self.epe_out = z(2)
+
+    def _build_masks(self):
+        """create_border_mask(im, 0.1) (losses.py:338-344) then downsample 4, 2, 2, 2, 2 (unsupervised.py:101,147)."""
+        from .. import ops
+        H, W = self.H, self.W
+        sz = int(math.ceil(min(H, W) * 0.1))
+        m = torch.zeros(1, H, W, 1, device=self.dev)
+        m[:, sz:H - sz, sz:W - sz] = 1.0
+        ones = torch.ones(1, H, W, 1, device=self.dev)
+        use_border = bool(self.params.get('border_mask'))
+        cur = ops.downsample(m, 4)
+        cur1 = ops.downsample(ones, 4)
+        for i, lv in enumerate(self.lv):
+            lv['mask'] = (cur if use_border else cur1).reshape(1, lv['h'], lv['w']).contiguous()
+            if i + 1 < len(self.lv):
+                cur = ops.downsample(cur, 2)
+                cur1 = ops.downsample(cur1, 2)
+        if not use_border:
+            raise NotImplementedError("border_mask=False (create_outgoing_mask) is not wired into the engine yet")
+
+    # ------------------------------------------------------------------ forward
+    def _sl(self, name, lo, hi):
+        return self.act[name][..., lo:hi]
+
+    def _gsl(self, name, lo, hi):
+        return self.grad[name][..., lo:hi]
+
+    def _conv(self, lname, x, y):
+        l = self.by_name[lname]
+        if l.kind == 'conv':
+            L.conv2d_fwd(x, l.w, l.b, y, l.stride, l.act)
+        else:
+            L.conv2d_transpose_fwd(x, l.w, l.b, y, l.act)
+
+    def set_input(self, im1, im2):
+        """im1, im2: [B,H,W,3] float32 in [0,255] (what the reference's input queue delivers)."""
+        B = self.B
+        self.raw[:B].copy_(im1)
+        self.raw[B:].copy_(im2)
+        check(_lib.lib().unflow_prepare_images(ptr(self.raw), ptr(self.act['x0']), ptr(self.act['im01']),
+                                               self.mean_host, cl(self.N * self.H * self.W), stream()), "prepare_images")
+
+    def forward_net(self):
+        a, s = self.act, self._sl
+        B = self.B
+        self._conv('conv1', a['x0'], a['c1'])
+        self._conv('conv2', a['c1'], s('cat2', 0, 128))
+        self._conv('conv3', s('cat2', 0, 128), a['c3'])
+        N, h8, w8 = self.N, self.H // 8, self.W // 8
+        corr_out = s('catc', 32, 473)
+        check(_lib.lib().unflow_correlation_nhwc_fwd(ptr(a['c3']), ptr(a['c3']), 256, B, ptr(corr_out), 476, N, 256,
+                                                     h8, w8, 1, 20, 20, 1, 2, stream()), "correlation")
+        self._conv('conv_redir', a['c3'], s('catc', 0, 32))
+        self._conv('conv3_1', a['catc'], s('cat3', 0, 256))
+        self._conv('conv4', s('cat3', 0, 256), a['c4'])
+        self._conv('conv4_1', a['c4'], s('cat4', 0, 512))
+        self._conv('conv5', s('cat4', 0, 512), a['c5'])
+        self._conv('conv5_1', a['c5'], s('cat5', 0, 512))
+        self._conv('conv6', s('cat5', 0, 512), a['c6'])
+        self._conv('conv6_1', a['c6'], a['c6_1'])
+        # refinement decoder (_flownet_upconv, flownet.py:89-131)
+        self._conv('flow6', a['c6_1'], a['flow6'])
+        self._conv('deconv5', a['c6_1'], s('cat5', 512, 1024))
+        self._conv('flow6_up5', a['flow6'], s('cat5', 1024, 1026))
+        self._conv('flow5', a['cat5'], a['flow5'])
+        self._conv('deconv4', a['cat5'], s('cat4', 512, 768))
+        self._conv('flow5_up4', a['flow5'], s('cat4', 768, 770))
+        self._conv('flow4', a['cat4'], a['flow4'])
+        self._conv('deconv3', a['cat4'], s('cat3', 256, 384))
+        self._conv('flow4_up3', a['flow4'], s('cat3', 384, 386))
+        self._conv('flow3', a['cat3'], a['flow3'])
+        self._conv('deconv2', a['cat3'], s('cat2', 128, 192))
+        self._conv('flow3_up2', a['flow3'], s('cat2', 192, 194))
+        self._conv('flow2', a['cat2'], a['flow2'])
+
+    def forward_loss(self, with_grad=True):
+        """unsupervised.py:85-150 for the default [train] terms; also writes d(loss)/d(flowN) when with_grad."""
+        lib = _lib.lib()
+        st = stream()
+        N, B = self.N, self.B
+        self.loss_acc.zero_()
+        tw = float(self.params.get('ternary_weight') or 0.0)
+        sw = float(self.params.get('smooth_2nd_weight') or 0.0)
+        levels = self.lv if self.params.get('pyramid_loss') else self.lv[:1]
+        # image pyramid: downsample(im, 4) then successive downsample(., 2) (unsupervised.py:99-100,145-146)
+        check(lib.unflow_downsample_fwd(ptr(self.act['im01']), ptr(self.lv[0]['im']), N, self.H, self.W, 3, 4, st),
+              "downsample")
+        for i in range(1, len(levels)):
+            p = self.lv[i - 1]
+            check(lib.unflow_downsample_fwd(ptr(p['im']), ptr(self.lv[i]['im']), N, p['h'], p['w'], 3, 2, st),
+                  "downsample")
+        for i, lv in enumerate(levels):
+            h, w = lv['h'], lv['w']
+            fs = FLOW_SCALE / (2 ** i)
+            lw = LAYER_WEIGHTS[i]
+            gf = ptr(lv['gflow']) if with_grad else ptr(None)
+            if sw:
+                check(lib.unflow_second_order_fwd_bwd(ptr(lv['flow']), cf(fs), ptr(self.loss_acc), gf, 0, cf(lw * sw),
+                                                      cf(B * h * w * 4), N, h, w, st), "second_order")
+            elif with_grad:
+                lv['gflow'].zero_()
+            if tw:
+                D = LAYER_PATCH_DISTANCES[i]
+                check(lib.unflow_rgb_to_gray255(ptr(lv['im']), 3, ptr(lv['gray1']), cl(N * h * w), st), "gray")
+                check(lib.unflow_warp_gray_fwd(ptr(lv['im']), 3, ptr(lv['flow']), cf(fs), ptr(lv['gray2w']), B, N, h,
+                                               w, st), "warp_gray")
+                check(lib.unflow_ternary_fwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(lv['mask']), 1, ptr(lv['dist']),
+                                             ptr(self.loss_acc), cf(lw * tw), cf(B * h * w), D, N, h, w, st), "ternary")
+                if with_grad:
+                    check(lib.unflow_ternary_bwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(lv['mask']), 1,
+                                                 ptr(lv['dist']), ptr(lv['dgray']), cf(lw * tw), cf(B * h * w), D, N,
+                                                 h, w, st), "ternary_bwd")
+                    check(lib.unflow_warp_gray_bwd(ptr(lv['dgray']), ptr(lv['im']), 3, ptr(lv['flow']), cf(fs),
+                                                   ptr(lv['gflow']), 1, B, N, h, w, st), "warp_gray_bwd")
+        if with_grad and not self.params.get('pyramid_loss'):
+            for lv in self.lv[1:]:
+                lv['gflow'].zero_()
+        # regularisation term (value only; its gradient is fused into adam_step)
+        check(lib.unflow_l2_loss(ptr(self.P), cl(self.n_weights), cf(L2_SCALE), ptr(self.loss_acc), st), "l2_loss")
+        return self.loss_acc
+
+    # ------------------------------------------------------------------ backward
+    def _bwd(self, lname, x, dz, dx=None, accumulate=False, act_src=None, act_lo=0, act_hi=0):
+        """Filter + bias gradient of layer `lname` from dz (d pre-activation), then (optionally) the data gradient."""
+        l = self.by_name[lname]
+        if l.kind == 'conv':
+            L.conv2d_bwd_filter(x, dz, l.dw, l.db, l.stride)
+            if dx is not None:
+                L.conv2d_bwd_data(dz, l.w, dx, l.stride, accumulate, act_src, act_lo, act_hi)
+        else:
+            L.conv2d_transpose_bwd_filter(x, dz, l.dw, l.db)
+            if dx is not None:
+                L.conv2d_transpose_bwd_data(dz, l.w, dx, accumulate, act_src, act_lo, act_hi)
+
+    def backward_net(self):
+        a, g, s, gs = self.act, self.grad, self._sl, self._gsl
+        B, N = self.B, self.N
+        # level 2 (flow2 head reads concat2 = [conv2_a | deconv2 | flow3_up2])
+        self._bwd('flow2', a['cat2'], g['flow2'], g['cat2'], False, a['cat2'], 128, 192)
+        self._bwd('flow3_up2', a['flow3'], gs('cat2', 192, 194), g['flow3'], True)
+        self._bwd('flow3', a['cat3'], g['flow3'], g['cat3'], False)
+        self._bwd('deconv2', a['cat3'], gs('cat2', 128, 192), g['cat3'], True, a['cat3'], 256, 384)
+        self._bwd('flow4_up3', a['flow4'], gs('cat3', 384, 386), g['flow4'], True)
+        self._bwd('flow4', a['cat4'], g['flow4'], g['cat4'], False)
+        self._bwd('deconv3', a['cat4'], gs('cat3', 256, 384), g['cat4'], True, a['cat4'], 512, 768)
+        self._bwd('flow5_up4', a['flow5'], gs('cat4', 768, 770), g['flow5'], True)
+        self._bwd('flow5', a['cat5'], g['flow5'], g['cat5'], False)
+        self._bwd('deconv4', a['cat5'], gs('cat4', 512, 768), g['cat5'], True, a['cat5'], 512, 1024)
+        self._bwd('flow6_up5', a['flow6'], gs('cat5', 1024, 1026), g['flow6'], True)
+        self._bwd('flow6', a['c6_1'], g['flow6'], g['c6_1'], False)
+        self._bwd('deconv5', a['c6_1'], gs('cat5', 512, 1024), g['c6_1'], True, a['c6_1'], 0, 1024)
+        # contracting part
+        self._bwd('conv6_1', a['c6'], g['c6_1'], g['c6'], False, a['c6'], 0, 1024)
+        self._bwd('conv6', s('cat5', 0, 512), g['c6'], gs('cat5', 0, 512), True, s('cat5', 0, 512), 0, 512)
+        self._bwd('conv5_1', a['c5'], gs('cat5', 0, 512), g['c5'], False, a['c5'], 0, 512)
+        self._bwd('conv5', s('cat4', 0, 512), g['c5'], gs('cat4', 0, 512), True, s('cat4', 0, 512), 0, 512)
+        self._bwd('conv4_1', a['c4'], gs('cat4', 0, 512), g['c4'], False, a['c4'], 0, 512)
+        self._bwd('conv4', s('cat3', 0, 256), g['c4'], gs('cat3', 0, 256), True, s('cat3', 0, 256), 0, 256)
+        self._bwd('conv3_1', a['catc'], gs('cat3', 0, 256), g['catc'], False, a['catc'], 0, 32)
+        # correlation: gradient wrt the shared feature tensor (both roles of every sample), then conv_redir adds
+        h8, w8 = self.H // 8, self.W // 8
+        check(_lib.lib().unflow_correlation_nhwc_bwd(ptr(gs('catc', 32, 473)), 476, ptr(a['c3']), ptr(a['c3']), 256,
+                                                     B, ptr(g['c3']), ptr(None), 256, 1, N, 256, h8, w8, 1, 20, 20, 1,
+                                                     2, stream()), "correlation_grad")
+        self._bwd('conv_redir', a['c3'], gs('catc', 0, 32), g['c3'], True, a['c3'], 0, 256)
+        self._bwd('conv3', s('cat2', 0, 128), g['c3'], gs('cat2', 0, 128), True, s('cat2', 0, 128), 0, 128)
+        self._bwd('conv2', a['c1'], gs('cat2', 0, 128), g['c1'], False, a['c1'], 0, 64)
+        self._bwd('conv1', a['x0'], g['c1'], None)
+
+    # ------------------------------------------------------------------ optimiser
+    def adam_step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """tf.train.AdamOptimizer(beta1=0.9, beta2=0.999) update (train.py:151-152), TF formulation, with the
+        slim.l2_regularizer(0.0004) gradient added for the weight tensors (biases are not regularised)."""
+        self.step_count += 1
+        t = self.step_count
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        check(_lib.lib().unflow_adam_step(ptr(self.P), ptr(self.G), ptr(self.M), ptr(self.V), cl(self.n_params),
+                                          cl(self.n_weights), cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1),
+                                          cf(beta2), cf(eps), stream()), "adam")
+
+    # ------------------------------------------------------------------ composite
+    def fwd_bwd(self, im1=None, im2=None):
+        if im1 is not None:
+            self.set_input(im1, im2)
+        self.forward_net()
+        loss = self.forward_loss(with_grad=True)
+        self.backward_net()
+        return loss
+
+    def train_step(self, im1, im2, lr):
+        loss = self.fwd_bwd(im1, im2)
+        self.adam_step(lr)
+        return loss
+
+    def final_flows(self):
+        """final_flow_fw / _bw (unsupervised.py:103-104): resize_bilinear(flow2, im_shape) * 5 * 4."""
+        f2 = self.act['flow2']
+        N, h, w, _ = f2.shape
+        check(_lib.lib().unflow_resize_bilinear_tf1(ptr(f2), ptr(self.final_flow), N, h, w, 2, self.H, self.W,
+                                                    cf(FLOW_SCALE * 4), stream()), "resize_bilinear")
+        return self.final_flow[:self.B], self.final_flow[self.B:]
+
+    def flows(self):
+        """(flows_fw, flows_bw): lists [flow2..flow6], NHWC, like flownet(..., backward_flow=True)[-1]."""
+        B = self.B
+        fw = [self.act['flow%d' % l][:B] for l in (2, 3, 4, 5, 6)]
+        bw = [self.act['flow%d' % l][B:] for l in (2, 3, 4, 5, 6)]
+        return fw, bw
+
+
+def flow_error_avg(flow_1, flow_2, mask=None):
+    """core/flow_util.py:98-103 (EPE)."""
+    f1, f2 = flow_1.contiguous(), flow_2.contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=f1.device)
+    npix = f1.numel() // 2
+    check(_lib.lib().unflow_flow_error_sums(ptr(f1), ptr(f2), ptr(None if mask is None else mask.contiguous()),
+                                            ptr(out), cl(npix), stream()), "flow_error")
+    return out[0] / out[1]
