@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""UnFlow training-step benchmark (BASELINE.json metric: image-pairs/s, FlowNetC 384x512).
+
+One "step" = one unsupervised training step of FlowNetC on a synthetic minibatch of 4 image pairs per
+GPU (BASELINE.json configs[1]; configs[2] = the same per-GPU work on 8 ranks): bidirectional forward
+(both feature towers, both flownet_c passes, 441-channel correlation), census + second-order loss
+pyramid, full backward, gradient all-reduce over RCCL when N > 1, fused L2 + Adam update.
+Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+# CPU-baseline leg: bound the host thread count BEFORE torch / libgomp initialise (a 256-thread oneDNN +
+# OpenMP run of this small problem is ~100x slower than 32 threads on the GPU host).
+CPU_THREADS = min(os.cpu_count() or 1, 32)
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
+os.environ.setdefault("MKL_NUM_THREADS", str(CPU_THREADS))
+
+FWD_BWD_GFLOP_PER_PAIR = 204.9      # algorithmic 2*MAC, FlowNetC 384x512 bidirectional
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def conv_family_gflop(eng):
+    """Algorithmic GFLOP (2*MAC, true channel counts) of all conv/deconv fwd + dgrad + wgrad launches of one step."""
+    N = eng.N
+    sizes = {}
+    H, W = eng.H, eng.W
+    tot = 0.0
+    res = {'conv1': 2, 'conv2': 4, 'conv3': 8, 'conv_redir': 8, 'conv3_1': 8, 'conv4': 16, 'conv4_1': 16, 'conv5': 32,
+           'conv5_1': 32, 'conv6': 64, 'conv6_1': 64, 'flow6': 64, 'deconv5': 32, 'flow6_up5': 32, 'flow5': 32,
+           'deconv4': 16, 'flow5_up4': 16, 'flow4': 16, 'deconv3': 8, 'flow4_up3': 8, 'flow3': 8, 'deconv2': 4,
+           'flow3_up2': 4, 'flow2': 4}
+    for l in eng.layers:
+        nm = l.name.split('/')[-1]
+        d = res[nm]
+        opix = N * (H // d) * (W // d)
+        taps = l.k * l.k if l.kind == 'conv' else 4      # conv_transpose k4 s2: 4 taps reach each output pixel
+        f = 2.0 * opix * taps * l.cin * l.cout / 1e9
+        sizes[nm] = f
+        tot += f * (2 if nm == 'conv1' else 3)          # fwd + wgrad (+ dgrad except for the first layer)
+    return tot, sizes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="image pairs per GPU")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from unflow_amd.core.engine import FlowNetCEngine
+    from unflow_amd.core.data_parallel import GradAllReducer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, H, W = args.batch, args.height, args.width
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=0)            # same weights on every rank
+    g = torch.Generator().manual_seed(1234 + rank)               # distinct shard per rank
+    im1 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
+    im2 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
+    reducer = GradAllReducer(eng.G, world) if world > 1 else None
+    lr = 1e-4
+    eng.set_input(im1, im2)
+
+    graph = None
+
+    def fwd_bwd():
+        if graph is not None:
+            graph.replay()
+        else:
+            eng.fwd_bwd()
+
+    def step():
+        fwd_bwd()
+        if reducer is not None:
+            reducer.all_reduce()
+        eng.adam_step(lr, grad_scale=1.0 / world)
+
+    # first eager step grows the workspaces; then capture fwd+loss+bwd (~230 launches) into one hipGraph
+    step()
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            eng.fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eng.fwd_bwd()
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    loss = eng.loss_acc.item()
+    ms = dt / args.steps * 1e3
+    pairs_per_s = world * B * args.steps / dt
+
+    out = {
+        "metric": "image-pairs/s (fwd+bwd) FlowNetC 384x512", "value": round(pairs_per_s, 3), "unit": "image-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "FlowNetC unsupervised step: bidirectional fwd + census/2nd-order loss pyramid + bwd + "
+                               "L2/Adam%s, %d pairs/GPU, %dx%d, 441-ch correlation (BASELINE configs[%d])"
+                               % (" + RCCL grad all-reduce" if world > 1 else "", B, H, W, 2 if world > 1 else 1),
+                   "global_batch": world * B, "height": H, "width": W, "parallelism": "dp%d" % world,
+                   "hipgraph": graph is not None, "final_loss": round(loss, 4)},
+        "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W) == (384, 512) else None,
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        out["roofline"] = measure_roofline(eng, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = measure_cpu_baseline(H, W)
+        if out["cpu_baseline"]["value"]:
+            out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_roofline(eng, args):
+    """Dominant kernel class = the fp32-MFMA implicit-GEMM conv family (igemm_gather_kernel /
+    igemm_wgrad_kernel): algorithmic FLOPs of those launches / their summed duration, the duration
+    measured with HIP events recorded on the launch stream around every conv-family call of a step."""
+    import torch
+    from unflow_amd.core import layers as L
+    gflop, _ = conv_family_gflop(eng)
+    names = ["conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_filter", "conv2d_transpose_fwd",
+             "conv2d_transpose_bwd_data", "conv2d_transpose_bwd_filter"]
+    orig = {n: getattr(L, n) for n in names}
+    events = []
+
+    def wrap(fn):
+        def inner(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()            # current stream == the stream the kernels are launched on (_lib.stream())
+            r = fn(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            return r
+        return inner
+
+    reps = 3
+    try:
+        for n in names:
+            setattr(L, n, wrap(orig[n]))
+        eng.fwd_bwd()              # warm
+        torch.cuda.synchronize()
+        events.clear()
+        for _ in range(reps):
+            eng.fwd_bwd()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in events) / reps
+        launches = len(events) // reps
+    finally:
+        for n in names:
+            setattr(L, n, orig[n])
+    achieved = gflop / ms            # GFLOP / ms == TFLOP/s
+    return {"bound": "mfma", "kernel": "igemm_gather_kernel + igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32 conv family, "
+                                       "%d launches/step incl. split-K reduces)" % launches,
+            "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
+
+
+def measure_cpu_baseline(H, W):
+    """The reference's step on the host cores: the literal TF graph cannot run (no TensorFlow, GPU-only ops),
+    so this times the CPU oracle restatement (oracle/model_ref.py: torch-CPU convs, C ops) — kind "port".
+    Bounded sample: 1 image pair, one warm-up + one timed fwd+bwd step."""
+    import torch
+    try:
+        from oracle import model_ref as M
+        cores = CPU_THREADS
+        torch.set_num_threads(cores)
+        P = M.init_params('C', 0)
+        for v in P.values():
+            v.requires_grad_()
+        g = torch.Generator().manual_seed(1234)
+        im1 = torch.rand(1, H, W, 3, generator=g) * 255
+        im2 = torch.rand(1, H, W, 3, generator=g) * 255
+        times = []
+        for it in range(5):
+            for v in P.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            loss = M.unsupervised_loss(P, im1, im2)
+            loss.backward()
+            times.append(time.perf_counter() - t0)
+            if sum(times) > 40.0 and it >= 1:     # hard bound on the CPU leg
+                break
+        t = sum(times[1:]) / len(times[1:])
+        return {"value": round(1.0 / t, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+                "sample": "1 image pair %dx%d per step, 1 warm-up + %d timed fwd+bwd steps of the torch-CPU/C oracle "
+                          "on %d threads (%.1f s of CPU work)" % (H, W, len(times) - 1, cores, sum(times))}
+    except Exception as e:  # the oracle is a checker, never a dependency of the measured path
+        return {"value": None, "unit": "image-pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+if __name__ == "__main__":
+    main()

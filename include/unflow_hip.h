@@ -168,7 +168,14 @@ int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const float* dz,
                                        int B, int H, int W, int Cin, int Cout, void* workspace,
                                        size_t workspace_bytes, unflow_stream_t stream);
 
-/* Workspace upper bound for any conv/deconv entry above with these dimensions. */
+/* All bias gradients of a step in two launches: out[i][c] = sum over the npix[i] rows of x[i][., c]
+ * (x[i]: [npix[i], ld[i]] slice with C[i] columns).  The pointer/size arrays are HOST arrays, n <= 32.
+ * Deterministic (fixed-order chunked reduction). */
+size_t unflow_colsum_batched_workspace_bytes(int n, const int* C);
+int unflow_colsum_batched(int n, const float* const* x, const int* ld, const long* npix, const int* C,
+                          float* const* out, void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+
+/* Exact workspace requirement of the conv/deconv entry points above for these dimensions. */
 size_t unflow_conv_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride);
 
 /* dz[., c] = dy[., c] * leaky'(y[., c]) in place over a [npix, C] slice (stand-alone form of the epilogue). */

@@ -34,6 +34,9 @@ def lib():
             raise RuntimeError(
                 "libunflow_hip.so not found at %s — build it with `python -m unflow_amd.build` "
                 "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        # torch must be imported first: libunflow_hip.so depends on libamdhip64 by SONAME, and it has to bind
+        # to the ONE HIP runtime torch already loaded (its streams / device pointers are that runtime's).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.unflow_status_string.restype = ctypes.c_char_p
         _lib.unflow_correlation_workspace_bytes.restype = ctypes.c_size_t

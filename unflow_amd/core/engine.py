@@ -102,6 +102,7 @@ class FlowNetCEngine:
         self._alloc_activations()
         self._build_masks()
         self.step_count = 0
+        self._bias_jobs, self._bias_plan = [], None
         if seed is not None:
             self.init_params(seed)
 
@@ -322,14 +323,36 @@ class FlowNetCEngine:
     def _bwd(self, lname, x, dz, dx=None, accumulate=False, act_src=None, act_lo=0, act_hi=0):
         """Filter + bias gradient of layer `lname` from dz (d pre-activation), then (optionally) the data gradient."""
         l = self.by_name[lname]
+        if self._bias_plan is None:
+            self._bias_jobs.append((dz, l))         # bias gradients: one batched column-sum launch at the end
         if l.kind == 'conv':
-            L.conv2d_bwd_filter(x, dz, l.dw, l.db, l.stride)
+            L.conv2d_bwd_filter(x, dz, l.dw, None, l.stride)
             if dx is not None:
                 L.conv2d_bwd_data(dz, l.w, dx, l.stride, accumulate, act_src, act_lo, act_hi)
         else:
-            L.conv2d_transpose_bwd_filter(x, dz, l.dw, l.db)
+            L.conv2d_transpose_bwd_filter(x, dz, l.dw, None)
             if dx is not None:
                 L.conv2d_transpose_bwd_data(dz, l.w, dx, accumulate, act_src, act_lo, act_hi)
+
+    def _bias_grads(self):
+        """db = column sums of every layer's dz, batched (unflow_colsum_batched)."""
+        import ctypes
+        lib = _lib.lib()
+        if self._bias_plan is None:
+            jobs = self._bias_jobs
+            n = len(jobs)
+            xs = (ctypes.c_void_p * n)(*[dz.data_ptr() for dz, _ in jobs])
+            lds = (ctypes.c_int * n)(*[dz.stride(2) for dz, _ in jobs])
+            npx = (ctypes.c_long * n)(*[dz.shape[0] * dz.shape[1] * dz.shape[2] for dz, _ in jobs])
+            cs = (ctypes.c_int * n)(*[l.cout for _, l in jobs])
+            outs = (ctypes.c_void_p * n)(*[l.db.data_ptr() for _, l in jobs])
+            lib.unflow_colsum_batched_workspace_bytes.restype = ctypes.c_size_t
+            nbytes = lib.unflow_colsum_batched_workspace_bytes(n, cs)
+            ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.dev)
+            self._bias_plan = (n, xs, lds, npx, cs, outs, ws)
+        n, xs, lds, npx, cs, outs, ws = self._bias_plan
+        check(lib.unflow_colsum_batched(n, xs, lds, npx, cs, outs, ptr(ws), _lib.csz(ws.numel() * 4), stream()),
+              "colsum_batched")
 
     def backward_net(self):
         a, g, s, gs = self.act, self.grad, self._sl, self._gsl
@@ -365,6 +388,7 @@ class FlowNetCEngine:
         self._bwd('conv3', s('cat2', 0, 128), g['c3'], gs('cat2', 0, 128), True, s('cat2', 0, 128), 0, 128)
         self._bwd('conv2', a['c1'], gs('cat2', 0, 128), g['c1'], False, a['c1'], 0, 64)
         self._bwd('conv1', a['x0'], g['c1'], None)
+        self._bias_grads()
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):

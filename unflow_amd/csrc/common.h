@@ -6,7 +6,13 @@
 
 #define UNFLOW_API extern "C" __attribute__((visibility("default")))
 
-static inline hipStream_t as_stream(unflow_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its stream argument right before launching: also drop any stale error
+// code a previous, unrelated runtime call of this thread left behind, so that launch_status() reports
+// only this entry's launches.
+static inline hipStream_t as_stream(unflow_stream_t s) {
+  (void)hipGetLastError();
+  return reinterpret_cast<hipStream_t>(s);
+}
 
 static inline int launch_status() {
   return hipGetLastError() == hipSuccess ? UNFLOW_OK : UNFLOW_ERR_LAUNCH;

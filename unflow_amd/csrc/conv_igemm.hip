@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDK = BK + 1;
+constexpr int LDK = BK + 4;
 
 struct TapClass {
   int nty, ntx;  // taps of this class
@@ -57,22 +57,25 @@ __device__ __forceinline__ unsigned fast_div(unsigned a, unsigned magic) { retur
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// LDS operand layout: [row][LDK] with LDK = 36 floats (16-byte aligned rows, conflict-free for the
+// 128-bit reads and writes used below).  K order inside a tile is permuted: wave half lh (lanes 32*lh..)
+// supplies k = 16*lh + s at MFMA step s, so one ds_read_b128 feeds 4 consecutive steps.  Both operands
+// use the same permutation, so the sum over k is unchanged (only its fp32 order).
 template <int BM, int BN, int WM, int WN, bool B_NK>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
   constexpr int A_ELEMS = BM * LDK;
-  constexpr int B_ELEMS = B_NK ? BN * LDK : BK * BN;
-  constexpr int AR = BM / 32;                       // A rows per thread
-  constexpr int BR = B_NK ? BN / 32 : (BK * BN / 4) / 256;  // B rows (or k-rows) per thread
-  constexpr int BQ = BN / 4;                        // quads per B k-row (KN layout)
-  constexpr int BKSTEP = 256 / BQ;                  // k-row step between a thread's loads (KN layout)
+  constexpr int AR = BM / 32;                 // A rows per thread (quad column kq fixed)
+  constexpr int BR_NK = BN / 32;              // B rows per thread, K-contiguous weights
+  constexpr int KG = 256 / BN;                // KN weights: thread = (n, k-group); k-quads kq = kg + KG*i
+  constexpr int BQ_KN = 8 / KG;               // quads per thread (KN)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * A_ELEMS;
-  int* pix = reinterpret_cast<int*>(smem + 2 * A_ELEMS + 2 * B_ELEMS);
+  float* Bs = smem + A_ELEMS;
+  int* pix = reinterpret_cast<int*>(smem + A_ELEMS + BN * LDK);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -84,7 +87,6 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   const int Cq = p.Cs >> 2;
   const int Ktot = ntaps * p.Cs;
   const int KT = (Ktot + BK - 1) / BK;
-  // split-K range of K-tiles
   const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
   const int kt0 = split * kt_per;
   const int kt1 = min(KT, kt0 + kt_per);
@@ -128,10 +130,10 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     q_tx = q_tap - q_ty * tc.ntx;
   }
 
-  float4 ra[AR], rb[BR];
+  float4 ra[AR];
+  float4 rb[B_NK ? BR_NK : BQ_KN];
 
   auto load_tile = [&](int kt) {
-    // A: gathered source rows
     const bool kvalid = q_tap < ntaps;
     const int dy = tc.dy0 + q_ty * p.dstep, dx = tc.dx0 + q_tx * p.dstep;
 #pragma unroll
@@ -143,21 +145,23 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     if constexpr (B_NK) {
       const int widx = (tc.ky0 + q_ty * p.kstep) * p.KW + tc.kx0 + q_tx * p.kstep;
 #pragma unroll
-      for (int i = 0; i < BR; i++) {
+      for (int i = 0; i < BR_NK; i++) {
         const int n = n0 + (tid >> 3) + 32 * i;
         rb[i] = (kvalid && n < p.N) ? ldg4(p.w + ((size_t)widx * p.N + n) * p.Cs + q_c4 * 4) : make_float4(0, 0, 0, 0);
       }
     } else {
-      const int nq = tid % BQ;
-      const int n = n0 + nq * 4;
+      // W[kk][n] (conv fwd, deconv dgrad: the class walks all taps in weight order, so the flattened K
+      // index is the weight row).  Lane = n (coalesced 256 B per wave and k), 4 dwords = 4 consecutive k.
+      const int n = n0 + (tid % BN);
+      const bool nok = n < p.N;
 #pragma unroll
-      for (int i = 0; i < BR; i++) {
-        const unsigned kk = (unsigned)kt * BK + (unsigned)(tid / BQ) + (unsigned)(BKSTEP * i);
-        const unsigned tap = fast_div(kk, p.cs_magic);
-        const unsigned c = kk - tap * (unsigned)p.Cs;
-        const unsigned ty = tap / (unsigned)tc.ntx, tx = tap - ty * (unsigned)tc.ntx;
-        const int widx = (tc.ky0 + (int)ty * p.kstep) * p.KW + tc.kx0 + (int)tx * p.kstep;
-        rb[i] = ((int)kk < Ktot && n < p.N) ? ldg4(p.w + ((size_t)widx * p.Cs + c) * p.N + n) : make_float4(0, 0, 0, 0);
+      for (int i = 0; i < BQ_KN; i++) {
+        const int kk = kt * BK + 4 * ((tid / BN) + KG * i);
+        const float* wp = p.w + (size_t)kk * p.N + n;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = (nok && kk + j < Ktot) ? wp[(size_t)j * p.N] : 0.f;
+        rb[i] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
     // advance the quad walker by one K-tile (8 quads)
@@ -169,24 +173,18 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     }
   };
 
-  auto store_tile = [&](int stage) {
-    float* a = As + stage * A_ELEMS;
+  auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < AR; i++) {
-      float* d = a + ((tid >> 3) + 32 * i) * LDK + kq * 4;
-      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-    }
-    float* bsm = Bs + stage * B_ELEMS;
+    for (int i = 0; i < AR; i++)
+      *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * i) * LDK + kq * 4) = ra[i];
     if constexpr (B_NK) {
 #pragma unroll
-      for (int i = 0; i < BR; i++) {
-        float* d = bsm + ((tid >> 3) + 32 * i) * LDK + kq * 4;
-        d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
-      }
+      for (int i = 0; i < BR_NK; i++)
+        *reinterpret_cast<float4*>(Bs + ((tid >> 3) + 32 * i) * LDK + kq * 4) = rb[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < BR; i++)
-        *reinterpret_cast<float4*>(bsm + ((tid / BQ) + BKSTEP * i) * BN + (tid % BQ) * 4) = rb[i];
+      for (int i = 0; i < BQ_KN; i++)
+        *reinterpret_cast<float4*>(Bs + (tid % BN) * LDK + 4 * ((tid / BN) + KG * i)) = rb[i];
     }
   };
 
@@ -201,30 +199,31 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   const int l31 = lane & 31, lh = lane >> 5;
   if (kt0 < kt1) {
     load_tile(kt0);
-    store_tile(0);
+    store_tile();
   }
   __syncthreads();
+  const float* a_rd = As + (wm * WM + l31) * LDK + 16 * lh;
+  const float* b_rd = Bs + (wn * WN + l31) * LDK + 16 * lh;
   for (int kt = kt0; kt < kt1; kt++) {
-    const int stage = (kt - kt0) & 1;
     const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
-    const float* a = As + stage * A_ELEMS + (wm * WM + l31) * LDK + lh;
-    const float* b = B_NK ? Bs + stage * B_ELEMS + (wn * WN + l31) * LDK + lh
-                          : Bs + stage * B_ELEMS + lh * BN + wn * WN + l31;
+    if (more) load_tile(kt + 1);  // global -> registers, in flight during the MFMAs below
 #pragma unroll
-    for (int s = 0; s < BK / 2; s++) {
-      float av[TM], bv[TN];
+    for (int j4 = 0; j4 < 4; j4++) {
+      float4 av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) av[i] = a[i * 32 * LDK + 2 * s];
+      for (int i = 0; i < TM; i++) av[i] = *reinterpret_cast<const float4*>(a_rd + i * 32 * LDK + 4 * j4);
 #pragma unroll
-      for (int j = 0; j < TN; j++) bv[j] = B_NK ? b[j * 32 * LDK + 2 * s] : b[2 * s * BN + j * 32];
+      for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const float4*>(b_rd + j * 32 * LDK + 4 * j4);
 #pragma unroll
-      for (int i = 0; i < TM; i++)
+      for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int j = 0; j < TN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&av[i].x)[e], (&bv[j].x)[e], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(stage ^ 1);
+    __syncthreads();  // every wave is done reading this tile
+    if (more) store_tile();
     __syncthreads();
   }
 
@@ -293,14 +292,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
-  constexpr int A_ELEMS = BK * BM, B_ELEMS = BK * BN;
+  constexpr int A_ELEMS = BK * BM;
   constexpr int AQ = BM / 4, BQ = BN / 4;
   constexpr int AR = (BK * AQ) / 256, BR = (BK * BQ) / 256;
   constexpr int ASTEP = 256 / AQ, BSTEP = 256 / BQ;
 
+  // Both operands are row(site)-major in HBM, so the LDS image is [k = site][rows] (16-byte stores, and
+  // the MFMA operand read of lane i is the i-th consecutive dword: conflict-free ds_read_b32).
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * A_ELEMS;
+  float* Bs = smem + A_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -321,35 +322,45 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
   const int nb = n0 + (tid % BQ) * 4;
   const bool n_ok = nb < p.Cb;
 
+  // site walkers (one per A row of this thread): decoded once, then advanced by BK sites per tile
+  int sx[AR], sy[AR], sb[AR];
+#pragma unroll
+  for (int i = 0; i < AR; i++) {
+    const int s0 = kt0 * BK + tid / AQ + ASTEP * i;
+    sx[i] = s0 % p.Wg;
+    const int t = s0 / p.Wg;
+    sy[i] = t % p.Hg;
+    sb[i] = t / p.Hg;
+  }
+  const float* bptr = p.dst + (size_t)(kt0 * BK + tid / BQ) * p.ldd + nb;
+
   float4 ra[AR], rb[BR];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < AR; i++) {
-      const int s = kt * BK + tid / AQ + ASTEP * i;
-      bool ok = m_ok && s < S;
-      size_t off = 0;
-      if (ok) {
-        const int xg = s % p.Wg, t = s / p.Wg;
-        const int yg = t % p.Hg, b = t / p.Hg;
-        const int y = yg * p.sm + dy, x = xg * p.sm + dx;
-        ok = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-        off = ((size_t)(b * p.Hs + y) * p.Ws + x) * p.lds + a_ch;
+      const int y = sy[i] * p.sm + dy, x = sx[i] * p.sm + dx;
+      const bool ok = m_ok && sb[i] < p.B && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+      ra[i] = ok ? ldg4(p.src + ((size_t)(sb[i] * p.Hs + y) * p.Ws + x) * p.lds + a_ch) : make_float4(0, 0, 0, 0);
+      sx[i] += BK;
+      while (sx[i] >= p.Wg) {
+        sx[i] -= p.Wg;
+        if (++sy[i] == p.Hg) { sy[i] = 0; sb[i]++; }
       }
-      ra[i] = ok ? ldg4(p.src + off) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BR; i++) {
       const int s = kt * BK + tid / BQ + BSTEP * i;
-      rb[i] = (n_ok && s < S) ? ldg4(p.dst + (size_t)s * p.ldd + nb) : make_float4(0, 0, 0, 0);
+      rb[i] = (n_ok && s < S) ? ldg4(bptr + (size_t)(BSTEP * i) * p.ldd) : make_float4(0, 0, 0, 0);
     }
+    bptr += (size_t)BK * p.ldd;
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < AR; i++)
-      *reinterpret_cast<float4*>(As + stage * A_ELEMS + (tid / AQ + ASTEP * i) * BM + (tid % AQ) * 4) = ra[i];
+      *reinterpret_cast<float4*>(As + (tid / AQ + ASTEP * i) * BM + (tid % AQ) * 4) = ra[i];
 #pragma unroll
     for (int i = 0; i < BR; i++)
-      *reinterpret_cast<float4*>(Bs + stage * B_ELEMS + (tid / BQ + BSTEP * i) * BN + (tid % BQ) * 4) = rb[i];
+      *reinterpret_cast<float4*>(Bs + (tid / BQ + BSTEP * i) * BN + (tid % BQ) * 4) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -363,15 +374,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
   const int l31 = lane & 31, lh = lane >> 5;
   if (kt0 < kt1) {
     load_tile(kt0);
-    store_tile(0);
+    store_tile();
   }
   __syncthreads();
+  const float* a = As + lh * BM + wm * WM + l31;
+  const float* b = Bs + lh * BN + wn * WN + l31;
   for (int kt = kt0; kt < kt1; kt++) {
-    const int stage = (kt - kt0) & 1;
     const bool more = kt + 1 < kt1;
     if (more) load_tile(kt + 1);
-    const float* a = As + stage * A_ELEMS + lh * BM + wm * WM + l31;
-    const float* b = Bs + stage * B_ELEMS + lh * BN + wn * WN + l31;
 #pragma unroll
     for (int s = 0; s < BK / 2; s++) {
       float av[TM], bv[TN];
@@ -385,7 +395,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < TN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(stage ^ 1);
+    __syncthreads();
+    if (more) store_tile();
     __syncthreads();
   }
 
@@ -404,12 +415,18 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
     }
 }
 
-// out[e] = sum_s partial[s][e], fixed order.
-__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n, int nsplit) {
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+// out[g][e] = sum_{k < fan} partial[g*fan + k][e]  (fixed order; g < ceil(S/fan)).  With S <= fan this is the
+// final sum.  Applied repeatedly it is a deterministic tree reduction whose serial depth is <= fan.
+__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n, int S,
+                                    int fan) {
+  const int G = (S + fan - 1) / fan;
+  const size_t total = n * (size_t)G;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = t / n, e = t - g * n;
+    const int k1 = min(S, (int)(g + 1) * fan);
     float v = 0.f;
-    for (int s = 0; s < nsplit; s++) v += partial[(size_t)s * n + e];
-    out[e] = v;
+    for (int k = (int)g * fan; k < k1; k++) v += partial[(size_t)k * n + e];
+    out[g * n + e] = v;
   }
 }
 
@@ -651,7 +668,8 @@ template <int CI, int CO>
 __global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __restrict__ x, int ldx,
                                                                 const float* __restrict__ dz, int lddz,
                                                                 float* __restrict__ partial, int B, int H, int W) {
-  __shared__ float red[4];
+  constexpr int NV = 16 * CO * CI;
+  __shared__ float red[4][NV];
   const int OH = 2 * H, OW = 2 * W;
   const long n = (long)B * H * W;
   float acc[16][CO][CI];
@@ -683,15 +701,102 @@ __global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __r
       }
     }
   }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < 16; t++)
 #pragma unroll
     for (int a = 0; a < CO; a++)
 #pragma unroll
       for (int c = 0; c < CI; c++) {
-        const float s = block_sum(acc[t][a][c], red);
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 16 * CO * CI + (t * CO + a) * CI + c] = s;
+        const float s = wave_sum(acc[t][a][c]);
+        if (lane == 0) red[wid][(t * CO + a) * CI + c] = s;
       }
+  __syncthreads();
+  if (threadIdx.x < NV)
+    partial[(size_t)blockIdx.x * NV + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Batched column sums (all bias gradients of a step in one launch): block -> (descriptor, 64-col tile, row chunk).
+constexpr int MAX_COLSUM = 32;
+constexpr int COLSUM_MAX_CHUNKS = 256;
+struct ColsumBatch {
+  const float* x[MAX_COLSUM];
+  float* out[MAX_COLSUM];
+  long npix[MAX_COLSUM];
+  int ld[MAX_COLSUM], C[MAX_COLSUM], chunks[MAX_COLSUM];
+  int block0[MAX_COLSUM + 1];   // first block of each descriptor
+  long part0[MAX_COLSUM];       // offset (floats) of each descriptor's partials [chunks][C]
+  int n;
+};
+
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const ColsumBatch d, float* __restrict__ partial) {
+  __shared__ float red[16][64];
+  int di = 0;
+  while (di + 1 < d.n && (int)blockIdx.x >= d.block0[di + 1]) di++;
+  const int lb = blockIdx.x - d.block0[di];
+  const int C = d.C[di], ld = d.ld[di];
+  const int ctiles = (C + 63) / 64;
+  const int ct = lb % ctiles, chunk = lb / ctiles;
+  const long per = (d.npix[di] + d.chunks[di] - 1) / d.chunks[di];
+  const long r0 = chunk * per, r1 = min(d.npix[di], r0 + per);
+  const float* x = d.x[di];
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<size_t>(x) & 15) == 0);
+  if (vec) {
+    // thread = (4 columns, one of 16 row lanes): 16-byte loads, 2 rows in flight per thread
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = ct * 64 + cq * 4;
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+    if (col < C) {
+      long r = r0 + rl;
+      for (; r + 16 < r1; r += 32) {
+        const float4 a = *reinterpret_cast<const float4*>(x + r * ld + col);
+        const float4 b = *reinterpret_cast<const float4*>(x + (r + 16) * ld + col);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      }
+      if (r < r1) {
+        const float4 a = *reinterpret_cast<const float4*>(x + r * ld + col);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      }
+    }
+    red[rl][cq * 4] = s0.x + s1.x; red[rl][cq * 4 + 1] = s0.y + s1.y;
+    red[rl][cq * 4 + 2] = s0.z + s1.z; red[rl][cq * 4 + 3] = s0.w + s1.w;
+  } else {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = ct * 64 + cl;
+    float s0 = 0.f;
+    if (col < C)
+      for (long r = r0 + rl; r < r1; r += 4) s0 += x[r * ld + col];
+    red[rl][cl] = s0;
+    for (int k = 4 + rl; k < 16; k += 4) red[k][cl] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int col = ct * 64 + threadIdx.x;
+    if (col < C) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) v += red[k][threadIdx.x];
+      partial[d.part0[di] + (size_t)chunk * C + col] = v;
+    }
+  }
+}
+
+// one block per (descriptor, 64 columns): 4 row lanes stride over the chunks, then a fixed-order combine
+__global__ __launch_bounds__(256) void colsum_batched_final_kernel(const ColsumBatch d, const float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int di = blockIdx.y;
+  const int C = d.C[di];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= C) return;
+  float v = 0.f;
+  if (col < C)
+    for (int k = rl; k < d.chunks[di]; k += 4) v += partial[d.part0[di] + (size_t)k * C + col];
+  red[rl][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    d.out[di][col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void leaky_bwd_inplace_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
@@ -785,6 +890,13 @@ inline void build_deconv_wgrad(WgradParams& p, int B, int H, int W, int Cin, int
 }
 
 // ---- planners
+constexpr int REDUCE_FAN = 32;
+
+// Bytes of scratch reduce_partials needs after the S*n partials themselves.
+inline size_t reduce_scratch_bytes(size_t n, int S) {
+  return S > REDUCE_FAN ? 2 * (size_t)((S + REDUCE_FAN - 1) / REDUCE_FAN) * n * sizeof(float) : 0;
+}
+
 struct GatherPlan {
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
   int nsplit;
@@ -835,18 +947,39 @@ inline int plan_wgrad(const WgradParams& p) {
 }
 
 inline size_t wgrad_partial_bytes(const WgradParams& p, int nsplit) {
-  return nsplit > 1 ? (size_t)nsplit * p.KH * p.KW * p.Ca * p.Cb * sizeof(float) : 0;
+  const size_t n = (size_t)p.KH * p.KW * p.Ca * p.Cb;
+  return nsplit > 1 ? (size_t)nsplit * n * sizeof(float) + reduce_scratch_bytes(n, nsplit) : 0;
 }
 
-constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)256 * C * sizeof(float) + 512; }
+// pixel chunks of the skinny (Cout == 2) filter-gradient kernel: enough single-wave blocks to fill the chip
+inline int skinny_wgrad_chunks(long npix, int Cin) {
+  const long colblocks = (Cin / 4 + 63) / 64;
+  long c = (4096 + colblocks - 1) / colblocks;
+  c = min(c, max((long)1, npix / 8));
+  return (int)min(c, (long)1024);
+}
+
+constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)REDUCE_FAN * C * sizeof(float) + 512; }
 
 // ---- launchers
+// out[e] = sum_s partial[s][e]; `scratch` (reduce_scratch_bytes) is used when S > REDUCE_FAN.
+inline int reduce_partials(const float* partial, float* scratch, float* out, size_t n, int S, hipStream_t st) {
+  while (S > REDUCE_FAN) {
+    const int G = (S + REDUCE_FAN - 1) / REDUCE_FAN;
+    sum_partials_kernel<<<stream_grid((long)(n * G)), 256, 0, st>>>(partial, scratch, n, S, REDUCE_FAN);
+    // next level reads `scratch`; its output must not alias: levels alternate between scratch halves
+    partial = scratch;
+    scratch = scratch + (size_t)G * n;
+    S = G;
+  }
+  sum_partials_kernel<<<stream_grid((long)n), 256, 0, st>>>(partial, out, n, S, REDUCE_FAN);
+  return launch_status();
+}
+
 template <int BM, int BN, int WM, int WN, bool B_NK>
 int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
-  constexpr int A_ELEMS = BM * LDK;
-  constexpr int B_ELEMS = B_NK ? BN * LDK : BK * BN;
-  const size_t smem = (2 * A_ELEMS + 2 * B_ELEMS) * sizeof(float) + BM * sizeof(int);
+  const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK>),
@@ -886,7 +1019,7 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
 template <int BM, int BN, int WM, int WN>
 int launch_wgrad_cfg(const WgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
-  const size_t smem = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float);
+  const size_t smem = (size_t)(BK * BM + BK * BN) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM, BN, WM, WN>),
@@ -904,7 +1037,7 @@ int run_wgrad(WgradParams& p, void* ws, size_t ws_bytes, size_t* used, hipStream
   const size_t wsize = (size_t)p.KH * p.KW * p.Ca * p.Cb;
   int ns = plan_wgrad(p);
   if (ns > 1 && (!ws || ws_bytes < wgrad_partial_bytes(p, ns))) {
-    ns = ws ? (int)(ws_bytes / (wsize * sizeof(float))) : 1;
+    ns = ws ? (int)min((size_t)REDUCE_FAN, ws_bytes / (wsize * sizeof(float))) : 1;
     if (ns < 1) ns = 1;
   }
   p.nsplit = ns;
@@ -912,17 +1045,14 @@ int run_wgrad(WgradParams& p, void* ws, size_t ws_bytes, size_t* used, hipStream
   *used = wgrad_partial_bytes(p, ns);
   const int code = p.Cb <= 64 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st) : launch_wgrad_cfg<128, 128, 64, 64>(p, st);
   if (code != UNFLOW_OK) return code;
-  if (ns > 1) {
-    sum_partials_kernel<<<stream_grid((long)wsize), 256, 0, st>>>(p.partial, p.out, wsize, ns);
-    return launch_status();
-  }
+  if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);
   return UNFLOW_OK;
 }
 
 // bias gradient: column sums of dz [npix, C]; scratch placed after `ws_used` bytes of the workspace.
 int run_colsum(const float* dz, int ld, long npix, int C, float* out, void* ws, size_t ws_bytes, size_t ws_used,
                hipStream_t st) {
-  int chunks = (int)min((long)256, max((long)1, npix / 64));
+  int chunks = (int)min((long)REDUCE_FAN, max((long)1, npix / 256));
   float* part = nullptr;
   const size_t need = (size_t)chunks * C * sizeof(float);
   const size_t off = (ws_used + 255) & ~(size_t)255;
@@ -930,7 +1060,7 @@ int run_colsum(const float* dz, int ld, long npix, int C, float* out, void* ws, 
   else chunks = 1;
   dim3 grid(cdiv(C, 64), chunks);
   colsum_partial_kernel<<<grid, 256, 0, st>>>(dz, ld, npix, C, chunks == 1 ? out : part);
-  if (chunks > 1) sum_partials_kernel<<<stream_grid(C), 256, 0, st>>>(part, out, (size_t)C, chunks);
+  if (chunks > 1) sum_partials_kernel<<<stream_grid(C), 256, 0, st>>>(part, out, (size_t)C, chunks, REDUCE_FAN);
   return launch_status();
 }
 
@@ -944,8 +1074,10 @@ UNFLOW_API size_t unflow_conv_workspace_bytes(int B, int H, int W, int Cin, int 
   size_t need = 4096;
   const int cmax = max(Cin, Cout);
   if (Cout <= 4 || Cin < 4) {
-    // skinny kernels: wgrad partials [<=256][k*k*Cin*Cout]
-    need = max(need, (size_t)256 * k * k * max(Cin, 4) * max(Cout, 2) * sizeof(float));
+    // skinny kernels: wgrad partials [chunks][k*k*Cin*Cout] + tree-reduce scratch
+    const size_t wsz = (size_t)k * k * max(Cin, 4) * max(Cout, 2);
+    const int ch = skinny_wgrad_chunks((long)B * H * W, max(Cin, 4));
+    need = max(need, (size_t)ch * wsz * sizeof(float) + reduce_scratch_bytes(wsz, ch));
   } else {
     GatherParams g{};
     build_conv_fwd(g, B, H, W, Cin, Cout, k, stride);
@@ -1045,14 +1177,15 @@ UNFLOW_API int unflow_conv2d_bwd_filter(const float* x, int ldx, const float* dz
   if (Cout <= 4) {
     if (stride != 1 || k != 3 || Cout != 2) return UNFLOW_ERR_UNSUPPORTED;
     const long npix = (long)B * H * W;
-    const int chunks = (int)min((long)256, max((long)1, npix / 32));
     const size_t wsz = (size_t)9 * Cin * Cout;
-    if (!workspace || workspace_bytes < (size_t)chunks * wsz * sizeof(float)) return UNFLOW_ERR_WORKSPACE;
+    const int chunks = skinny_wgrad_chunks(npix, Cin);
+    used = (size_t)chunks * wsz * sizeof(float) + reduce_scratch_bytes(wsz, chunks);
+    if (!workspace || workspace_bytes < used) return UNFLOW_ERR_WORKSPACE;
     SkinnyWgradParams p{x, ldx, dz, lddz, reinterpret_cast<float*>(workspace), B, H, W, Cin, pt, pl};
     dim3 grid(cdiv(Cin / 4, 64), chunks);
     skinny_conv_wgrad3_kernel<2><<<grid, 64, 0, st>>>(p);
-    sum_partials_kernel<<<stream_grid((long)wsz), 256, 0, st>>>(p.partial, dw, wsz, chunks);
-    used = (size_t)chunks * wsz * sizeof(float);
+    const int rc = reduce_partials(p.partial, p.partial + (size_t)chunks * wsz, dw, wsz, chunks, st);
+    if (rc != UNFLOW_OK) return rc;
   } else {
     if (Cout % 4 != 0 || lddz % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
     WgradParams p{};
@@ -1117,7 +1250,7 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const
     if (!workspace || workspace_bytes < (size_t)blocks * 64 * sizeof(float)) return UNFLOW_ERR_WORKSPACE;
     float* part = reinterpret_cast<float*>(workspace);
     tiny_deconv_wgrad_kernel<2, 2><<<blocks, 256, 0, st>>>(x, ldx, dz, lddz, part, B, H, W);
-    sum_partials_kernel<<<1, 64, 0, st>>>(part, dw, 64, blocks);
+    sum_partials_kernel<<<1, 64, 0, st>>>(part, dw, 64, blocks, 128);
     used = (size_t)blocks * 64 * sizeof(float);
   } else {
     if (Cout % 4 != 0 || Cin % 4 != 0 || lddz % 4 != 0 || ldx % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
@@ -1136,5 +1269,41 @@ UNFLOW_API int unflow_leaky_bwd_inplace(float* dy, int lddy, const float* y, int
   if (!dy || !y) return UNFLOW_ERR_NULL;
   if (npix <= 0 || C <= 0) return UNFLOW_OK;
   leaky_bwd_inplace_kernel<<<stream_grid(npix * C), 256, 0, as_stream(stream)>>>(dy, lddy, y, ldy, npix, C);
+  return launch_status();
+}
+
+UNFLOW_API size_t unflow_colsum_batched_workspace_bytes(int n, const int* C) {
+  size_t t = 0;
+  for (int i = 0; i < n; i++) t += (size_t)COLSUM_MAX_CHUNKS * C[i];
+  return t * sizeof(float) + 256;
+}
+
+UNFLOW_API int unflow_colsum_batched(int n, const float* const* x, const int* ld, const long* npix, const int* C,
+                                     float* const* out, void* workspace, size_t workspace_bytes,
+                                     unflow_stream_t stream) {
+  if (!x || !ld || !npix || !C || !out || !workspace) return UNFLOW_ERR_NULL;
+  if (n <= 0) return UNFLOW_OK;
+  if (n > MAX_COLSUM) return UNFLOW_ERR_UNSUPPORTED;
+  if (workspace_bytes < unflow_colsum_batched_workspace_bytes(n, C)) return UNFLOW_ERR_WORKSPACE;
+  ColsumBatch d{};
+  d.n = n;
+  int blocks = 0;
+  long poff = 0;
+  for (int i = 0; i < n; i++) {
+    if (!x[i] || !out[i] || C[i] <= 0 || npix[i] <= 0 || ld[i] < C[i]) return UNFLOW_ERR_SHAPE;
+    d.x[i] = x[i]; d.out[i] = out[i]; d.npix[i] = npix[i]; d.ld[i] = ld[i]; d.C[i] = C[i];
+    d.chunks[i] = (int)min((long)COLSUM_MAX_CHUNKS, max((long)1, npix[i] / 512));
+    d.block0[i] = blocks;
+    blocks += ((C[i] + 63) / 64) * d.chunks[i];
+    d.part0[i] = poff;
+    poff += (long)d.chunks[i] * C[i];
+  }
+  d.block0[n] = blocks;
+  hipStream_t st = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  colsum_batched_kernel<<<blocks, 256, 0, st>>>(d, part);
+  int maxc = 0;
+  for (int i = 0; i < n; i++) maxc = max(maxc, C[i]);
+  colsum_batched_final_kernel<<<dim3((maxc + 63) / 64, n), 256, 0, st>>>(d, part);
   return launch_status();
 }
