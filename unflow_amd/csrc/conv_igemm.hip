@@ -19,6 +19,7 @@
 // HBM side: 16-byte loads, 128 B contiguous per pixel-row of a tile (channels-last).
 // Deep layers (M = 384..6144 sites) use split-K so the launch covers the 256 CUs; partials go to a
 // caller workspace and a fixed-order reduce applies the epilogue (deterministic, no float atomics).
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,6 +51,8 @@ struct GatherParams {
   int ncls, nsplit;
   int leaky, accumulate;
   unsigned cs_magic;  // ceil(2^32 / Cs)
+  int dbg;            // ablation switches (UNFLOW_DBG env; 0 in production)
+  int wtaps;          // taps of the whole weight tensor (KH*KW)
   TapClass cls[4];
 };
 
@@ -57,10 +60,32 @@ __device__ __forceinline__ unsigned fast_div(unsigned a, unsigned magic) { retur
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor; an offset >= num_records returns 0
+// (hardware bounds check), which replaces every predicate/select of the zero-padding logic.  OOB_MARK is added
+// to (or used as) an offset to force that; two marks sum to 2^31, still out of range.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB_MARK = 0x40000000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(bytes > 0x3fffffffu ? 0x3fffffffu : bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 // LDS operand layout: [row][LDK] with LDK = 36 floats (16-byte aligned rows, conflict-free for the
 // 128-bit reads and writes used below).  K order inside a tile is permuted: wave half lh (lanes 32*lh..)
 // supplies k = 16*lh + s at MFMA step s, so one ds_read_b128 feeds 4 consecutive steps.  Both operands
 // use the same permutation, so the sum over k is unchanged (only its fp32 order).
+//
+// Schedule: the global loads of tile t+1 (address arithmetic, bounds predicates, loads into registers) are
+// cut into pieces that sit BETWEEN the MFMA groups of tile t, fenced with sched_barrier so they stay
+// there: an in-order wave then always has an MFMA within a few instructions, instead of a ~300
+// instruction load prologue during which its SIMD's matrix pipe idles (and co-resident waves lock-step).
+// All predication is by address select + value select — no divergent branches in the loop.
 template <int BM, int BN, int WM, int WN, bool B_NK>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -71,6 +96,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   constexpr int BR_NK = BN / 32;              // B rows per thread, K-contiguous weights
   constexpr int KG = 256 / BN;                // KN weights: thread = (n, k-group); k-quads kq = kg + KG*i
   constexpr int BQ_KN = 8 / KG;               // quads per thread (KN)
+  constexpr int NB = B_NK ? BR_NK : BQ_KN;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -91,9 +117,13 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   const int kt0 = split * kt_per;
   const int kt1 = min(KT, kt0 + kt_per);
 
+  const __amdgpu_buffer_rsrc_t src_rs =
+      make_rsrc(p.src, ((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds * 4 + (size_t)p.Cs * 4);
+  const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(p.w, (size_t)p.wtaps * p.Cs * p.N * 4);
+
   // ---- per-thread A row decode (fixed for the whole K loop)
   const int kq = tid & 7;
-  int a_y[AR], a_x[AR], a_b[AR];
+  int a_y[AR], a_x[AR], a_lin[AR];
 #pragma unroll
   for (int i = 0; i < AR; i++) {
     const int m = m0 + (tid >> 3) + 32 * i;
@@ -102,11 +132,11 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
       const int yg = t % p.Hg, b = t / p.Hg;
       a_y[i] = yg * p.sm;
       a_x[i] = xg * p.sm;
-      a_b[i] = b * p.Hs * p.Ws;
+      a_lin[i] = b * p.Hs * p.Ws + a_y[i] * p.Ws + a_x[i];
     } else {
       a_y[i] = -(1 << 28);  // forces out-of-bounds
       a_x[i] = 0;
-      a_b[i] = 0;
+      a_lin[i] = 0;
     }
   }
   if (tid < BM) {
@@ -119,59 +149,87 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     }
     pix[tid] = v;
   }
+  // weight-side per-thread constants
+  int b_row[NB];   // NK: byte offset of row n (or mark); KN: unused
+  int kn_voff = 0; // KN: byte offset of column n (or mark)
+  int kn_kg = 0;   // KN: k-group of this wave (wave-uniform)
+  if constexpr (B_NK) {
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int n = n0 + (tid >> 3) + 32 * i;
+      b_row[i] = n < p.N ? n * p.Cs * 4 : OOB_MARK;
+    }
+  } else {
+    const int n = n0 + (tid % BN);
+    kn_voff = n < p.N ? n * 4 : OOB_MARK;
+    kn_kg = __builtin_amdgcn_readfirstlane(tid / BN);
+  }
+  const int lds4 = p.lds * 4;
 
-  // ---- K walker for the quad column this thread loads (A, and B when K-contiguous)
-  int q_tap, q_c4, q_ty, q_tx;
+  // ---- K walker: (tap, quad-in-tap) of the 16-byte column this thread loads; advanced by 8 quads per tile
+  // with selects only.  8 = adv_t * Cq + adv_c.
+  const int adv_t = 8 / Cq, adv_c = 8 - adv_t * Cq;
+  const unsigned ntx_magic = (65536u + (unsigned)tc.ntx - 1u) / (unsigned)tc.ntx;  // exact for tap < 2^10
+  int q_tap, q_c4;
   {
     const unsigned q = (unsigned)kt0 * 8u + (unsigned)kq;
     q_tap = (int)(q / (unsigned)Cq);
     q_c4 = (int)(q - (unsigned)q_tap * (unsigned)Cq);
-    q_ty = q_tap / tc.ntx;
-    q_tx = q_tap - q_ty * tc.ntx;
   }
+  bool live = kt0 < kt1;  // false while "loading" past the last tile: every load is forced out of range
 
   float4 ra[AR];
-  float4 rb[B_NK ? BR_NK : BQ_KN];
+  float4 rb[NB];
+  // state of the tile being loaded (set by piece 0)
+  int dy, dx, a_tile, w_tile;
 
-  auto load_tile = [&](int kt) {
-    const bool kvalid = q_tap < ntaps;
-    const int dy = tc.dy0 + q_ty * p.dstep, dx = tc.dx0 + q_tx * p.dstep;
-#pragma unroll
-    for (int i = 0; i < AR; i++) {
-      const int y = a_y[i] + dy, x = a_x[i] + dx;
-      const bool inb = kvalid && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-      ra[i] = inb ? ldg4(p.src + (size_t)(a_b[i] + y * p.Ws + x) * p.lds + q_c4 * 4) : make_float4(0, 0, 0, 0);
-    }
+  auto piece_begin = [&]() {
+    const int ty = (int)(((unsigned)q_tap * ntx_magic) >> 16), tx = q_tap - ty * tc.ntx;
+    const bool kvalid = live && q_tap < ntaps;
+    dy = tc.dy0 + ty * p.dstep;
+    dx = tc.dx0 + tx * p.dstep;
+    const int cofs = q_c4 * 16;
+    a_tile = kvalid ? (dy * p.Ws + dx) * lds4 + cofs : OOB_MARK;
     if constexpr (B_NK) {
-      const int widx = (tc.ky0 + q_ty * p.kstep) * p.KW + tc.kx0 + q_tx * p.kstep;
-#pragma unroll
-      for (int i = 0; i < BR_NK; i++) {
-        const int n = n0 + (tid >> 3) + 32 * i;
-        rb[i] = (kvalid && n < p.N) ? ldg4(p.w + ((size_t)widx * p.N + n) * p.Cs + q_c4 * 4) : make_float4(0, 0, 0, 0);
-      }
-    } else {
-      // W[kk][n] (conv fwd, deconv dgrad: the class walks all taps in weight order, so the flattened K
-      // index is the weight row).  Lane = n (coalesced 256 B per wave and k), 4 dwords = 4 consecutive k.
-      const int n = n0 + (tid % BN);
-      const bool nok = n < p.N;
-#pragma unroll
-      for (int i = 0; i < BQ_KN; i++) {
-        const int kk = kt * BK + 4 * ((tid / BN) + KG * i);
-        const float* wp = p.w + (size_t)kk * p.N + n;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = (nok && kk + j < Ktot) ? wp[(size_t)j * p.N] : 0.f;
-        rb[i] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-    // advance the quad walker by one K-tile (8 quads)
-    q_c4 += 8;
-    while (q_c4 >= Cq) {
-      q_c4 -= Cq;
-      q_tap++;
-      if (++q_tx == tc.ntx) { q_tx = 0; q_ty++; }
+      const int widx = (tc.ky0 + ty * p.kstep) * p.KW + tc.kx0 + tx * p.kstep;
+      w_tile = kvalid ? widx * p.N * p.Cs * 4 + cofs : OOB_MARK;
     }
   };
+  auto piece_a = [&](int i) {
+    const int y = a_y[i] + dy, x = a_x[i] + dx;
+    const bool inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+    const int voff = inb ? a_lin[i] * lds4 + a_tile : OOB_MARK;
+    ra[i] = buf_ld4(src_rs, voff, 0);
+  };
+  auto piece_b = [&](int i, int kt_next) {
+    if constexpr (B_NK) {
+      rb[i] = buf_ld4(w_rs, b_row[i] + w_tile, 0);
+    } else {
+      // W[kk][n] (conv fwd, deconv dgrad: the class walks all taps in weight order, so the flattened K
+      // index is the weight row).  Lane = n (coalesced 256 B per wave and k); the row offset is a scalar
+      // (rows past Ktot are clamped to the last row: the A operand is zero there).
+      const int kk = kt_next * BK + 4 * (kn_kg + KG * i);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = buf_ld1(w_rs, kn_voff, min(kk + j, Ktot - 1) * p.N * 4);
+      rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto piece_end = [&]() {
+    q_c4 += adv_c;
+    q_tap += adv_t;
+    const bool wrap = q_c4 >= Cq;
+    q_c4 -= wrap ? Cq : 0;
+    q_tap += wrap ? 1 : 0;
+  };
+  // piece schedule over the 16 MFMA steps of a tile: 0: begin, 1..AR: A rows, then B, then end
+  auto piece = [&](int step, int kt_next) {
+    if (step == 0) piece_begin();
+    if (step >= 1 && step <= AR) piece_a(step - 1);
+    if (step > AR && step <= AR + NB) piece_b(step - AR - 1, kt_next);
+    if (step == AR + NB + 1) piece_end();
+  };
+  static_assert(AR + NB + 2 <= 16, "pieces must fit the 16 steps");
 
   auto store_tile = [&]() {
 #pragma unroll
@@ -197,16 +255,15 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
-  if (kt0 < kt1) {
-    load_tile(kt0);
-    store_tile();
-  }
+  // prologue: tile kt0
+#pragma unroll
+  for (int st = 0; st < 16; st++) piece(st, kt0);
+  store_tile();
   __syncthreads();
   const float* a_rd = As + (wm * WM + l31) * LDK + 16 * lh;
   const float* b_rd = Bs + (wn * WN + l31) * LDK + 16 * lh;
   for (int kt = kt0; kt < kt1; kt++) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);  // global -> registers, in flight during the MFMAs below
+    live = (kt + 1 < kt1) && !(p.dbg & 1);
 #pragma unroll
     for (int j4 = 0; j4 < 4; j4++) {
       float4 av[TM], bv[TN];
@@ -215,16 +272,19 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
 #pragma unroll
       for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const float4*>(b_rd + j * 32 * LDK + 4 * j4);
 #pragma unroll
-      for (int e = 0; e < 4; e++)
+      for (int e = 0; e < 4; e++) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32((&av[i].x)[e], (&bv[j].x)[e], acc[i][j], 0, 0, 0);
+        piece(j4 * 4 + e, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __syncthreads();  // every wave is done reading this tile
-    if (more) store_tile();
-    __syncthreads();
+    if (!(p.dbg & 2)) __syncthreads();  // every wave is done reading this tile
+    if (!(p.dbg & 4)) store_tile();     // (last iteration: zeros, never read)
+    if (!(p.dbg & 2)) __syncthreads();
   }
 
   // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -312,6 +372,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
   const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
   const int kt0 = blockIdx.z * kt_per, kt1 = min(KT, kt0 + kt_per);
 
+  const __amdgpu_buffer_rsrc_t src_rs =
+      make_rsrc(p.src, ((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds * 4 + (size_t)p.Ca * 4);
+  const __amdgpu_buffer_rsrc_t dst_rs = make_rsrc(p.dst, ((size_t)S - 1) * (size_t)p.ldd * 4 + (size_t)p.Cb * 4);
+
   // this thread's (tap, a) quad — fixed
   const int mm = m0 + (tid % AQ) * 4;
   const bool m_ok = mm < Mp;
@@ -319,41 +383,39 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
   const int a_ch = mm - (int)tap * p.Ca;
   const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
   const int dy = p.dy0 + ky, dx = p.dx0 + kx;
+  const int a_base = m_ok ? a_ch * 4 : OOB_MARK;
   const int nb = n0 + (tid % BQ) * 4;
-  const bool n_ok = nb < p.Cb;
+  const int lds4 = p.lds * 4;
+  const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
 
-  // site walkers (one per A row of this thread): decoded once, then advanced by BK sites per tile
-  int sx[AR], sy[AR], sb[AR];
+  int bvoff[BR];  // dense operand: byte offset of (site row, 4 columns); rows past S fall out of the buffer
 #pragma unroll
-  for (int i = 0; i < AR; i++) {
-    const int s0 = kt0 * BK + tid / AQ + ASTEP * i;
-    sx[i] = s0 % p.Wg;
-    const int t = s0 / p.Wg;
-    sy[i] = t % p.Hg;
-    sb[i] = t / p.Hg;
-  }
-  const float* bptr = p.dst + (size_t)(kt0 * BK + tid / BQ) * p.ldd + nb;
+  for (int i = 0; i < BR; i++)
+    bvoff[i] = nb < p.Cb ? ((kt0 * BK + tid / BQ + BSTEP * i) * p.ldd + nb) * 4 : OOB_MARK;
+  const int bstep = BK * p.ldd * 4;
 
   float4 ra[AR], rb[BR];
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < AR; i++) {
-      const int y = sy[i] * p.sm + dy, x = sx[i] * p.sm + dx;
-      const bool ok = m_ok && sb[i] < p.B && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-      ra[i] = ok ? ldg4(p.src + ((size_t)(sb[i] * p.Hs + y) * p.Ws + x) * p.lds + a_ch) : make_float4(0, 0, 0, 0);
-      sx[i] += BK;
-      while (sx[i] >= p.Wg) {
-        sx[i] -= p.Wg;
-        if (++sy[i] == p.Hg) { sy[i] = 0; sb[i]++; }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BR; i++) {
-      const int s = kt * BK + tid / BQ + BSTEP * i;
-      rb[i] = (n_ok && s < S) ? ldg4(bptr + (size_t)(BSTEP * i) * p.ldd) : make_float4(0, 0, 0, 0);
-    }
-    bptr += (size_t)BK * p.ldd;
+  // gathered operand row i of tile kt: site -> (b, yg, xg) by magic division (exact: site * Wg < 2^32)
+  auto piece_a = [&](int i, int kt) {
+    const unsigned sidx = (unsigned)(kt * BK + tid / AQ + ASTEP * i);
+    const unsigned q = fast_div(sidx, magW);
+    const int xg = (int)(sidx - q * (unsigned)p.Wg);
+    const unsigned bb = fast_div(q, magH);
+    const int yg = (int)(q - bb * (unsigned)p.Hg);
+    const int y = yg * p.sm + dy, x = xg * p.sm + dx;
+    const bool ok = (int)bb < p.B && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+    const int voff = ok ? (((int)bb * p.Hs + y) * p.Ws + x) * lds4 + a_base : OOB_MARK;
+    ra[i] = buf_ld4(src_rs, voff, 0);
   };
+  auto piece_b = [&](int i) {
+    rb[i] = buf_ld4(dst_rs, bvoff[i], 0);
+    bvoff[i] += bstep;   // may wrap past 2^31 only for tensors > 1 GB (then marked out of range anyway)
+  };
+  auto piece = [&](int step, int kt) {
+    if (step < AR) piece_a(step, kt);
+    else if (step < AR + BR) piece_b(step - AR);
+  };
+  static_assert(AR + BR <= 16, "pieces must fit the 16 steps");
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < AR; i++)
@@ -372,16 +434,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
-  if (kt0 < kt1) {
-    load_tile(kt0);
-    store_tile();
-  }
+#pragma unroll
+  for (int st = 0; st < 16; st++) piece(st, kt0);
+  store_tile();
   __syncthreads();
   const float* a = As + lh * BM + wm * WM + l31;
   const float* b = Bs + lh * BN + wn * WN + l31;
   for (int kt = kt0; kt < kt1; kt++) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
+    // tile kt+1 is loaded while tile kt is multiplied (past the last tile the loads read zeros / are harmless)
+    const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;
 #pragma unroll
     for (int s = 0; s < BK / 2; s++) {
       float av[TM], bv[TN];
@@ -394,9 +455,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < TN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      piece(s, ktn);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    if (more) store_tile();
+    store_tile();
     __syncthreads();
   }
 
@@ -826,7 +889,7 @@ inline void build_conv_fwd(GatherParams& p, int B, int H, int W, int Cin, int Co
   same_pads(H, k, stride, &pt, &Ho);
   same_pads(W, k, stride, &pl, &Wo);
   p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
-  p.dstep = 1; p.kstep = 1; p.KW = k; p.Cs = Cin; p.N = Cout;
+  p.dstep = 1; p.kstep = 1; p.KW = k; p.Cs = Cin; p.N = Cout; p.wtaps = k * k;
   p.Hd = Ho; p.Wd = Wo; p.so = 1; p.ncls = 1;
   p.cls[0] = TapClass{k, k, -pt, -pl, 0, 0, 0, 0};
 }
@@ -836,7 +899,7 @@ inline int build_conv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int C
   same_pads(H, k, stride, &pt, &Ho);
   same_pads(W, k, stride, &pl, &Wo);
   p.B = B; p.Hs = Ho; p.Ws = Wo; p.sm = 1;
-  p.dstep = -1; p.KW = k; p.Cs = Cout; p.N = Cin;
+  p.dstep = -1; p.KW = k; p.Cs = Cout; p.N = Cin; p.wtaps = k * k;
   p.Hd = H; p.Wd = W;
   if (stride == 1) {
     p.Hg = H; p.Wg = W; p.so = 1; p.ncls = 1; p.kstep = 1;
@@ -859,7 +922,7 @@ inline int build_conv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int C
 // conv_transpose k4 s2 'SAME': oy = 2*iy + ky - 1
 inline void build_deconv_fwd(GatherParams& p, int B, int H, int W, int Cin, int Cout) {
   p.B = B; p.Hg = H; p.Wg = W; p.Hs = H; p.Ws = W; p.sm = 1;
-  p.dstep = -1; p.kstep = 2; p.KW = 4; p.Cs = Cin; p.N = Cout;
+  p.dstep = -1; p.kstep = 2; p.KW = 4; p.Cs = Cin; p.N = Cout; p.wtaps = 16;
   p.Hd = 2 * H; p.Wd = 2 * W; p.so = 2; p.ncls = 4;
   for (int c = 0; c < 4; c++) {
     const int py = c >> 1, px = c & 1;
@@ -870,7 +933,7 @@ inline void build_deconv_fwd(GatherParams& p, int B, int H, int W, int Cin, int 
 
 inline void build_deconv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int Cout) {
   p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
-  p.dstep = 1; p.kstep = 1; p.KW = 4; p.Cs = Cout; p.N = Cin;
+  p.dstep = 1; p.kstep = 1; p.KW = 4; p.Cs = Cout; p.N = Cin; p.wtaps = 16;
   p.Hd = H; p.Wd = W; p.so = 1; p.ncls = 1;
   p.cls[0] = TapClass{4, 4, -1, -1, 0, 0, 0, 0};
 }
@@ -994,6 +1057,10 @@ int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
 template <bool B_NK>
 int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   p.cs_magic = magic_u32((unsigned)p.Cs);
+  {
+    static const int dbg = getenv("UNFLOW_DBG") ? atoi(getenv("UNFLOW_DBG")) : 0;
+    p.dbg = dbg;
+  }
   const GatherPlan pl = plan_gather(p);
   p.nsplit = pl.nsplit;
   p.partial = nullptr;
