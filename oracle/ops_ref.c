@@ -62,7 +62,9 @@ int ref_correlation_out_shape(int H, int W, int k, int md, int pad, int s1, int 
   if (k % 2 == 0) return ST_EVEN_KERNEL;
   corr_geom g = make_geom(H, W, k, md, pad, s1, s2);
   out3[0] = g.oc; out3[1] = g.oh; out3[2] = g.ow;
-  return (g.ow * g.oh > 0) ? ST_OK : ST_EMPTY_OUTPUT;
+  /* the reference tests the PRODUCT (correlation_op.cc:60), which lets two negative sizes through to a failing
+   * TF allocation; both sizes must be positive here */
+  return (g.ow > 0 && g.oh > 0) ? ST_OK : ST_EMPTY_OUTPUT;
 }
 
 /* Zero-padded channels-last copy of an NCHW tensor: what the two memsets and
@@ -89,7 +91,7 @@ int ref_correlation_fwd(const float* in0, const float* in1, float* out, int B, i
                         int H, int W, int k, int md, int pad, int s1, int s2) {
   if (k % 2 == 0) return ST_EVEN_KERNEL;
   corr_geom g = make_geom(H, W, k, md, pad, s1, s2);
-  if (g.ow * g.oh <= 0) return ST_EMPTY_OUTPUT;
+  if (g.ow <= 0 || g.oh <= 0) return ST_EMPTY_OUTPUT;
   float* P0 = padded_nhwc(in0, B, C, H, W, pad);
   float* P1 = padded_nhwc(in1, B, C, H, W, pad);
   const float denom = (float)(k * k * C);
@@ -135,7 +137,7 @@ int ref_correlation_bwd(const float* dout, const float* in0, const float* in1,
                         int md, int pad, int s1, int s2) {
   if (k % 2 == 0) return ST_EVEN_KERNEL;
   corr_geom g = make_geom(H, W, k, md, pad, s1, s2);
-  if (g.ow * g.oh <= 0) return ST_EMPTY_OUTPUT;
+  if (g.ow <= 0 || g.oh <= 0) return ST_EMPTY_OUTPUT;
   float* P0 = padded_nhwc(in0, B, C, H, W, pad);
   float* P1 = padded_nhwc(in1, B, C, H, W, pad);
   const float denom = (float)((2 * g.kr + 1) * (2 * g.kr + 1) * C);

@@ -1,0 +1,121 @@
+"""CPU (-m "not gpu"): the data-parallel exchange with gloo, world_size 2.
+
+(1) GradAllReducer: bucketed in-place SUM == sum of the ranks' buffers; mean_() == the reference's
+    average_gradients (src/e2eflow/core/train.py:388-422: concat + reduce_mean per variable).
+(2) N-rank sharded step == 1-rank step on the concatenated batch: each rank computes the gradient of
+    its shard's mean loss (here with the CPU oracle as the compute, the GPU engine being unavailable), the reducer
+    averages, and the result equals the single-process gradient of the full batch's loss.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker_reducer(rank, world, port, out_dir):
+    from unflow_amd.core.data_parallel import GradAllReducer
+    _init(rank, world, port)
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 100003                                    # not a multiple of the bucket size
+    buf = torch.randn(n, generator=g)
+    mine = buf.clone()
+    red = GradAllReducer(buf, world, bucket_bytes=64 * 1024)
+    assert len(red.bounds) > 1
+    red.all_reduce()
+    torch.save((mine, buf.clone()), os.path.join(out_dir, "sum%d.pt" % rank))
+    buf2 = mine.clone()
+    GradAllReducer(buf2, world, bucket_bytes=1 << 20).mean_()
+    torch.save(buf2, os.path.join(out_dir, "mean%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_grad_all_reducer_gloo(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_reducer, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mine0, sum0 = torch.load(tmp_path / "sum0.pt")
+    mine1, sum1 = torch.load(tmp_path / "sum1.pt")
+    assert torch.equal(sum0, sum1)
+    assert torch.allclose(sum0, mine0 + mine1, atol=1e-6)
+    m0, m1 = torch.load(tmp_path / "mean0.pt"), torch.load(tmp_path / "mean1.pt")
+    assert torch.equal(m0, m1)
+    # average_gradients: expand_dims + concat + reduce_mean over towers
+    assert torch.allclose(m0, torch.stack([mine0, mine1], 0).mean(0), atol=1e-6)
+
+
+H, W = 128, 128
+
+
+def _data(i):
+    g = torch.Generator().manual_seed(1234 + i)
+    return torch.rand(1, H, W, 3, generator=g) * 255, torch.rand(1, H, W, 3, generator=g) * 255
+
+
+def _flat_grad(P, im1, im2):
+    from oracle import model_ref as M
+    Pg = {k: v.clone().requires_grad_() for k, v in P.items()}
+    M.unsupervised_loss(Pg, im1, im2).backward()
+    return torch.cat([Pg[k].grad.reshape(-1) for k in Pg])
+
+
+def _worker_step(rank, world, port, out_dir):
+    from oracle import model_ref as M
+    from unflow_amd.core.data_parallel import GradAllReducer
+    torch.set_num_threads(2)
+    _init(rank, world, port)
+    P = M.init_params('C', 0)                     # same weights on every rank
+    im1, im2 = _data(rank)                        # distinct shard per rank
+    flat = _flat_grad(P, im1, im2)
+    GradAllReducer(flat, world).mean_()
+    if rank == 0:
+        torch.save(flat, os.path.join(out_dir, "dp.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_equals_one_rank_full_batch(tmp_path):
+    from oracle import model_ref as M
+    world, port = 2, _free_port()
+    mp.spawn(_worker_step, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    dp = torch.load(tmp_path / "dp.pt")
+    P = M.init_params('C', 0)
+    a, b = _data(0), _data(1)
+    full = _flat_grad(P, torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]]))
+    # every loss term is a mean over the replica batch (charbonnier_loss normaliser, losses.py:311-312), the L2
+    # term is data independent: mean of the shard gradients == gradient of the full-batch loss
+    rel = ((dp - full).abs().max() / full.abs().max()).item()
+    assert rel < 5e-3, rel     # fp32 torch-CPU conv gradients differ with the batch size (see test_engine_gpu.py)
+    cos = torch.nn.functional.cosine_similarity(dp, full, dim=0).item()
+    assert cos > 0.99999, cos
+
+
+def test_engine_layer_table_matches_reference_variables():
+    """Host logic of the engine that needs no GPU: the layer list equals the oracle's variable list and the
+    channel padding is zero-extension at the END of Cin."""
+    from unflow_amd.core import engine
+    from oracle import model_ref as M
+    layers = engine.flownet_c_layers()
+    spec = M.flownet_layer_specs('C')
+    assert [l.name for l in layers] == [s[0] for s in spec]
+    for l, s in zip(layers, spec):
+        assert (l.kind, l.k, l.cin, l.cout, l.stride, l.act) == s[1:]
+        assert l.cin_p >= l.cin and (l.cin_p % 4 == 0 or l.cin == 2)
+    n_logical = sum(l.k * l.k * l.cin * l.cout + l.cout for l in layers)
+    assert n_logical == 39175298
+    assert engine.LAYER_WEIGHTS == [12.7, 4.35, 3.9, 3.4, 1.1] and engine.LAYER_PATCH_DISTANCES == [3, 2, 2, 1, 1]
