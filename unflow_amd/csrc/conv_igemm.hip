@@ -965,27 +965,34 @@ struct GatherPlan {
   int nsplit;
 };
 
+// Resident workgroups per launch ("slots"): 256 CUs x blocks per CU of each tile config (LDS/VGPR bound:
+// 128x128 -> 3, 128x64 -> 4, 64x64 -> 6).  A split count is chosen so the launch is ONE full round of
+// resident blocks (blocks * nsplit <= slots, as close as possible): 1088 blocks on 768 slots run as 1.4 rounds.
+inline int fill_one_round(long blocks, int slots, int max_split) {
+  if (blocks >= slots) return 1;
+  int ns = (int)(slots / blocks);
+  if (ns > max_split) ns = max_split;
+  return ns < 1 ? 1 : ns;
+}
+
 inline GatherPlan plan_gather(const GatherParams& p) {
   GatherPlan pl;
   const long M = (long)p.B * p.Hg * p.Wg;
   if (p.N <= 32) pl.cfg = 2;
   else if (p.N <= 64) pl.cfg = 1;
   else pl.cfg = 0;
-  if (pl.cfg == 0 && ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls < 192) pl.cfg = 2;  // small: more, smaller tiles
-  const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
-  const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   int maxtaps = 0;
   for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
   const int KT = (maxtaps * p.Cs + BK - 1) / BK;
-  int ns = 1;
-  if (blocks < 512) {
-    ns = (int)((768 + blocks - 1) / blocks);
-    const int max_by_k = KT / 8 > 0 ? KT / 8 : 1;  // keep >= 8 K-tiles per split
-    if (ns > max_by_k) ns = max_by_k;
-    if (ns > 16) ns = 16;
-    if (ns < 1) ns = 1;
+  const int max_by_k = min(16, KT / 8 > 0 ? KT / 8 : 1);  // keep >= 8 K-tiles per split
+  if (pl.cfg == 0) {
+    const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
+    if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
   }
-  pl.nsplit = ns;
+  const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
+  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : 6);
+  const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
+  pl.nsplit = fill_one_round(blocks, slots, max_by_k);
   return pl;
 }
 
@@ -993,20 +1000,25 @@ inline size_t gather_partial_bytes(const GatherParams& p, int nsplit) {
   return nsplit > 1 ? (size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
 }
 
+// tile of the filter-gradient kernel: 0 = 128x128, 1 = 128x64, 2 = 256x128 (8 accumulators per wave)
+inline int wgrad_cfg(const WgradParams& p) {
+  static const int force = getenv("UNFLOW_WGRAD_CFG") ? atoi(getenv("UNFLOW_WGRAD_CFG")) : -1;  // tuning knob
+  const int Mp = p.KH * p.KW * p.Ca;
+  if (p.Cb <= 64) return 1;
+  if (force == 2) return Mp >= 1024 ? 2 : 0;
+  return 0;
+}
+
 inline int plan_wgrad(const WgradParams& p) {
   const int Mp = p.KH * p.KW * p.Ca;
-  const int bn = p.Cb <= 64 ? 64 : 128;
-  const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
+  const int cfg = wgrad_cfg(p);
+  const int bn = cfg == 1 ? 64 : 128, bm = cfg == 2 ? 256 : 128;
+  const long blocks = (long)cdiv(Mp, bm) * cdiv(p.Cb, bn);
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
-  int ns = 1;
-  if (blocks < 512) {
-    ns = (int)((1024 + blocks - 1) / blocks);
-    const int max_by_k = KT / 4 > 0 ? KT / 4 : 1;
-    if (ns > max_by_k) ns = max_by_k;
-    if (ns > 256) ns = 256;
-  }
-  return ns;
+  const int max_by_k = min(256, KT / 4 > 0 ? KT / 4 : 1);
+  const int slots = 256 * (cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // single-stage LDS 32 KB / 122 regs: 4 per CU
+  return fill_one_round(blocks, slots, max_by_k);
 }
 
 inline size_t wgrad_partial_bytes(const WgradParams& p, int nsplit) {
@@ -1110,7 +1122,10 @@ int run_wgrad(WgradParams& p, void* ws, size_t ws_bytes, size_t* used, hipStream
   p.nsplit = ns;
   p.partial = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
   *used = wgrad_partial_bytes(p, ns);
-  const int code = p.Cb <= 64 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st) : launch_wgrad_cfg<128, 128, 64, 64>(p, st);
+  const int cfg = wgrad_cfg(p);
+  const int code = cfg == 1 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st)
+                 : cfg == 2 ? launch_wgrad_cfg<256, 128, 128, 64>(p, st)
+                            : launch_wgrad_cfg<128, 128, 64, 64>(p, st);
   if (code != UNFLOW_OK) return code;
   if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);
   return UNFLOW_OK;
