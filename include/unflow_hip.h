@@ -217,6 +217,40 @@ int unflow_second_order_fwd_bwd(const float* flow, float flow_scale, float* loss
                                 int accumulate, float weight, float normalizer, int N, int H, int W,
                                 unflow_stream_t stream);
 
+/* Masks and the non-data terms of compute_losses (losses.py:25-73) in one pass over the directed batch:
+ *   mask = base_mask (broadcast over n_base samples; the down-sampled border mask) or, when base_mask is NULL,
+ *          create_outgoing_mask(flow*flow_scale) (losses.py:347-366);
+ *   fb_occ = |f + w|^2 > 0.01(|f|^2 + |w|^2) + 0.5 with w = warped_other*flow_scale (losses.py:43-49);
+ *   disocc_other = fwarp[(n+pair_shift)%N] < 0.8 (forward_warp of the partner's flow, losses.py:28-29);
+ *   occlusion_mode 0: none, 1: 'fb' (mask *= 1-fb_occ), 2: 'disocc' (mask *= 1-disocc_other) (losses.py:51-56);
+ *   loss_acc += occ_weight*charb(1-mask) + sym_weight*charb((1-mask)-disocc_other) + fb_weight*charb(f+w, mask),
+ *   each with the reference's normaliser (batch_per_direction*H*W*channels).
+ * mask_out [N,H,W] (may be NULL) receives the final mask for the data terms.  Only 'fb' is differentiable:
+ * d_flow (+)= its gradient wrt the raw flow, d_warped = its gradient wrt warped_other (feed to
+ * unflow_image_warp_bwd).  warped_other / fwarp may be NULL when no term needs them. */
+int unflow_mask_terms(const float* flow, const float* warped_other, const float* fwarp, const float* base_mask,
+                      int n_base, float flow_scale, int occlusion_mode, float* mask_out, float* loss_acc, float* d_flow,
+                      float* d_warped, int accumulate, float fb_weight, float occ_weight, float sym_weight,
+                      int batch_per_direction, int pair_shift, int N, int H, int W, unflow_stream_t stream);
+
+/* photometric_loss (losses.py:198-199): charbonnier(im1 - image_warp(im2, flow), mask, beta=255), fused with the warp;
+ * loss_acc[0] += weight*sum/normalizer; d_flow (+)= gradient wrt the raw flow.  mask: [n_mask,H,W]. */
+int unflow_photometric_fwd_bwd(const float* im, int ld_im, const float* flow, float flow_scale, const float* mask,
+                               int n_mask, float* loss_acc, float* d_flow, int accumulate, float weight, float normalizer,
+                               int pair_shift, int N, int H, int W, unflow_stream_t stream);
+
+/* smoothness_loss (losses.py:206-255): first-order forward differences of flow*flow_scale, Charbonnier. */
+int unflow_smooth_1st_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow, int accumulate,
+                              float weight, float normalizer, int N, int H, int W, unflow_stream_t stream);
+
+/* gradient_loss (losses.py:225-247): Sobel-gradient constancy between im1 and the warped second image [N,H,W,3].
+ * fwd writes gdiff [N,H,W,6] = d(weighted loss)/d(diff); bwd turns it into d/d(im2_warped) [N,H,W,3]
+ * (then unflow_image_warp_bwd gives the flow gradient). */
+int unflow_gradient_loss_fwd(const float* im1, int ld_im1, const float* im2_warped, const float* mask, int n_mask,
+                             float* gdiff, float* loss_acc, float weight, float normalizer, int N, int H, int W,
+                             unflow_stream_t stream);
+int unflow_gradient_loss_bwd(const float* gdiff, float* d_im2_warped, int N, int H, int W, unflow_stream_t stream);
+
 /* ===================================================================== */
 /* step plumbing                                                           */
 /* ===================================================================== */

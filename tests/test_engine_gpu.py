@@ -127,3 +127,57 @@ def test_adam_step_vs_oracle(dev):
     got = eng.export_tf_params()
     for k in P:
         assert (got[k] - P[k]).abs().max().item() < 2e-7, k     # <= 0.2 % of one Adam step (lr = 1e-4)
+
+
+FULL_PARAMS = [
+    # KITTI-style: forward-backward consistency + occlusion masking (config.ini [train_kitti]: fb 0.2, occ 12.4)
+    dict(flownet='C', pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0, fb_weight=0.2,
+         occ_weight=12.4, mask_occlusion='fb'),
+    # every term of compute_losses at once, outgoing mask instead of the border mask, disocclusion masking
+    dict(flownet='C', pyramid_loss=True, border_mask=False, ternary_weight=1.0, smooth_2nd_weight=3.0,
+         smooth_1st_weight=3.0, photo_weight=1.0, grad_weight=1.0, fb_weight=0.2, occ_weight=12.4, sym_weight=1.0,
+         mask_occlusion='disocc'),
+    # single-level loss (pyramid_loss off), photometric + first-order only
+    dict(flownet='C', pyramid_loss=False, border_mask=True, photo_weight=1.0, smooth_1st_weight=3.0),
+]
+
+
+@pytest.mark.parametrize("pi", range(len(FULL_PARAMS)))
+def test_all_loss_terms_vs_oracle(pi, dev):
+    """compute_losses with every term / mask mode (losses.py:16-87) through the engine vs the oracle: loss value and
+    the gradient wrt the five flow outputs (what the network backward consumes)."""
+    from unflow_amd.core.engine import FlowNetCEngine
+    from oracle import model_ref as M
+    params = FULL_PARAMS[pi]
+    B, H, W = 1, 128, 192
+    eng = FlowNetCEngine(B, H, W, params=params, device=dev, seed=None)
+    eng.init_params(seed=3)
+    g = torch.Generator().manual_seed(40 + pi)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.roll(im1, shifts=(1, -2), dims=(1, 2)) * 0.95 + torch.rand(B, H, W, 3, generator=g) * 12
+    # drive the loss with synthetic flows of realistic magnitude (random-init nets output ~0): overwrite flowN
+    eng.set_input(im1.to(dev), im2.to(dev))
+    flows = []
+    for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):
+        f = torch.randn(2 * B, H // d, W // d, 2, generator=g) * (1.5 / (lvl - 1))
+        eng.act['flow%d' % lvl].copy_(f.to(dev))
+        flows.append(f)
+    loss = eng.forward_loss(with_grad=True)
+    torch.cuda.synchronize()
+    reg = 0.0004 * 0.5 * sum((l.w.double() ** 2).sum().item() for l in eng.layers)
+    # oracle
+    fl = [f.clone().double().requires_grad_() for f in flows]
+    fw = [f[:B] for f in fl]
+    bw = [f[B:] for f in fl]
+    comb, terms = M.pyramid_loss_from_flows(im1.double(), im2.double(), fw, bw, params)
+    comb.backward()
+    assert abs((loss.item() - reg) - comb.item()) <= 2e-4 * abs(comb.item()), (loss.item() - reg, comb.item())
+    nlev = 5 if params.get('pyramid_loss') else 1
+    for k in range(5):
+        got = eng.grad['flow%d' % (k + 2)].cpu().double()
+        ref = fl[k].grad if k < nlev else torch.zeros_like(got)
+        scale = ref.abs().max().item() + 1e-12
+        # thresholded masks (fb_occ, disocc, outgoing) are discontinuous: allow a handful of pixels whose mask bit differs
+        # between fp32 (GPU) and fp64 (oracle); everything else must match tightly
+        bad = ((got - ref).abs() > 2e-4 * scale).float().mean().item()
+        assert bad < 2e-3, (k, bad)

@@ -36,7 +36,6 @@ LAYER_WEIGHTS = [12.7, 4.35, 3.9, 3.4, 1.1]        # unsupervised.py:87
 LAYER_PATCH_DISTANCES = [3, 2, 2, 1, 1]            # unsupervised.py:88
 L2_SCALE = 0.0004                                  # flownet.py:176
 LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']  # unsupervised.py:15
-IMPLEMENTED_LOSSES = ('ternary', 'smooth_2nd')
 
 DEFAULT_PARAMS = dict(flownet='C', pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0)
 
@@ -86,11 +85,8 @@ class FlowNetCEngine:
     def __init__(self, batch, height, width, params=None, device=None, seed=0):
         assert height % 64 == 0 and width % 64 == 0, "FlowNetC needs H, W divisible by 64"
         self.params = dict(DEFAULT_PARAMS) if params is None else dict(params)
-        for l in LOSSES:
-            if self.params.get(l + '_weight') and l not in IMPLEMENTED_LOSSES:
-                raise NotImplementedError("loss term '%s' is not implemented in the HIP step yet" % l)
-        if self.params.get('mask_occlusion'):
-            raise NotImplementedError("mask_occlusion is not implemented in the HIP step yet")
+        if self.params.get('mask_occlusion', '') not in ('', 'fb', 'disocc'):   # unsupervised.py:125-126
+            raise ValueError("mask_occlusion must be one of 'fb', 'disocc', ''")
         if self.params.get('flownet', 'C') != 'C':
             raise NotImplementedError("only flownet='C' is wired into the engine")
         self.B, self.H, self.W = batch, height, width
@@ -215,8 +211,6 @@ class FlowNetCEngine:
             if i + 1 < len(self.lv):
                 cur = ops.downsample(cur, 2)
                 cur1 = ops.downsample(cur1, 2)
-        if not use_border:
-            raise NotImplementedError("border_mask=False (create_outgoing_mask) is not wired into the engine yet")
 
     # ------------------------------------------------------------------ forward
     def _sl(self, name, lo, hi):
@@ -274,14 +268,18 @@ class FlowNetCEngine:
         self._conv('flow2', a['cat2'], a['flow2'])
 
     def forward_loss(self, with_grad=True):
-        """unsupervised.py:85-150 for the default [train] terms; also writes d(loss)/d(flowN) when with_grad."""
+        """compute_losses + the pyramid assembly (losses.py:16-87, unsupervised.py:85-150) over the directed batch;
+        with_grad also leaves d(loss)/d(flowN) in self.grad['flowN'].  Terms enter iff their `<name>_weight` is set
+        (unsupervised.py:136-141), exactly the pruning TF does."""
         lib = _lib.lib()
         st = stream()
         N, B = self.N, self.B
+        P = self.params
+        wt = lambda k: float(P.get(k + '_weight') or 0.0)
         self.loss_acc.zero_()
-        tw = float(self.params.get('ternary_weight') or 0.0)
-        sw = float(self.params.get('smooth_2nd_weight') or 0.0)
-        levels = self.lv if self.params.get('pyramid_loss') else self.lv[:1]
+        occl = {'': 0, None: 0, 'fb': 1, 'disocc': 2}[P.get('mask_occlusion', '')]
+        use_border = bool(P.get('border_mask'))
+        levels = self.lv if P.get('pyramid_loss') else self.lv[:1]
         # image pyramid: downsample(im, 4) then successive downsample(., 2) (unsupervised.py:99-100,145-146)
         check(lib.unflow_downsample_fwd(ptr(self.act['im01']), ptr(self.lv[0]['im']), N, self.H, self.W, 3, 4, st),
               "downsample")
@@ -289,35 +287,104 @@ class FlowNetCEngine:
             p = self.lv[i - 1]
             check(lib.unflow_downsample_fwd(ptr(p['im']), ptr(self.lv[i]['im']), N, p['h'], p['w'], 3, 2, st),
                   "downsample")
+        need_fbwarp = bool(wt('fb')) or occl == 1
+        need_fwarp = bool(wt('sym')) or occl == 2
+        need_mask_terms = need_fbwarp or need_fwarp or bool(wt('occ')) or not use_border
         for i, lv in enumerate(levels):
             h, w = lv['h'], lv['w']
             fs = FLOW_SCALE / (2 ** i)
             lw = LAYER_WEIGHTS[i]
-            gf = ptr(lv['gflow']) if with_grad else ptr(None)
-            if sw:
-                check(lib.unflow_second_order_fwd_bwd(ptr(lv['flow']), cf(fs), ptr(self.loss_acc), gf, 0, cf(lw * sw),
-                                                      cf(B * h * w * 4), N, h, w, st), "second_order")
-            elif with_grad:
-                lv['gflow'].zero_()
-            if tw:
+            flow, gflow = lv['flow'], lv['gflow']
+            gf = ptr(gflow) if with_grad else ptr(None)
+            n1 = B * h * w
+            wrote = [False]
+
+            def acc():      # first writer of gflow overwrites, later ones accumulate
+                a = 1 if wrote[0] else 0
+                wrote[0] = True
+                return a
+            # ---- smoothness terms (flow only)
+            if wt('smooth_2nd'):
+                check(lib.unflow_second_order_fwd_bwd(ptr(flow), cf(fs), ptr(self.loss_acc), gf, acc(),
+                                                      cf(lw * wt('smooth_2nd')), cf(n1 * 4), N, h, w, st), "second_order")
+            if wt('smooth_1st'):
+                check(lib.unflow_smooth_1st_fwd_bwd(ptr(flow), cf(fs), ptr(self.loss_acc), gf, acc(),
+                                                    cf(lw * wt('smooth_1st')), cf(n1 * 2), N, h, w, st), "smooth_1st")
+            if with_grad and not wrote[0]:
+                gflow.zero_()
+                wrote[0] = True
+            # ---- masks, fb / occ / sym
+            mask, n_mask = lv['mask'], 1
+            if need_mask_terms:
+                self._level_extra(lv)
+                warped = fwm = None
+                if need_fbwarp:     # image_warp(flow_other, flow_own) (losses.py:38-39); scaling is linear, applied later
+                    warped = lv['fwarped']
+                    check(lib.unflow_image_warp_fwd(ptr(flow), 2, ptr(flow), cf(fs), ptr(warped), ptr(None), B, N, h, w,
+                                                    2, st), "image_warp(flow)")
+                if need_fwarp:      # forward_warp(flow*scale) (losses.py:28-29), deterministic accumulation
+                    torch.mul(flow, fs, out=lv['fscaled'])
+                    fwm = lv['fwmap']
+                    ws = workspace(8 * N * h * w, self.dev, slot=2)
+                    check(lib.unflow_forward_warp_fwd(ptr(lv['fscaled']), ptr(fwm), N, h, w, 1, ptr(ws),
+                                                      _lib.csz(ws.numel() * 4), st), "forward_warp")
+                a = acc() if (with_grad and wt('fb')) else 0
+                check(lib.unflow_mask_terms(ptr(flow), ptr(warped), ptr(fwm), ptr(lv['mask'] if use_border else None), 1,
+                                            cf(fs), occl, ptr(lv['maskN']), ptr(self.loss_acc),
+                                            gf if wt('fb') else ptr(None), ptr(lv['gwarped']), a, cf(lw * wt('fb')),
+                                            cf(lw * wt('occ')), cf(lw * wt('sym')), B, B, N, h, w, st), "mask_terms")
+                mask, n_mask = lv['maskN'], N
+                if with_grad and wt('fb'):
+                    # back through image_warp(flow_other, flow_own): scatter into the partner's flow gradient (via a
+                    # scratch buffer: the scatter must not race with the in-place accumulation) + own flow gradient
+                    lv['dimtmp'].zero_()
+                    check(lib.unflow_image_warp_bwd(ptr(lv['gwarped']), ptr(flow), 2, ptr(flow), cf(fs), ptr(lv['dimtmp']),
+                                                    ptr(gflow), 1, B, N, h, w, 2, st), "image_warp_bwd(flow)")
+                    gflow.add_(lv['dimtmp'])
+            # ---- data terms
+            if wt('ternary'):
                 D = LAYER_PATCH_DISTANCES[i]
                 check(lib.unflow_rgb_to_gray255(ptr(lv['im']), 3, ptr(lv['gray1']), cl(N * h * w), st), "gray")
-                check(lib.unflow_warp_gray_fwd(ptr(lv['im']), 3, ptr(lv['flow']), cf(fs), ptr(lv['gray2w']), B, N, h,
-                                               w, st), "warp_gray")
-                check(lib.unflow_ternary_fwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(lv['mask']), 1, ptr(lv['dist']),
-                                             ptr(self.loss_acc), cf(lw * tw), cf(B * h * w), D, N, h, w, st), "ternary")
+                check(lib.unflow_warp_gray_fwd(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(lv['gray2w']), B, N, h, w, st),
+                      "warp_gray")
+                check(lib.unflow_ternary_fwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(mask), n_mask, ptr(lv['dist']),
+                                             ptr(self.loss_acc), cf(lw * wt('ternary')), cf(n1), D, N, h, w, st), "ternary")
                 if with_grad:
-                    check(lib.unflow_ternary_bwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(lv['mask']), 1,
-                                                 ptr(lv['dist']), ptr(lv['dgray']), cf(lw * tw), cf(B * h * w), D, N,
-                                                 h, w, st), "ternary_bwd")
-                    check(lib.unflow_warp_gray_bwd(ptr(lv['dgray']), ptr(lv['im']), 3, ptr(lv['flow']), cf(fs),
-                                                   ptr(lv['gflow']), 1, B, N, h, w, st), "warp_gray_bwd")
-        if with_grad and not self.params.get('pyramid_loss'):
+                    check(lib.unflow_ternary_bwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(mask), n_mask, ptr(lv['dist']),
+                                                 ptr(lv['dgray']), cf(lw * wt('ternary')), cf(n1), D, N, h, w, st),
+                          "ternary_bwd")
+                    check(lib.unflow_warp_gray_bwd(ptr(lv['dgray']), ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(gflow), 1, B,
+                                                   N, h, w, st), "warp_gray_bwd")
+            if wt('photo'):
+                check(lib.unflow_photometric_fwd_bwd(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(mask), n_mask,
+                                                     ptr(self.loss_acc), gf, 1, cf(lw * wt('photo')), cf(n1 * 3), B, N, h,
+                                                     w, st), "photometric")
+            if wt('grad'):
+                self._level_extra(lv)
+                check(lib.unflow_image_warp_fwd(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(lv['imw']), ptr(None), B, N, h, w,
+                                                3, st), "image_warp(im)")
+                check(lib.unflow_gradient_loss_fwd(ptr(lv['im']), 3, ptr(lv['imw']), ptr(mask), n_mask, ptr(lv['gdiff']),
+                                                   ptr(self.loss_acc), cf(lw * wt('grad')), cf(n1 * 6), N, h, w, st),
+                      "gradient_loss")
+                if with_grad:
+                    check(lib.unflow_gradient_loss_bwd(ptr(lv['gdiff']), ptr(lv['dimw']), N, h, w, st), "gradient_loss_bwd")
+                    check(lib.unflow_image_warp_bwd(ptr(lv['dimw']), ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(None),
+                                                    ptr(gflow), 1, B, N, h, w, 3, st), "image_warp_bwd(im)")
+        if with_grad and not P.get('pyramid_loss'):
             for lv in self.lv[1:]:
                 lv['gflow'].zero_()
         # regularisation term (value only; its gradient is fused into adam_step)
         check(lib.unflow_l2_loss(ptr(self.P), cl(self.n_weights), cf(L2_SCALE), ptr(self.loss_acc), st), "l2_loss")
         return self.loss_acc
+
+    def _level_extra(self, lv):
+        """Buffers only the non-default loss terms need (allocated on first use, before any graph capture)."""
+        if 'maskN' in lv:
+            return
+        N, h, w = self.N, lv['h'], lv['w']
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
+        lv.update(maskN=z(N, h, w), fwarped=z(N, h, w, 2), gwarped=z(N, h, w, 2), dimtmp=z(N, h, w, 2),
+                  fscaled=z(N, h, w, 2), fwmap=z(N, h, w), imw=z(N, h, w, 3), gdiff=z(N, h, w, 6), dimw=z(N, h, w, 3))
 
     # ------------------------------------------------------------------ backward
     def _bwd(self, lname, x, dz, dx=None, accumulate=False, act_src=None, act_lo=0, act_hi=0):

@@ -300,3 +300,274 @@ UNFLOW_API int unflow_second_order_fwd_bwd(const float* flow, float flow_scale, 
       flow, flow_scale, loss_acc, d_flow, accumulate, weight / normalizer, N, H, W);
   return launch_status();
 }
+
+// ------------------------------------------------------------------ masks + fb / occ / sym terms (losses.py:25-73)
+// One pass per level over the directed batch.  Sample n's partner is m = (n + shift) % N.
+//   u      = flow[n]*fs                         (own flow, scaled)
+//   wv     = warped[n]*fs                       (partner's flow warped by own flow: image_warp(flow_other, flow_own))
+//   mask   = border mask (broadcast) or create_outgoing_mask(u) (losses.py:31-36,347-366)
+//   fb_occ = |u+wv|^2 > 0.01(|u|^2+|wv|^2)+0.5  (losses.py:43-49)
+//   disocc_other = forward_warp(flow_other*fs) < 0.8 at this pixel (losses.py:28-29)
+//   mask_occlusion 'fb': mask *= 1-fb_occ; 'disocc': mask *= 1-disocc_other (losses.py:51-56)
+//   losses: occ = charb(1-mask); sym = charb((1-mask) - disocc_other); fb = charb(u+wv, mask)   (losses.py:61-79)
+// Only fb has a gradient (thresholds and masks are non-differentiable casts): d/du direct, d/dwv handed to
+// image_warp's backward by the caller.
+__global__ __launch_bounds__(256) void mask_terms_kernel(const float* __restrict__ flow, const float* __restrict__ warped,
+                                                         const float* __restrict__ fwarp, const float* __restrict__ base,
+                                                         int n_base, float fs, int occl_mode, float* __restrict__ mask_out,
+                                                         float* __restrict__ loss_acc, float* __restrict__ gflow,
+                                                         float* __restrict__ gwarped, int acc, float s_fb, float s_occ,
+                                                         float s_sym, int shift, int N, int H, int W) {
+  __shared__ float red[4];
+  const long npx = (long)N * H * W;
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    const long pix = (long)y * W + x;
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const float ux = f.x * fs, uy = f.y * fs;
+    float mask;
+    if (base) {
+      mask = base[(long)(n % n_base) * H * W + pix];
+    } else {
+      const float px = (float)x + ux, py = (float)y + uy;
+      mask = (px <= (float)(W - 1) && px >= 0.f && py <= (float)(H - 1) && py >= 0.f) ? 1.f : 0.f;
+    }
+    float dxx = 0.f, dyy = 0.f, fb_occ = 0.f;
+    if (warped) {
+      const float2 wv = reinterpret_cast<const float2*>(warped)[i];
+      const float wx = wv.x * fs, wy = wv.y * fs;
+      dxx = ux + wx;
+      dyy = uy + wy;
+      const float mag = (ux * ux + uy * uy) + (wx * wx + wy * wy);
+      fb_occ = (dxx * dxx + dyy * dyy) > (0.01f * mag + 0.5f) ? 1.f : 0.f;
+    }
+    float dis = 0.f;
+    if (fwarp) dis = fwarp[(long)((n + shift) % N) * H * W + pix] < 0.8f ? 1.f : 0.f;
+    if (occl_mode == 1) mask *= (1.f - fb_occ);
+    else if (occl_mode == 2) mask *= (1.f - dis);
+    if (mask_out) mask_out[i] = mask;
+    const float occ = 1.f - mask;
+    if (s_occ != 0.f) local += s_occ * charb(occ);
+    if (s_sym != 0.f) local += s_sym * charb(occ - dis);
+    if (s_fb != 0.f) {
+      local += s_fb * mask * (charb(dxx) + charb(dyy));
+      if (gflow) {
+        const float gx = s_fb * mask * charb_grad(dxx) * fs, gy = s_fb * mask * charb_grad(dyy) * fs;
+        float2* o = reinterpret_cast<float2*>(gflow) + i;
+        float2 e = acc ? *o : make_float2(0.f, 0.f);
+        *o = make_float2(e.x + gx, e.y + gy);
+        reinterpret_cast<float2*>(gwarped)[i] = make_float2(gx, gy);
+      }
+    }
+  }
+  const float t = block_sum(local, red);
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t);
+}
+
+UNFLOW_API int unflow_mask_terms(const float* flow, const float* warped_other, const float* fwarp, const float* base_mask,
+                                 int n_base, float flow_scale, int occlusion_mode, float* mask_out, float* loss_acc,
+                                 float* d_flow, float* d_warped, int accumulate, float fb_weight, float occ_weight,
+                                 float sym_weight, int batch_per_direction, int pair_shift, int N, int H, int W,
+                                 unflow_stream_t stream) {
+  if (!flow) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || batch_per_direction <= 0) return UNFLOW_ERR_SHAPE;
+  if (fb_weight != 0.f && !warped_other) return UNFLOW_ERR_NULL;
+  if ((occlusion_mode == 1 && !warped_other) || (occlusion_mode == 2 && !fwarp) || (sym_weight != 0.f && !fwarp)) return UNFLOW_ERR_NULL;
+  if (d_flow && fb_weight != 0.f && !d_warped) return UNFLOW_ERR_NULL;
+  const float n1 = (float)batch_per_direction * H * W;
+  mask_terms_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      flow, warped_other, fwarp, base_mask, n_base > 0 ? n_base : 1, flow_scale, occlusion_mode, mask_out, loss_acc, d_flow,
+      d_warped, accumulate, fb_weight / (n1 * 2.f), occ_weight / n1, sym_weight / n1, pair_shift, N, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ photometric loss (losses.py:198-199), fused with the warp
+// charbonnier(im1 - image_warp(im2, flow), mask, beta = 255); normaliser N_dir*H*W*3.  fwd + flow gradient in one pass.
+__global__ __launch_bounds__(256) void photometric_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow,
+                                                          float fs, const float* __restrict__ mask, int n_mask,
+                                                          float* __restrict__ loss_acc, float* __restrict__ dflow, int acc,
+                                                          float scale, int shift, int N, int H, int W) {
+  __shared__ float red[4];
+  const long npx = (long)N * H * W;
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % W), py = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    const long sb = (long)((n + shift) % N) * H * W;
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const Taps t = iw_taps(px, py, f.x * fs, f.y * fs, H, W);
+    const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
+                *pd = im + (sb + t.id) * ld;
+    const float* p1 = im + i * ld;
+    const float m = mask[(long)(n % n_mask) * H * W + (long)py * W + px];
+    float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float w = ((t.wa * pa[k] + t.wb * pb[k]) + t.wc * pc[k]) + t.wd * pd[k];
+      const float d = (p1[k] - w) * 255.0f;
+      local += m * powf(d * d + CHARB_EPS * CHARB_EPS, CHARB_ALPHA);
+      // d/dw of ((x*beta)^2+eps^2)^alpha with x = im1 - w
+      const float g = -m * CHARB_ALPHA * powf(d * d + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * d * 255.0f;
+      ga += g * pa[k]; gb += g * pb[k]; gc += g * pc[k]; gd += g * pd[k];
+    }
+    if (dflow) {
+      float du = ((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw) * fs * scale;
+      float dv = ((gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw) * fs * scale;
+      float2* o = reinterpret_cast<float2*>(dflow) + i;
+      if (acc) { const float2 e = *o; du += e.x; dv += e.y; }
+      *o = make_float2(du, dv);
+    }
+  }
+  const float tt = block_sum(local, red);
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, tt * scale);
+}
+
+UNFLOW_API int unflow_photometric_fwd_bwd(const float* im, int ld_im, const float* flow, float flow_scale,
+                                          const float* mask, int n_mask, float* loss_acc, float* d_flow, int accumulate,
+                                          float weight, float normalizer, int pair_shift, int N, int H, int W,
+                                          unflow_stream_t stream) {
+  if (!im || !flow || !mask) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || ld_im < 3 || n_mask <= 0) return UNFLOW_ERR_SHAPE;
+  photometric_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      im, ld_im, flow, flow_scale, mask, n_mask, loss_acc, d_flow, accumulate, weight / normalizer, pair_shift, N, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ first-order smoothness (losses.py:206-255)
+// delta_x(p) = f(p) - f(p+(0,1)) (masked on the last column), delta_y(p) = f(p) - f(p+(1,0)) (last row);
+// Charbonnier on each, normaliser N_dir*H*W*2 per flow channel.
+__global__ __launch_bounds__(256) void smooth_1st_kernel(const float* __restrict__ flow, float fs, float* __restrict__ loss_acc,
+                                                         float* __restrict__ dflow, int acc, float scale, int N, int H, int W) {
+  __shared__ float red[4];
+  const long npx = (long)N * H * W;
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float2* f = reinterpret_cast<const float2*>(flow) + (i - ((long)y * W + x));
+    const float2 c = f[(long)y * W + x];
+    float gu = 0.f, gv = 0.f;
+    if (x + 1 < W) {  // own delta_x
+      const float2 r = f[(long)y * W + x + 1];
+      const float du = (c.x - r.x) * fs, dv = (c.y - r.y) * fs;
+      local += charb(du) + charb(dv);
+      gu += charb_grad(du); gv += charb_grad(dv);
+    }
+    if (x >= 1) {  // left neighbour's delta_x contains -f(p)
+      const float2 l = f[(long)y * W + x - 1];
+      gu -= charb_grad((l.x - c.x) * fs); gv -= charb_grad((l.y - c.y) * fs);
+    }
+    if (y + 1 < H) {
+      const float2 d = f[(long)(y + 1) * W + x];
+      const float du = (c.x - d.x) * fs, dv = (c.y - d.y) * fs;
+      local += charb(du) + charb(dv);
+      gu += charb_grad(du); gv += charb_grad(dv);
+    }
+    if (y >= 1) {
+      const float2 u = f[(long)(y - 1) * W + x];
+      gu -= charb_grad((u.x - c.x) * fs); gv -= charb_grad((u.y - c.y) * fs);
+    }
+    if (dflow) {
+      float2* o = reinterpret_cast<float2*>(dflow) + i;
+      float a = gu * scale * fs, b = gv * scale * fs;
+      if (acc) { const float2 e = *o; a += e.x; b += e.y; }
+      *o = make_float2(a, b);
+    }
+  }
+  const float t = block_sum(local, red);
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
+}
+
+UNFLOW_API int unflow_smooth_1st_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow,
+                                         int accumulate, float weight, float normalizer, int N, int H, int W,
+                                         unflow_stream_t stream) {
+  if (!flow) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0) return UNFLOW_ERR_SHAPE;
+  smooth_1st_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(flow, flow_scale, loss_acc, d_flow,
+                                                                                 accumulate, weight / normalizer, N, H, W);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------ gradient (Sobel) constancy loss (losses.py:225-247)
+// diff[c][x|y] = sobel(im1)[c] - sobel(im2_warped)[c] (SAME zero padding), Charbonnier, mask * gradient_mask
+// (x-gradient channels zero on the first/last column, y-gradient channels on the first/last row); normaliser N_dir*H*W*6.
+__device__ __forceinline__ float img_at(const float* __restrict__ im, int ld, int H, int W, int y, int x, int c) {
+  return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? im[((long)y * W + x) * ld + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gradient_loss_fwd_kernel(const float* __restrict__ im1, int ld1,
+                                                                const float* __restrict__ im2w, const float* __restrict__ mask,
+                                                                int n_mask, float* __restrict__ gdiff,
+                                                                float* __restrict__ loss_acc, float scale, int N, int H, int W) {
+  __shared__ float red[4];
+  const long npx = (long)N * H * W;
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long n = i / ((long)W * H);
+    const float* a = im1 + n * H * W * ld1;
+    const float* b = im2w + n * H * W * 3;
+    const float m = mask[(n % n_mask) * (long)H * W + (long)y * W + x];
+    const float mx = (x >= 1 && x < W - 1) ? m : 0.f, my = (y >= 1 && y < H - 1) ? m : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float gx = 0.f, gy = 0.f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+          const float v = img_at(a, ld1, H, W, y + dy, x + dx, c) - img_at(b, 3, H, W, y + dy, x + dx, c);
+          gx += (float)(dx * (dy == 0 ? 2 : 1)) * v;   // [[-1,0,1],[-2,0,2],[-1,0,1]]
+          gy += (float)(dy * (dx == 0 ? 2 : 1)) * v;   // its transpose
+        }
+      local += mx * charb(gx) + my * charb(gy);
+      gdiff[i * 6 + 2 * c] = scale * mx * charb_grad(gx);
+      gdiff[i * 6 + 2 * c + 1] = scale * my * charb_grad(gy);
+    }
+  }
+  const float t = block_sum(local, red);
+  if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
+}
+
+// d/d(im2_warped)[q,c] = - sum_t coef(t) * gdiff[q - t]  (gather form)
+__global__ void gradient_loss_bwd_kernel(const float* __restrict__ gdiff, float* __restrict__ d_im2w, int N, int H, int W) {
+  const long npx = (long)N * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long n = i / ((long)W * H);
+    const float* g = gdiff + n * H * W * 6;
+    float out[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int py = y - dy, px = x - dx;  // pixel p whose stencil tap (dy,dx) lands on q
+        if ((unsigned)py >= (unsigned)H || (unsigned)px >= (unsigned)W) continue;
+        const float cx = (float)(dx * (dy == 0 ? 2 : 1)), cy = (float)(dy * (dx == 0 ? 2 : 1));
+        const float* gp = g + ((long)py * W + px) * 6;
+#pragma unroll
+        for (int c = 0; c < 3; c++) out[c] -= cx * gp[2 * c] + cy * gp[2 * c + 1];
+      }
+    d_im2w[i * 3] = out[0];
+    d_im2w[i * 3 + 1] = out[1];
+    d_im2w[i * 3 + 2] = out[2];
+  }
+}
+
+UNFLOW_API int unflow_gradient_loss_fwd(const float* im1, int ld_im1, const float* im2_warped, const float* mask, int n_mask,
+                                        float* gdiff, float* loss_acc, float weight, float normalizer, int N, int H, int W,
+                                        unflow_stream_t stream) {
+  if (!im1 || !im2_warped || !mask || !gdiff) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || n_mask <= 0) return UNFLOW_ERR_SHAPE;
+  gradient_loss_fwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      im1, ld_im1, im2_warped, mask, n_mask, gdiff, loss_acc, weight / normalizer, N, H, W);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_gradient_loss_bwd(const float* gdiff, float* d_im2_warped, int N, int H, int W, unflow_stream_t stream) {
+  if (!gdiff || !d_im2_warped) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0) return UNFLOW_ERR_SHAPE;
+  gradient_loss_bwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(gdiff, d_im2_warped, N, H, W);
+  return launch_status();
+}
