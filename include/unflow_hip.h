@@ -260,6 +260,13 @@ int unflow_gradient_loss_bwd(const float* gdiff, float* d_im2_warped, int N, int
 int unflow_prepare_images(const float* im_u8range, float* net_in4, float* out01, const float* mean3, long npix,
                           unflow_stream_t stream);
 
+/* Input tensor of a FlowNetS stage (flownet.py:46-59), channels-last with stride ld_out (pad channels untouched):
+ * [first, second] (6 ch) when prev_flow2 == NULL, else [first, second, flow, warp(second, flow), |warp - first|]
+ * (14 ch) with flow = resize_bilinear(prev_flow2 [N,h,w,2]) * flow_scale (= 4 * FLOW_SCALE).  Forward only: the
+ * reference stops the gradient here unless train_all (flownet.py:51-54). */
+int unflow_stack_input(const float* net_in4, const float* prev_flow2, float* out, int ld_out, int pair_shift, int N,
+                       int H, int W, int h, int w, float flow_scale, unflow_stream_t stream);
+
 /* tf.image.resize_bilinear (TF1 legacy, align_corners=False) * scale (unsupervised.py:103-104). */
 int unflow_resize_bilinear_tf1(const float* in, float* out, int B, int H, int W, int C, int out_h, int out_w,
                                float scale, unflow_stream_t stream);

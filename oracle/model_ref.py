@@ -230,20 +230,58 @@ def flownet_s(P, inputs_nhwc, pre='flownet_s/'):
     return [t.permute(0, 2, 3, 1) for t in res]
 
 
-def flownet(P, im1, im2, flownet_spec='C', backward_flow=False):
-    """flownet.py:14-81 for the single-network specs 'C' and 'S'."""
-    if flownet_spec == 'C':
-        _, conv2_a, conv3_a = flownet_c_features(P, im1)
-        _, conv2_b, conv3_b = flownet_c_features(P, im2)
-        fw = flownet_c(P, conv3_a, conv3_b, conv2_a)
-        if backward_flow:
-            return [fw], [flownet_c(P, conv3_b, conv3_a, conv2_b)]
-        return [fw]
-    assert flownet_spec == 'S'
-    fw = flownet_s(P, torch.cat([im1, im2], 3))
+def flownet(P, im1, im2, flownet_spec='C', backward_flow=False, train_all=False):
+    """flownet.py:14-81 (full_resolution off).  'C', 'S' and stacked specs ('CS', 'CSS', 'SS' ...): every later net is
+    a FlowNetS on [im1, im2, flow*20 upsampled, warp(im2, flow), |warp - im1|] of the previous net's finest flow,
+    with stop_gradient on flow/warp/diff unless train_all (:46-57).  Variable scopes: first net 'flownet_c*/' or
+    'flownet_s/', net i >= 1 'stack_<i>_flownet/flownet_s/' (:72-77)."""
+    H, W = im1.shape[1:3]
+    flows_fw, flows_bw = [], []
+    for i, name in enumerate(flownet_spec):
+        assert name in ('C', 'S')
+        scope = '' if i == 0 else 'stack_%d_flownet/' % i
+        if name == 'C':
+            assert i == 0, 'FlowNetS must be used for refinement networks'
+            _, conv2_a, conv3_a = flownet_c_features(P, im1)
+            _, conv2_b, conv3_b = flownet_c_features(P, im2)
+            flows_fw.append(flownet_c(P, conv3_a, conv3_b, conv2_a))
+            if backward_flow:
+                flows_bw.append(flownet_c(P, conv3_b, conv3_a, conv2_b))
+        else:
+            def _s(a, b, flow):
+                if flow is not None:
+                    flow = resize_bilinear_tf1(flow, H, W) * 4 * FLOW_SCALE
+                    warp = image_warp(b, flow)
+                    diff = torch.abs(warp - a)
+                    if not train_all:
+                        flow, warp, diff = flow.detach(), warp.detach(), diff.detach()
+                    inputs = torch.cat([a, b, flow, warp, diff], 3)
+                else:
+                    inputs = torch.cat([a, b], 3)
+                return flownet_s(P, inputs, pre=scope + 'flownet_s/')
+            stacked = len(flows_fw) > 0
+            flows_fw.append(_s(im1, im2, flows_fw[-1][0] if stacked else None))
+            if backward_flow:
+                flows_bw.append(_s(im2, im1, flows_bw[-1][0] if stacked else None))
     if backward_flow:
-        return [fw], [flownet_s(P, torch.cat([im2, im1], 3))]
-    return [fw]
+        return flows_fw, flows_bw
+    return flows_fw
+
+
+def init_params_spec(flownet_spec='C', seed=0):
+    """Variables of a (possibly stacked) spec with the reference's scope names."""
+    gen = torch.Generator().manual_seed(seed)
+    P = OrderedDict()
+    for i, name in enumerate(flownet_spec):
+        scope = '' if i == 0 else 'stack_%d_flownet/' % i
+        for lname, kind, k, cin, cout, stride, act in flownet_layer_specs(name, 14 if i > 0 else 6):
+            lname = scope + lname
+            if kind == 'conv':
+                P[lname + '/weights'] = _vs_init((k, k, cin, cout), k * k * cin, gen)
+            else:
+                P[lname + '/weights'] = _vs_init((k, k, cout, cin), k * k * cout, gen)
+            P[lname + '/biases'] = torch.zeros(cout)
+    return P
 
 
 # ----------------------------------------------------------------------------
@@ -544,7 +582,8 @@ def unsupervised_loss(P, im1, im2, params=None, return_flow=False):
     mean = torch.tensor(CHANNEL_MEAN, dtype=im1.dtype) / 255.0
     a = im1 / 255.0 - mean
     b = im2 / 255.0 - mean
-    flows_fw, flows_bw = flownet(P, a, b, flownet_spec=params.get('flownet', 'S'), backward_flow=True)
+    flows_fw, flows_bw = flownet(P, a, b, flownet_spec=params.get('flownet', 'S'), backward_flow=True,
+                                 train_all=bool(params.get('train_all')))
     flows_fw, flows_bw = flows_fw[-1], flows_bw[-1]
     combined, terms = pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params)
     final_loss = combined + regularization_loss(P)

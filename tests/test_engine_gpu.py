@@ -181,3 +181,41 @@ def test_all_loss_terms_vs_oracle(pi, dev):
         # between fp32 (GPU) and fp64 (oracle); everything else must match tightly
         bad = ((got - ref).abs() > 2e-4 * scale).float().mean().item()
         assert bad < 2e-3, (k, bad)
+
+
+@pytest.mark.parametrize("spec", ["S", "CS", "CSS"])
+def test_flownet_s_and_stacks_vs_oracle(spec, dev):
+    """FlowNetS and the stacked specs (flownet.py:46-77; BASELINE config 4 is 'CSS'): forward flows of every stage,
+    loss, and the gradients of the trained (last) network vs the oracle; earlier nets get no data gradient."""
+    from unflow_amd.core.engine import FlowNetEngine, flow_error_avg
+    from oracle import model_ref as M
+    B, H, W = 1, 128, 128
+    params = dict(flownet=spec, pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0)
+    eng = FlowNetEngine(B, H, W, params=params, device=dev, seed=None)
+    tf_params = M.init_params_spec(spec, seed=7)
+    assert [l.name for l in eng.layers] == [k[:-8] for k in tf_params if k.endswith('/weights')]
+    eng.load_tf_params(tf_params)
+    g = torch.Generator().manual_seed(8)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.roll(im1, shifts=(1, 2), dims=(1, 2)) * 0.9 + torch.rand(B, H, W, 3, generator=g) * 25
+    P64 = {k: v.clone().double().requires_grad_() for k, v in tf_params.items()}
+    loss_ref, ffw, fbw, _ = M.unsupervised_loss(P64, im1.double(), im2.double(), params, return_flow=True)
+    loss_ref.backward()
+    loss = eng.fwd_bwd(im1.to(dev), im2.to(dev))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    fw, bw = eng.final_flows()
+    assert flow_error_avg(fw, ffw.float().to(dev)).item() < 1e-3
+    assert flow_error_avg(bw, fbw.float().to(dev)).item() < 1e-3
+    got = eng.export_tf_grads()
+    last_scope = '' if len(spec) == 1 else 'stack_%d_flownet/' % (len(spec) - 1)
+    for k, v in P64.items():
+        l2 = 0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0
+        gref = (v.grad if v.grad is not None else torch.zeros_like(v)) - l2
+        if len(spec) > 1 and not k.startswith(last_scope):
+            assert got[k].abs().max().item() == 0.0 and gref.abs().max().item() < 1e-12, k   # frozen stage
+        else:
+            # single net: fp32-vs-fp64 noise only; stacks: the refinement input (warp by the previous net's fp32 flow,
+            # |.|, leaky kinks) amplifies that noise ~10x per stage
+            tol = 3e-4 * 10 ** (len(spec) - 1) if len(spec) < 3 else 1e-2
+            assert _rel(got[k], gref) < tol, (k, _rel(got[k], gref))

@@ -1,4 +1,4 @@
-"""Static-plan training-step engine for FlowNetC (and FlowNetS) on one MI355X.
+"""Static-plan training-step engine for FlowNetC / FlowNetS / stacked C->S->S on one MI355X.
 
 Replaces, for the hot path, what TensorFlow's executor does for the reference graph built by
   core/flownet.py:14-237  (network, shared weights for both images and both flow directions)
@@ -57,16 +57,9 @@ class Layer:
         return (self.k, self.k, self.cout, self.cin_p)       # conv2d_transpose: [k,k,out,in]
 
 
-def flownet_c_layers():
-    """Variables of flownet_c_features + flownet_c in the reference's creation order (flownet.py:195-237,89-131)."""
-    f, c = 'flownet_c_features/', 'flownet_c/'
+def _decoder_layers(c, skip2=128):
+    """_flownet_upconv variables (flownet.py:89-131) under scope prefix c."""
     return [
-        Layer(f + 'conv1', 'conv', 7, 3, 64, 2, True), Layer(f + 'conv2', 'conv', 5, 64, 128, 2, True),
-        Layer(f + 'conv3', 'conv', 5, 128, 256, 2, True),
-        Layer(c + 'conv_redir', 'conv', 1, 256, 32, 1, True), Layer(c + 'conv3_1', 'conv', 3, 473, 256, 1, True),
-        Layer(c + 'conv4', 'conv', 3, 256, 512, 2, True), Layer(c + 'conv4_1', 'conv', 3, 512, 512, 1, True),
-        Layer(c + 'conv5', 'conv', 3, 512, 512, 2, True), Layer(c + 'conv5_1', 'conv', 3, 512, 512, 1, True),
-        Layer(c + 'conv6', 'conv', 3, 512, 1024, 2, True), Layer(c + 'conv6_1', 'conv', 3, 1024, 1024, 1, True),
         Layer(c + 'flow6', 'conv', 3, 1024, 2, 1, False),
         Layer(c + 'deconv5', 'deconv', 4, 1024, 512, 2, True), Layer(c + 'flow6_up5', 'deconv', 4, 2, 2, 2, False),
         Layer(c + 'flow5', 'conv', 3, 1026, 2, 1, False),
@@ -75,25 +68,213 @@ def flownet_c_layers():
         Layer(c + 'deconv3', 'deconv', 4, 770, 128, 2, True), Layer(c + 'flow4_up3', 'deconv', 4, 2, 2, 2, False),
         Layer(c + 'flow3', 'conv', 3, 386, 2, 1, False),
         Layer(c + 'deconv2', 'deconv', 4, 386, 64, 2, True), Layer(c + 'flow3_up2', 'deconv', 4, 2, 2, 2, False),
-        Layer(c + 'flow2', 'conv', 3, 194, 2, 1, False),
+        Layer(c + 'flow2', 'conv', 3, skip2 + 64 + 2, 2, 1, False),
     ]
 
 
-class FlowNetCEngine:
-    """FlowNetC bidirectional forward / loss / backward / Adam on one GPU, fixed (B, H, W)."""
+def _contracting_layers(c):
+    return [
+        Layer(c + 'conv4', 'conv', 3, 256, 512, 2, True), Layer(c + 'conv4_1', 'conv', 3, 512, 512, 1, True),
+        Layer(c + 'conv5', 'conv', 3, 512, 512, 2, True), Layer(c + 'conv5_1', 'conv', 3, 512, 512, 1, True),
+        Layer(c + 'conv6', 'conv', 3, 512, 1024, 2, True), Layer(c + 'conv6_1', 'conv', 3, 1024, 1024, 1, True),
+    ]
+
+
+def flownet_c_layers(scope=''):
+    """Variables of flownet_c_features + flownet_c in the reference's creation order (flownet.py:195-237,89-131)."""
+    f, c = scope + 'flownet_c_features/', scope + 'flownet_c/'
+    return [
+        Layer(f + 'conv1', 'conv', 7, 3, 64, 2, True), Layer(f + 'conv2', 'conv', 5, 64, 128, 2, True),
+        Layer(f + 'conv3', 'conv', 5, 128, 256, 2, True),
+        Layer(c + 'conv_redir', 'conv', 1, 256, 32, 1, True), Layer(c + 'conv3_1', 'conv', 3, 473, 256, 1, True),
+    ] + _contracting_layers(c) + _decoder_layers(c)
+
+
+def flownet_s_layers(scope='', in_channels=6):
+    """Variables of flownet_s (flownet.py:166-192): 6 input channels, or 14 for a refinement stage (:56-57)."""
+    c = scope + 'flownet_s/'
+    return [
+        Layer(c + 'conv1', 'conv', 7, in_channels, 64, 2, True), Layer(c + 'conv2', 'conv', 5, 64, 128, 2, True),
+        Layer(c + 'conv3', 'conv', 5, 128, 256, 2, True), Layer(c + 'conv3_1', 'conv', 3, 256, 256, 1, True),
+    ] + _contracting_layers(c) + _decoder_layers(c)
+
+
+class _Stage:
+    """One network of the (possibly stacked) spec: its layers, activations, gradients and launch lists."""
+
+    def __init__(self, eng, kind, index):
+        self.eng, self.kind, self.index = eng, kind, index
+        scope = '' if index == 0 else 'stack_%d_flownet/' % index   # flownet.py:72-77
+        self.in_ch = 3 if kind == 'C' else (6 if index == 0 else 14)
+        self.layers = flownet_c_layers(scope) if kind == 'C' else flownet_s_layers(scope, self.in_ch)
+        self.by_name = {l.name.split('/')[-1]: l for l in self.layers}
+        self.trainable = True
+
+    def alloc(self):
+        e = self.eng
+        N, H, W, dev = e.N, e.H, e.W, e.dev
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        a = self.act = {}
+        if self.kind == 'S':
+            a['x0s'] = z(N, H, W, pad4(self.in_ch))
+        a['c1'] = z(N, H // 2, W // 2, 64)
+        a['cat2'] = z(N, H // 4, W // 4, 196)
+        a['c3'] = z(N, H // 8, W // 8, 256)
+        if self.kind == 'C':
+            a['catc'] = z(N, H // 8, W // 8, 476)
+        a['cat3'] = z(N, H // 8, W // 8, 388)
+        a['c4'] = z(N, H // 16, W // 16, 512)
+        a['cat4'] = z(N, H // 16, W // 16, 772)
+        a['c5'] = z(N, H // 32, W // 32, 512)
+        a['cat5'] = z(N, H // 32, W // 32, 1028)
+        a['c6'] = z(N, H // 64, W // 64, 1024)
+        a['c6_1'] = z(N, H // 64, W // 64, 1024)
+        for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):
+            a['flow%d' % lvl] = z(N, H // d, W // d, 2)
+        self.grad = {k: torch.zeros_like(v) for k, v in a.items() if k != 'x0s'} if self.trainable else {}
+
+    def _sl(self, name, lo, hi):
+        return self.act[name][..., lo:hi]
+
+    def _gsl(self, name, lo, hi):
+        return self.grad[name][..., lo:hi]
+
+    def _conv(self, lname, x, y):
+        l = self.by_name[lname]
+        if l.kind == 'conv':
+            L.conv2d_fwd(x, l.w, l.b, y, l.stride, l.act)
+        else:
+            L.conv2d_transpose_fwd(x, l.w, l.b, y, l.act)
+
+    # -------------------------------------------------------------- forward
+    def forward(self, prev_flow2=None):
+        e, a, s = self.eng, self.act, self._sl
+        B, N = e.B, e.N
+        if self.kind == 'C':
+            self._conv('conv1', e.x0, a['c1'])
+            self._conv('conv2', a['c1'], s('cat2', 0, 128))
+            self._conv('conv3', s('cat2', 0, 128), a['c3'])
+            h8, w8 = e.H // 8, e.W // 8
+            corr_out = s('catc', 32, 473)
+            check(_lib.lib().unflow_correlation_nhwc_fwd(ptr(a['c3']), ptr(a['c3']), 256, B, ptr(corr_out), 476, N, 256,
+                                                         h8, w8, 1, 20, 20, 1, 2, stream()), "correlation")
+            self._conv('conv_redir', a['c3'], s('catc', 0, 32))
+            self._conv('conv3_1', a['catc'], s('cat3', 0, 256))
+        else:
+            x0s = a['x0s']
+            pf = prev_flow2
+            check(_lib.lib().unflow_stack_input(ptr(e.x0), ptr(pf), ptr(x0s), x0s.shape[3], B, N, e.H, e.W,
+                                                0 if pf is None else pf.shape[1], 0 if pf is None else pf.shape[2],
+                                                cf(4 * FLOW_SCALE), stream()), "stack_input")
+            self._conv('conv1', x0s, a['c1'])
+            self._conv('conv2', a['c1'], s('cat2', 0, 128))
+            self._conv('conv3', s('cat2', 0, 128), a['c3'])
+            self._conv('conv3_1', a['c3'], s('cat3', 0, 256))
+        self._conv('conv4', s('cat3', 0, 256), a['c4'])
+        self._conv('conv4_1', a['c4'], s('cat4', 0, 512))
+        self._conv('conv5', s('cat4', 0, 512), a['c5'])
+        self._conv('conv5_1', a['c5'], s('cat5', 0, 512))
+        self._conv('conv6', s('cat5', 0, 512), a['c6'])
+        self._conv('conv6_1', a['c6'], a['c6_1'])
+        # refinement decoder (_flownet_upconv, flownet.py:89-131)
+        self._conv('flow6', a['c6_1'], a['flow6'])
+        self._conv('deconv5', a['c6_1'], s('cat5', 512, 1024))
+        self._conv('flow6_up5', a['flow6'], s('cat5', 1024, 1026))
+        self._conv('flow5', a['cat5'], a['flow5'])
+        self._conv('deconv4', a['cat5'], s('cat4', 512, 768))
+        self._conv('flow5_up4', a['flow5'], s('cat4', 768, 770))
+        self._conv('flow4', a['cat4'], a['flow4'])
+        self._conv('deconv3', a['cat4'], s('cat3', 256, 384))
+        self._conv('flow4_up3', a['flow4'], s('cat3', 384, 386))
+        self._conv('flow3', a['cat3'], a['flow3'])
+        self._conv('deconv2', a['cat3'], s('cat2', 128, 192))
+        self._conv('flow3_up2', a['flow3'], s('cat2', 192, 194))
+        self._conv('flow2', a['cat2'], a['flow2'])
+
+    # -------------------------------------------------------------- backward
+    def _bwd(self, lname, x, dz, dx=None, accumulate=False, act_src=None, act_lo=0, act_hi=0):
+        """Filter gradient of layer `lname` from dz (d pre-activation), then (optionally) the data gradient."""
+        l = self.by_name[lname]
+        e = self.eng
+        if e._bias_plan is None:
+            e._bias_jobs.append((dz, l))         # bias gradients: one batched column-sum launch at the end
+        if l.kind == 'conv':
+            L.conv2d_bwd_filter(x, dz, l.dw, None, l.stride)
+            if dx is not None:
+                L.conv2d_bwd_data(dz, l.w, dx, l.stride, accumulate, act_src, act_lo, act_hi)
+        else:
+            L.conv2d_transpose_bwd_filter(x, dz, l.dw, None)
+            if dx is not None:
+                L.conv2d_transpose_bwd_data(dz, l.w, dx, accumulate, act_src, act_lo, act_hi)
+
+    def backward(self):
+        e, a, g, s, gs = self.eng, self.act, self.grad, self._sl, self._gsl
+        B, N = e.B, e.N
+        # level 2 (flow2 head reads concat2 = [conv2 | deconv2 | flow3_up2])
+        self._bwd('flow2', a['cat2'], g['flow2'], g['cat2'], False, a['cat2'], 128, 192)
+        self._bwd('flow3_up2', a['flow3'], gs('cat2', 192, 194), g['flow3'], True)
+        self._bwd('flow3', a['cat3'], g['flow3'], g['cat3'], False)
+        self._bwd('deconv2', a['cat3'], gs('cat2', 128, 192), g['cat3'], True, a['cat3'], 256, 384)
+        self._bwd('flow4_up3', a['flow4'], gs('cat3', 384, 386), g['flow4'], True)
+        self._bwd('flow4', a['cat4'], g['flow4'], g['cat4'], False)
+        self._bwd('deconv3', a['cat4'], gs('cat3', 256, 384), g['cat4'], True, a['cat4'], 512, 768)
+        self._bwd('flow5_up4', a['flow5'], gs('cat4', 768, 770), g['flow5'], True)
+        self._bwd('flow5', a['cat5'], g['flow5'], g['cat5'], False)
+        self._bwd('deconv4', a['cat5'], gs('cat4', 512, 768), g['cat5'], True, a['cat5'], 512, 1024)
+        self._bwd('flow6_up5', a['flow6'], gs('cat5', 1024, 1026), g['flow6'], True)
+        self._bwd('flow6', a['c6_1'], g['flow6'], g['c6_1'], False)
+        self._bwd('deconv5', a['c6_1'], gs('cat5', 512, 1024), g['c6_1'], True, a['c6_1'], 0, 1024)
+        # contracting part
+        self._bwd('conv6_1', a['c6'], g['c6_1'], g['c6'], False, a['c6'], 0, 1024)
+        self._bwd('conv6', s('cat5', 0, 512), g['c6'], gs('cat5', 0, 512), True, s('cat5', 0, 512), 0, 512)
+        self._bwd('conv5_1', a['c5'], gs('cat5', 0, 512), g['c5'], False, a['c5'], 0, 512)
+        self._bwd('conv5', s('cat4', 0, 512), g['c5'], gs('cat4', 0, 512), True, s('cat4', 0, 512), 0, 512)
+        self._bwd('conv4_1', a['c4'], gs('cat4', 0, 512), g['c4'], False, a['c4'], 0, 512)
+        self._bwd('conv4', s('cat3', 0, 256), g['c4'], gs('cat3', 0, 256), True, s('cat3', 0, 256), 0, 256)
+        if self.kind == 'C':
+            self._bwd('conv3_1', a['catc'], gs('cat3', 0, 256), g['catc'], False, a['catc'], 0, 32)
+            # correlation: gradient wrt the shared feature tensor (both roles of every sample), then conv_redir adds
+            h8, w8 = e.H // 8, e.W // 8
+            check(_lib.lib().unflow_correlation_nhwc_bwd(ptr(gs('catc', 32, 473)), 476, ptr(a['c3']), ptr(a['c3']), 256,
+                                                         B, ptr(g['c3']), ptr(None), 256, 1, N, 256, h8, w8, 1, 20, 20,
+                                                         1, 2, stream()), "correlation_grad")
+            self._bwd('conv_redir', a['c3'], gs('catc', 0, 32), g['c3'], True, a['c3'], 0, 256)
+            x_in = e.x0
+        else:
+            self._bwd('conv3_1', a['c3'], gs('cat3', 0, 256), g['c3'], False, a['c3'], 0, 256)
+            x_in = a['x0s']
+        self._bwd('conv3', s('cat2', 0, 128), g['c3'], gs('cat2', 0, 128), True, s('cat2', 0, 128), 0, 128)
+        self._bwd('conv2', a['c1'], gs('cat2', 0, 128), g['c1'], False, a['c1'], 0, 64)
+        self._bwd('conv1', x_in, g['c1'], None)   # inputs are data (or stop_gradient, flownet.py:51-54)
+
+
+class FlowNetEngine:
+    """Bidirectional forward / loss / backward / Adam of a FlowNet spec on one GPU, fixed (B, H, W).
+    params['flownet']: 'C', 'S' or a stack 'CS', 'CSS', 'SS' ... (flownet.py:14-81).  In a stack only the last network
+    is trained (train_all is not implemented); the earlier ones run forward only and — exactly as in the reference,
+    whose regulariser and optimizer span all variables — still receive the L2 gradient in the Adam update."""
 
     def __init__(self, batch, height, width, params=None, device=None, seed=0):
-        assert height % 64 == 0 and width % 64 == 0, "FlowNetC needs H, W divisible by 64"
+        assert height % 64 == 0 and width % 64 == 0, "FlowNet needs H, W divisible by 64"
         self.params = dict(DEFAULT_PARAMS) if params is None else dict(params)
         if self.params.get('mask_occlusion', '') not in ('', 'fb', 'disocc'):   # unsupervised.py:125-126
             raise ValueError("mask_occlusion must be one of 'fb', 'disocc', ''")
-        if self.params.get('flownet', 'C') != 'C':
-            raise NotImplementedError("only flownet='C' is wired into the engine")
+        spec = self.params.get('flownet', 'C')
+        if not spec or any(ch not in 'CS' for ch in spec) or 'C' in spec[1:]:
+            raise ValueError("flownet spec must be 'C' or 'S' followed by 'S' refinement nets (full-size nets only)")
+        if self.params.get('train_all') and len(spec) > 1:
+            raise NotImplementedError("train_all for stacked networks is not implemented")
+        if self.params.get('full_res'):
+            raise NotImplementedError("full_res decoder is not implemented")
+        self.spec = spec
         self.B, self.H, self.W = batch, height, width
         self.N = 2 * batch
         self.dev = torch.device('cuda:0') if device is None else device
-        self.layers = flownet_c_layers()
-        self.by_name = {l.name.split('/')[-1]: l for l in self.layers}
+        self.stages = [_Stage(self, k, i) for i, k in enumerate(spec)]
+        for st in self.stages[:-1]:
+            st.trainable = False
+        self.layers = [l for st in self.stages for l in st.layers]
+        self.by_name = self.stages[-1].by_name
         self._alloc_params()
         self._alloc_activations()
         self._build_masks()
@@ -166,29 +347,20 @@ class FlowNetCEngine:
     def _alloc_activations(self):
         N, H, W, dev = self.N, self.H, self.W, self.dev
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        a = self.act = {}
-        a['x0'] = z(N, H, W, 4)
-        a['im01'] = z(N, H, W, 3)
-        a['c1'] = z(N, H // 2, W // 2, 64)
-        a['cat2'] = z(N, H // 4, W // 4, 196)
-        a['c3'] = z(N, H // 8, W // 8, 256)
-        a['catc'] = z(N, H // 8, W // 8, 476)
-        a['cat3'] = z(N, H // 8, W // 8, 388)
-        a['c4'] = z(N, H // 16, W // 16, 512)
-        a['cat4'] = z(N, H // 16, W // 16, 772)
-        a['c5'] = z(N, H // 32, W // 32, 512)
-        a['cat5'] = z(N, H // 32, W // 32, 1028)
-        a['c6'] = z(N, H // 64, W // 64, 1024)
-        a['c6_1'] = z(N, H // 64, W // 64, 1024)
-        for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):
-            a['flow%d' % lvl] = z(N, H // d, W // d, 2)
-        self.grad = {k: torch.zeros_like(v) for k, v in a.items() if k not in ('x0', 'im01')}
+        self.x0 = z(N, H, W, 4)       # mean-subtracted network input (4th channel zero)
+        self.im01 = z(N, H, W, 3)     # images in [0,1] for the losses
+        for st in self.stages:
+            st.alloc()
+        last = self.stages[-1]
+        # views used by the loss code, tests and tools: the trained (last) network
+        self.act = dict(last.act, x0=self.x0, im01=self.im01)
+        self.grad = last.grad
         # loss-side pyramid
         self.lv = []
         for i, d in enumerate((4, 8, 16, 32, 64)):
             h, w = H // d, W // d
             self.lv.append(dict(h=h, w=w, im=z(N, h, w, 3), gray1=z(N, h, w), gray2w=z(N, h, w), dist=z(N, h, w),
-                                dgray=z(N, h, w), flow=a['flow%d' % (i + 2)], gflow=self.grad['flow%d' % (i + 2)]))
+                                dgray=z(N, h, w), flow=last.act['flow%d' % (i + 2)], gflow=last.grad['flow%d' % (i + 2)]))
         self.loss_acc = z(1)
         self.raw = z(N, H, W, 3)
         self.final_flow = z(N, H, W, 2)
@@ -213,59 +385,21 @@ class FlowNetCEngine:
                 cur1 = ops.downsample(cur1, 2)
 
     # ------------------------------------------------------------------ forward
-    def _sl(self, name, lo, hi):
-        return self.act[name][..., lo:hi]
-
-    def _gsl(self, name, lo, hi):
-        return self.grad[name][..., lo:hi]
-
-    def _conv(self, lname, x, y):
-        l = self.by_name[lname]
-        if l.kind == 'conv':
-            L.conv2d_fwd(x, l.w, l.b, y, l.stride, l.act)
-        else:
-            L.conv2d_transpose_fwd(x, l.w, l.b, y, l.act)
-
     def set_input(self, im1, im2):
         """im1, im2: [B,H,W,3] float32 in [0,255] (what the reference's input queue delivers)."""
         B = self.B
         self.raw[:B].copy_(im1)
         self.raw[B:].copy_(im2)
-        check(_lib.lib().unflow_prepare_images(ptr(self.raw), ptr(self.act['x0']), ptr(self.act['im01']),
+        check(_lib.lib().unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(self.im01),
                                                self.mean_host, cl(self.N * self.H * self.W), stream()), "prepare_images")
 
     def forward_net(self):
-        a, s = self.act, self._sl
-        B = self.B
-        self._conv('conv1', a['x0'], a['c1'])
-        self._conv('conv2', a['c1'], s('cat2', 0, 128))
-        self._conv('conv3', s('cat2', 0, 128), a['c3'])
-        N, h8, w8 = self.N, self.H // 8, self.W // 8
-        corr_out = s('catc', 32, 473)
-        check(_lib.lib().unflow_correlation_nhwc_fwd(ptr(a['c3']), ptr(a['c3']), 256, B, ptr(corr_out), 476, N, 256,
-                                                     h8, w8, 1, 20, 20, 1, 2, stream()), "correlation")
-        self._conv('conv_redir', a['c3'], s('catc', 0, 32))
-        self._conv('conv3_1', a['catc'], s('cat3', 0, 256))
-        self._conv('conv4', s('cat3', 0, 256), a['c4'])
-        self._conv('conv4_1', a['c4'], s('cat4', 0, 512))
-        self._conv('conv5', s('cat4', 0, 512), a['c5'])
-        self._conv('conv5_1', a['c5'], s('cat5', 0, 512))
-        self._conv('conv6', s('cat5', 0, 512), a['c6'])
-        self._conv('conv6_1', a['c6'], a['c6_1'])
-        # refinement decoder (_flownet_upconv, flownet.py:89-131)
-        self._conv('flow6', a['c6_1'], a['flow6'])
-        self._conv('deconv5', a['c6_1'], s('cat5', 512, 1024))
-        self._conv('flow6_up5', a['flow6'], s('cat5', 1024, 1026))
-        self._conv('flow5', a['cat5'], a['flow5'])
-        self._conv('deconv4', a['cat5'], s('cat4', 512, 768))
-        self._conv('flow5_up4', a['flow5'], s('cat4', 768, 770))
-        self._conv('flow4', a['cat4'], a['flow4'])
-        self._conv('deconv3', a['cat4'], s('cat3', 256, 384))
-        self._conv('flow4_up3', a['flow4'], s('cat3', 384, 386))
-        self._conv('flow3', a['cat3'], a['flow3'])
-        self._conv('deconv2', a['cat3'], s('cat2', 128, 192))
-        self._conv('flow3_up2', a['flow3'], s('cat2', 192, 194))
-        self._conv('flow2', a['cat2'], a['flow2'])
+        """flownet(im1, im2, spec, backward_flow=True) (flownet.py:14-81): every stage in order; a refinement stage
+        consumes the previous stage's finest flow."""
+        prev = None
+        for st in self.stages:
+            st.forward(prev)
+            prev = st.act['flow2']
 
     def forward_loss(self, with_grad=True):
         """compute_losses + the pyramid assembly (losses.py:16-87, unsupervised.py:85-150) over the directed batch;
@@ -387,19 +521,10 @@ class FlowNetCEngine:
                   fscaled=z(N, h, w, 2), fwmap=z(N, h, w), imw=z(N, h, w, 3), gdiff=z(N, h, w, 6), dimw=z(N, h, w, 3))
 
     # ------------------------------------------------------------------ backward
-    def _bwd(self, lname, x, dz, dx=None, accumulate=False, act_src=None, act_lo=0, act_hi=0):
-        """Filter + bias gradient of layer `lname` from dz (d pre-activation), then (optionally) the data gradient."""
-        l = self.by_name[lname]
-        if self._bias_plan is None:
-            self._bias_jobs.append((dz, l))         # bias gradients: one batched column-sum launch at the end
-        if l.kind == 'conv':
-            L.conv2d_bwd_filter(x, dz, l.dw, None, l.stride)
-            if dx is not None:
-                L.conv2d_bwd_data(dz, l.w, dx, l.stride, accumulate, act_src, act_lo, act_hi)
-        else:
-            L.conv2d_transpose_bwd_filter(x, dz, l.dw, None)
-            if dx is not None:
-                L.conv2d_transpose_bwd_data(dz, l.w, dx, accumulate, act_src, act_lo, act_hi)
+    def backward_net(self):
+        """Gradients of the trained (last) network; earlier stages are behind stop_gradient (flownet.py:51-54)."""
+        self.stages[-1].backward()
+        self._bias_grads()
 
     def _bias_grads(self):
         """db = column sums of every layer's dz, batched (unflow_colsum_batched)."""
@@ -420,42 +545,6 @@ class FlowNetCEngine:
         n, xs, lds, npx, cs, outs, ws = self._bias_plan
         check(lib.unflow_colsum_batched(n, xs, lds, npx, cs, outs, ptr(ws), _lib.csz(ws.numel() * 4), stream()),
               "colsum_batched")
-
-    def backward_net(self):
-        a, g, s, gs = self.act, self.grad, self._sl, self._gsl
-        B, N = self.B, self.N
-        # level 2 (flow2 head reads concat2 = [conv2_a | deconv2 | flow3_up2])
-        self._bwd('flow2', a['cat2'], g['flow2'], g['cat2'], False, a['cat2'], 128, 192)
-        self._bwd('flow3_up2', a['flow3'], gs('cat2', 192, 194), g['flow3'], True)
-        self._bwd('flow3', a['cat3'], g['flow3'], g['cat3'], False)
-        self._bwd('deconv2', a['cat3'], gs('cat2', 128, 192), g['cat3'], True, a['cat3'], 256, 384)
-        self._bwd('flow4_up3', a['flow4'], gs('cat3', 384, 386), g['flow4'], True)
-        self._bwd('flow4', a['cat4'], g['flow4'], g['cat4'], False)
-        self._bwd('deconv3', a['cat4'], gs('cat3', 256, 384), g['cat4'], True, a['cat4'], 512, 768)
-        self._bwd('flow5_up4', a['flow5'], gs('cat4', 768, 770), g['flow5'], True)
-        self._bwd('flow5', a['cat5'], g['flow5'], g['cat5'], False)
-        self._bwd('deconv4', a['cat5'], gs('cat4', 512, 768), g['cat5'], True, a['cat5'], 512, 1024)
-        self._bwd('flow6_up5', a['flow6'], gs('cat5', 1024, 1026), g['flow6'], True)
-        self._bwd('flow6', a['c6_1'], g['flow6'], g['c6_1'], False)
-        self._bwd('deconv5', a['c6_1'], gs('cat5', 512, 1024), g['c6_1'], True, a['c6_1'], 0, 1024)
-        # contracting part
-        self._bwd('conv6_1', a['c6'], g['c6_1'], g['c6'], False, a['c6'], 0, 1024)
-        self._bwd('conv6', s('cat5', 0, 512), g['c6'], gs('cat5', 0, 512), True, s('cat5', 0, 512), 0, 512)
-        self._bwd('conv5_1', a['c5'], gs('cat5', 0, 512), g['c5'], False, a['c5'], 0, 512)
-        self._bwd('conv5', s('cat4', 0, 512), g['c5'], gs('cat4', 0, 512), True, s('cat4', 0, 512), 0, 512)
-        self._bwd('conv4_1', a['c4'], gs('cat4', 0, 512), g['c4'], False, a['c4'], 0, 512)
-        self._bwd('conv4', s('cat3', 0, 256), g['c4'], gs('cat3', 0, 256), True, s('cat3', 0, 256), 0, 256)
-        self._bwd('conv3_1', a['catc'], gs('cat3', 0, 256), g['catc'], False, a['catc'], 0, 32)
-        # correlation: gradient wrt the shared feature tensor (both roles of every sample), then conv_redir adds
-        h8, w8 = self.H // 8, self.W // 8
-        check(_lib.lib().unflow_correlation_nhwc_bwd(ptr(gs('catc', 32, 473)), 476, ptr(a['c3']), ptr(a['c3']), 256,
-                                                     B, ptr(g['c3']), ptr(None), 256, 1, N, 256, h8, w8, 1, 20, 20, 1,
-                                                     2, stream()), "correlation_grad")
-        self._bwd('conv_redir', a['c3'], gs('catc', 0, 32), g['c3'], True, a['c3'], 0, 256)
-        self._bwd('conv3', s('cat2', 0, 128), g['c3'], gs('cat2', 0, 128), True, s('cat2', 0, 128), 0, 128)
-        self._bwd('conv2', a['c1'], gs('cat2', 0, 128), g['c1'], False, a['c1'], 0, 64)
-        self._bwd('conv1', a['x0'], g['c1'], None)
-        self._bias_grads()
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -506,3 +595,6 @@ def flow_error_avg(flow_1, flow_2, mask=None):
     check(_lib.lib().unflow_flow_error_sums(ptr(f1), ptr(f2), ptr(None if mask is None else mask.contiguous()),
                                             ptr(out), cl(npix), stream()), "flow_error")
     return out[0] / out[1]
+
+
+FlowNetCEngine = FlowNetEngine   # the FlowNetC training step is the default spec ('C')

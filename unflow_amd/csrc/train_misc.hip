@@ -167,3 +167,61 @@ UNFLOW_API int unflow_flow_error_sums(const float* f1, const float* f2, const fl
   flow_error_sums_kernel<<<stream_grid(npix), 256, 0, as_stream(stream)>>>(f1, f2, mask, out2, npix);
   return launch_status();
 }
+
+// Input of a FlowNetS stage (flownet.py:46-59): out[n] = [first(3), second(3)] for a first-stage S, or
+// [first, second, flow(2), warp(3), |warp - first|(3)] for a refinement stage, where
+// flow = resize_bilinear_tf1(prev_flow2[n], [H,W]) * 4 * FLOW_SCALE, warp = image_warp(second, flow).
+// first = im[n], second = im[(n + shift) % N] (directed batch); im is the [N,H,W,4] mean-subtracted network input.
+__global__ void stack_input_kernel(const float* __restrict__ im, const float* __restrict__ prev, float* __restrict__ out,
+                                   int ldo, int shift, int N, int H, int W, int h, int w, float fscale) {
+  const long npx = (long)N * H * W;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    const long sb = (long)((n + shift) % N) * H * W;
+    const float4 a = reinterpret_cast<const float4*>(im)[i];
+    const float4 b = reinterpret_cast<const float4*>(im)[sb + (long)y * W + x];
+    float* o = out + i * ldo;
+    o[0] = a.x; o[1] = a.y; o[2] = a.z;
+    o[3] = b.x; o[4] = b.y; o[5] = b.z;
+    if (!prev) continue;
+    // TF1 legacy bilinear upsample of the coarse flow
+    const float fy = (float)y * sy, fx = (float)x * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float2* pf = reinterpret_cast<const float2*>(prev) + (long)n * h * w;
+    const float2 tl = pf[(long)y0 * w + x0], tr = pf[(long)y0 * w + x1], bl = pf[(long)y1 * w + x0], br = pf[(long)y1 * w + x1];
+    const float tu = tl.x + (tr.x - tl.x) * lx, bu = bl.x + (br.x - bl.x) * lx;
+    const float tv = tl.y + (tr.y - tl.y) * lx, bv = bl.y + (br.y - bl.y) * lx;
+    const float u = (tu + (bu - tu) * ly) * fscale, v = (tv + (bv - tv) * ly) * fscale;
+    o[6] = u; o[7] = v;
+    // image_warp(second, flow): x + int(floor(u)), clamp, bilinear (image_warp.py:26-73)
+    const float fu = floorf(u), fv = floorf(v);
+    const float xw = u - fu, yw = v - fv;
+    const float wa = (1.f - xw) * (1.f - yw), wb = (1.f - xw) * yw, wc = xw * (1.f - yw), wd = xw * yw;
+    const int xi = x + (int)fu, yi = y + (int)fv;
+    const int xa = min(max(xi, 0), W - 1), xb = min(max(xi + 1, 0), W - 1);
+    const int ya = min(max(yi, 0), H - 1), yb = min(max(yi + 1, 0), H - 1);
+    const float4 Ia = reinterpret_cast<const float4*>(im)[sb + (long)ya * W + xa];
+    const float4 Ib = reinterpret_cast<const float4*>(im)[sb + (long)yb * W + xa];
+    const float4 Ic = reinterpret_cast<const float4*>(im)[sb + (long)ya * W + xb];
+    const float4 Id = reinterpret_cast<const float4*>(im)[sb + (long)yb * W + xb];
+    const float w0 = ((wa * Ia.x + wb * Ib.x) + wc * Ic.x) + wd * Id.x;
+    const float w1 = ((wa * Ia.y + wb * Ib.y) + wc * Ic.y) + wd * Id.y;
+    const float w2 = ((wa * Ia.z + wb * Ib.z) + wc * Ic.z) + wd * Id.z;
+    o[8] = w0; o[9] = w1; o[10] = w2;
+    o[11] = fabsf(w0 - a.x); o[12] = fabsf(w1 - a.y); o[13] = fabsf(w2 - a.z);
+  }
+}
+
+UNFLOW_API int unflow_stack_input(const float* net_in4, const float* prev_flow2, float* out, int ld_out, int pair_shift,
+                                  int N, int H, int W, int h, int w, float flow_scale, unflow_stream_t stream) {
+  if (!net_in4 || !out) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || ld_out < (prev_flow2 ? 14 : 6)) return UNFLOW_ERR_SHAPE;
+  if (prev_flow2 && (h <= 0 || w <= 0)) return UNFLOW_ERR_SHAPE;
+  stack_input_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(net_in4, prev_flow2, out, ld_out,
+                                                                                  pair_shift, N, H, W, h, w, flow_scale);
+  return launch_status();
+}
