@@ -71,7 +71,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("UNFLOW_FORCE_REDUCER") == "1" and "RANK" in os.environ   # test knob
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -84,36 +85,54 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)               # distinct shard per rank
     im1 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
     im2 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
-    reducer = GradAllReducer(eng.G, world) if world > 1 else None
+    reducer = GradAllReducer(eng.G, world, force=force_dist) if (world > 1 or force_dist) else None
     lr = 1e-4
     eng.set_input(im1, im2)
 
-    graph = None
+    graphs = None
+    early, late = eng.grad_buckets()
 
-    def fwd_bwd():
-        if graph is not None:
-            graph.replay()
-        else:
-            eng.fwd_bwd()
+    def part_a():       # forward, losses, backward of the decoder and conv6_1..conv4 (94 % of the gradient bytes)
+        eng.forward_net()
+        eng.forward_loss(with_grad=True)
+        eng.backward_net(0)
+
+    def part_b():       # backward of conv3_1 .. conv1 + bias gradients (~3 ms: hides the big bucket's exchange)
+        eng.backward_net(1)
 
     def step():
-        fwd_bwd()
+        if graphs is not None:
+            graphs[0].replay()
+        else:
+            part_a()
         if reducer is not None:
-            reducer.all_reduce()
+            reducer.start_ranges(early)
+        if graphs is not None:
+            graphs[1].replay()
+        else:
+            part_b()
+        if reducer is not None:
+            reducer.start_ranges(late)
+            reducer.finish()
         eng.adam_step(lr, grad_scale=1.0 / world)
 
-    # first eager step grows the workspaces; then capture fwd+loss+bwd (~230 launches) into one hipGraph
+    # first eager step grows the workspaces; then capture fwd+loss+bwd (~230 launches) into two hipGraphs (the
+    # gradient exchange of the first, large bucket is launched between them)
     step()
     torch.cuda.synchronize()
     if not args.no_graph:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            eng.fwd_bwd()
+            part_a()
+            part_b()
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            eng.fwd_bwd()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            part_a()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            part_b()
+        graphs = (ga, gb)
     for _ in range(args.warmup):
         step()
 
@@ -144,7 +163,7 @@ def main():
                                "L2/Adam%s, %d pairs/GPU, %dx%d, 441-ch correlation (BASELINE configs[%d])"
                                % (" + RCCL grad all-reduce" if world > 1 else "", B, H, W, 2 if world > 1 else 1),
                    "global_batch": world * B, "height": H, "width": W, "parallelism": "dp%d" % world,
-                   "hipgraph": graph is not None, "final_loss": round(loss, 4)},
+                   "hipgraph": graphs is not None, "final_loss": round(loss, 4)},
         "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W) == (384, 512) else None,
     }
 
@@ -156,7 +175,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

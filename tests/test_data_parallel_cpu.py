@@ -41,6 +41,12 @@ def _worker_reducer(rank, world, port, out_dir):
     assert len(red.bounds) > 1
     red.all_reduce()
     torch.save((mine, buf.clone()), os.path.join(out_dir, "sum%d.pt" % rank))
+    buf3 = mine.clone()                            # two-phase (overlap) API: early range, then the rest
+    r3 = GradAllReducer(buf3, world, bucket_bytes=32 * 1024)
+    r3.start_ranges([(40000, n)])
+    r3.start_ranges([(0, 100), (100, 40000)])
+    r3.finish()
+    assert torch.equal(buf3, buf)
     buf2 = mine.clone()
     GradAllReducer(buf2, world, bucket_bytes=1 << 20).mean_()
     torch.save(buf2, os.path.join(out_dir, "mean%d.pt" % rank))

@@ -15,12 +15,15 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None):
+    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None, force=False):
         self.g = flat_grad
         self.world = world_size
+        self.force = force      # issue the collectives even for world_size 1 (exercises the stream logic on one GPU)
         self.group = group
         n = flat_grad.numel()
         per = max(1, bucket_bytes // 4)
+        self.per = per
+        self._pending = []
         self.bounds = [(i, min(n, i + per)) for i in range(0, n, per)]
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
@@ -42,6 +45,34 @@ class GradAllReducer:
         else:
             for a, b in self.bounds:
                 dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+
+    def start_ranges(self, ranges):
+        """Enqueue the SUM all-reduce of flat ranges [(lo, hi), ...] on the side stream, ordered after everything the
+        current stream has queued so far; returns immediately.  finish() makes the current stream wait for all
+        exchanges started since the last finish()."""
+        if self.world <= 1 and not self.force:
+            return
+        for lo, hi in ranges:
+            for a in range(lo, hi, self.per):
+                b = min(hi, a + self.per)
+                if self.cuda:
+                    cur = torch.cuda.current_stream(self.g.device)
+                    self.stream.wait_stream(cur)
+                    with torch.cuda.stream(self.stream):
+                        self._pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                             async_op=True))
+                else:
+                    dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+
+    def finish(self):
+        if self.world <= 1 and not self.force:
+            return
+        if self.cuda:
+            with torch.cuda.stream(self.stream):
+                for w in self._pending:
+                    w.wait()
+            torch.cuda.current_stream(self.g.device).wait_stream(self.stream)
+        self._pending = []
 
     def mean_(self):
         """all_reduce + divide: the semantics of train.py:388-422 in one call (used when the optimizer does not

@@ -207,9 +207,16 @@ class _Stage:
             if dx is not None:
                 L.conv2d_transpose_bwd_data(dz, l.w, dx, accumulate, act_src, act_lo, act_hi)
 
-    def backward(self):
+    def backward(self, part=None):
+        """part None: everything; 0: decoder + conv6_1..conv4 (94 % of the parameters — their gradients are final
+        afterwards, so their all-reduce can start); 1: conv3_1 .. conv1."""
+        if part in (None, 0):
+            self._backward_deep()
+        if part in (None, 1):
+            self._backward_shallow()
+
+    def _backward_deep(self):
         e, a, g, s, gs = self.eng, self.act, self.grad, self._sl, self._gsl
-        B, N = e.B, e.N
         # level 2 (flow2 head reads concat2 = [conv2 | deconv2 | flow3_up2])
         self._bwd('flow2', a['cat2'], g['flow2'], g['cat2'], False, a['cat2'], 128, 192)
         self._bwd('flow3_up2', a['flow3'], gs('cat2', 192, 194), g['flow3'], True)
@@ -231,6 +238,10 @@ class _Stage:
         self._bwd('conv5', s('cat4', 0, 512), g['c5'], gs('cat4', 0, 512), True, s('cat4', 0, 512), 0, 512)
         self._bwd('conv4_1', a['c4'], gs('cat4', 0, 512), g['c4'], False, a['c4'], 0, 512)
         self._bwd('conv4', s('cat3', 0, 256), g['c4'], gs('cat3', 0, 256), True, s('cat3', 0, 256), 0, 256)
+
+    def _backward_shallow(self):
+        e, a, g, s, gs = self.eng, self.act, self.grad, self._sl, self._gsl
+        B, N = e.B, e.N
         if self.kind == 'C':
             self._bwd('conv3_1', a['catc'], gs('cat3', 0, 256), g['catc'], False, a['catc'], 0, 32)
             # correlation: gradient wrt the shared feature tensor (both roles of every sample), then conv_redir adds
@@ -521,10 +532,22 @@ class FlowNetEngine:
                   fscaled=z(N, h, w, 2), fwmap=z(N, h, w), imw=z(N, h, w, 3), gdiff=z(N, h, w, 6), dimw=z(N, h, w, 3))
 
     # ------------------------------------------------------------------ backward
-    def backward_net(self):
-        """Gradients of the trained (last) network; earlier stages are behind stop_gradient (flownet.py:51-54)."""
-        self.stages[-1].backward()
-        self._bias_grads()
+    def backward_net(self, part=None):
+        """Gradients of the trained (last) network; earlier stages are behind stop_gradient (flownet.py:51-54).
+        part 0 / 1: the two halves used to overlap the data-parallel all-reduce (see grad_buckets)."""
+        self.stages[-1].backward(part)
+        if part in (None, 1):
+            self._bias_grads()
+
+    def grad_buckets(self):
+        """Flat ranges of self.G: (early, late).  `early` = the weights whose gradients are complete after
+        backward_net(0) (conv4 .. flow2 of the trained network: a contiguous tail of the weight region);
+        `late` = everything else (conv1 .. conv3_1 weights, all biases, and the never-written zeros of frozen stages)."""
+        st = self.stages[-1]
+        first = st.by_name['conv4']
+        lo = first.dw.data_ptr() - self.G.data_ptr()
+        lo //= 4
+        return [(lo, self.n_weights)], [(0, lo), (self.n_weights, self.n_params)]
 
     def _bias_grads(self):
         """db = column sums of every layer's dz, batched (unflow_colsum_batched)."""
