@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Op-level roofline microbenchmarks: HBM-bound ops at full-resolution shapes, where the bandwidth
+fraction is meaningful (inside the training step they run on <= 96x128 pyramid levels and are launch-latency bound).
+Prints one JSON object per op: algorithmic bytes (SURVEY 8d per-pixel figures), time (HIP events on the launch
+stream, median of 20), GB/s and the fraction of the 8 TB/s HBM3E peak (6.3 TB/s is the measured streaming ceiling)."""
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+
+from unflow_amd import _lib, ops
+from unflow_amd._lib import ptr, cf, cl, stream, check
+from unflow_amd.core.image_warp import image_warp
+
+HBM_PEAK = 8000.0
+
+
+def timeit(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2] * 1e3   # us
+
+
+def report(name, nbytes, us, extra=None):
+    gbs = nbytes / us / 1e3
+    out = {"op": name, "algorithmic_MB": round(nbytes / 1e6, 1), "us": round(us, 1), "GB/s": round(gbs, 1),
+           "frac_of_8TBs": round(gbs / HBM_PEAK, 3)}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out))
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    N, H, W = 16, 768, 1024
+    npx = N * H * W
+    im = torch.rand(N, H, W, 3, generator=g).to(dev)
+    flow_iid = (torch.randn(N, H, W, 2, generator=g) * 4).to(dev)     # i.i.d. per pixel: worst case for the gathers
+    # smooth field of the same magnitude (what a flow network produces): coarse noise, bilinearly upsampled
+    flow = torch.nn.functional.interpolate(torch.randn(N, 2, H // 32, W // 32, generator=g) * 4, size=(H, W), mode='bilinear',
+                                           align_corners=False).permute(0, 2, 3, 1).contiguous().to(dev)
+    out3 = torch.empty_like(im)
+    st = stream()
+    # image_warp forward: (2C+2)*4 B/px  (read image once, flow, write warped)
+    report("image_warp_fwd C=3 %dx%dx%d" % (N, H, W), npx * 32,
+           timeit(lambda: check(lib.unflow_image_warp_fwd(ptr(im), 3, ptr(flow), cf(1.0), ptr(out3), ptr(None), 0, N, H, W, 3, st))))
+    report("image_warp_fwd C=3, i.i.d. N(0,4^2) flow (gather worst case)", npx * 32,
+           timeit(lambda: check(lib.unflow_image_warp_fwd(ptr(im), 3, ptr(flow_iid), cf(1.0), ptr(out3), ptr(None), 0, N, H, W, 3, st))))
+    report("backward_warp_fwd C=3", npx * 32,
+           timeit(lambda: check(lib.unflow_backward_warp_fwd(ptr(im), ptr(flow), ptr(out3), N, H, W, 3, st))))
+    dfl = torch.empty_like(flow)
+    gout = torch.rand(N, H, W, 3, generator=g).to(dev)
+    # backward wrt flow: read dout (3), image (3 via taps), flow (2), write dflow (2): (3C+... ) = 40 B/px
+    report("backward_warp_bwd C=3", npx * 40,
+           timeit(lambda: check(lib.unflow_backward_warp_bwd(ptr(gout), ptr(im), ptr(flow), ptr(dfl), N, H, W, 3, st))))
+    gray1 = torch.empty(N, H, W, device=dev)
+    gray2 = torch.empty_like(gray1)
+    report("warp_gray_fwd (warp + grayscale fused)", npx * (12 + 8 + 4),
+           timeit(lambda: check(lib.unflow_warp_gray_fwd(ptr(im), 3, ptr(flow), cf(1.0), ptr(gray2), N // 2, N, H, W, st))))
+    check(lib.unflow_rgb_to_gray255(ptr(im), 3, ptr(gray1), cl(npx), st))
+    mask = torch.ones(1, H, W, device=dev)
+    dist = torch.empty_like(gray1)
+    acc = torch.zeros(1, device=dev)
+    dgray = torch.empty_like(gray1)
+    for D in (1, 3):
+        report("ternary_fwd D=%d (census %dx%d)" % (D, 2 * D + 1, 2 * D + 1), npx * 12,
+               timeit(lambda: check(lib.unflow_ternary_fwd(ptr(gray1), ptr(gray2), ptr(mask), 1, ptr(dist), ptr(acc), cf(1.0), cf(npx), D, N, H, W, st))))
+        report("ternary_bwd D=%d" % D, npx * 16,
+               timeit(lambda: check(lib.unflow_ternary_bwd(ptr(gray1), ptr(gray2), ptr(mask), 1, ptr(dist), ptr(dgray), cf(1.0), cf(npx), D, N, H, W, st))))
+    report("second_order fwd+bwd", npx * 16,
+           timeit(lambda: check(lib.unflow_second_order_fwd_bwd(ptr(flow), cf(1.0), ptr(acc), ptr(dfl), 0, cf(1.0), cf(npx), N, H, W, st))))
+    for s in (2, 4):
+        o = torch.empty(N, H // s, W // s, 3, device=dev)
+        report("downsample scale=%d C=3" % s, int(npx * 12 * (1 + 1.0 / (s * s))),
+               timeit(lambda: check(lib.unflow_downsample_fwd(ptr(im), ptr(o), N, H, W, 3, s, st))))
+    n = 39_200_000
+    p, gr, m, v = (torch.randn(n, generator=g).to(dev) for _ in range(4))
+    v.abs_()
+    report("adam_step (39.2 M params, fused L2)", n * 4 * 7,
+           timeit(lambda: check(lib.unflow_adam_step(ptr(p), ptr(gr), ptr(m), ptr(v), cl(n), cl(n), cf(1.0), cf(4e-4), cf(1e-4), cf(.9), cf(.999), cf(1e-8), st))))
+    # correlation, FlowNetC configuration, N=8 directed samples (compute-leaning: report both rooflines)
+    f = torch.randn(8, 48, 64, 256, generator=g).to(dev)
+    co = torch.empty(8, 48, 64, 441, device=dev)
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f), ptr(f), 256, 4, ptr(co), 441, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
+    report("correlation_nhwc_fwd 441ch N=8", 8 * 11.71e6, us, {"GFLOP_algorithmic": 5.55, "TFLOP/s": round(5.55e3 / us, 1)})
+    gco = torch.randn(8, 48, 64, 441, generator=g).to(dev)
+    gf = torch.empty_like(f)
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco), 441, ptr(f), ptr(f), 256, 4, ptr(gf), ptr(None), 256, 1, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
+    report("correlation_nhwc_bwd 441ch N=8 (fused g0+g1)", 8 * 18.0e6, us, {"GFLOP_algorithmic": 11.1, "TFLOP/s": round(11.1e3 / us, 1)})
+
+
+if __name__ == "__main__":
+    main()

@@ -201,12 +201,14 @@ int unflow_warp_gray_bwd(const float* d_gray, const float* im, int ld_im, const 
 
 /* ternary_loss (losses.py:90-122) on gray images: per pixel soft-Hamming distance of the census
  * transforms, Charbonnier (alpha .45, eps 1e-3), masked by mask*interior(max_distance), summed into
- * loss_acc[0] scaled by `weight`/(normalizer).  dist_out [N,H,W] keeps the per-pixel distance for
- * the backward pass.  mask: [N_mask,H,W] with sample n using mask[n % N_mask]. */
+ * loss_acc[0] scaled by `weight`/(normalizer).  dist_out [N,H,W] receives d(weighted loss)/d(distance) per
+ * pixel (mask, interior and weight folded in) — the only thing the backward pass needs.  mask: [N_mask,H,W] with
+ * sample n using mask[n % N_mask].  max_distance <= 4 (the reference uses 1..3, unsupervised.py:88). */
 int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask, float* dist_out,
                        float* loss_acc, float weight, float normalizer, int max_distance, int N, int H, int W,
                        unflow_stream_t stream);
-/* d_gray2w = d(weight * loss)/d(gray2w)  (gather form, no atomics). */
+/* d_gray2w = d(weight * loss)/d(gray2w)  (gather form, no atomics); `dist` is dist_out of unflow_ternary_fwd (the
+ * mask / weight arguments are kept for signature symmetry and ignored). */
 int unflow_ternary_bwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
                        const float* dist, float* d_gray2w, float weight, float normalizer, int max_distance,
                        int N, int H, int W, unflow_stream_t stream);

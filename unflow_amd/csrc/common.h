@@ -51,3 +51,22 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   __syncthreads();
   return t;
 }
+
+// ---- per-pixel kernels: 32-bit pixel decode (64-bit div/mod costs ~100 instructions per pixel)
+struct Pix {
+  int x, y, n;
+};
+__device__ __forceinline__ Pix decode_pix(unsigned i, unsigned W, unsigned H) {
+  const unsigned r = i / W;
+  Pix p;
+  p.x = (int)(i - r * W);
+  p.n = (int)(r / H);
+  p.y = (int)(r - (unsigned)p.n * H);
+  return p;
+}
+
+// ---- hardware transcendental forms (v_rsq_f32 / v_rcp_f32 / v_exp_f32 / v_log_f32, ~1 ulp): the IEEE sqrt / divide /
+// powf expansions cost 10-100 instructions each and made the census and Charbonnier kernels VALU-bound.
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_pow(float a, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(a)); }  // a > 0

@@ -55,10 +55,10 @@ __device__ __forceinline__ Taps iw_taps(int px, int py, float u, float v, int H,
 
 __global__ void warp_gray_fwd_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow,
                                      float fscale, float* __restrict__ out, int shift, int N, int H, int W) {
-  const long npx = (long)N * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const int n = (int)(i / ((long)W * H));
+  const unsigned npx = (unsigned)N * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y, n = pp.n;
     const long sb = (long)((n + shift) % N) * H * W;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
@@ -74,10 +74,10 @@ __global__ void warp_gray_fwd_kernel(const float* __restrict__ im, int ld, const
 __global__ void warp_gray_bwd_kernel(const float* __restrict__ dgray, const float* __restrict__ im, int ld,
                                      const float* __restrict__ flow, float fscale, float* __restrict__ dflow, int acc,
                                      int shift, int N, int H, int W) {
-  const long npx = (long)N * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const int n = (int)(i / ((long)W * H));
+  const unsigned npx = (unsigned)N * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y, n = pp.n;
     const long sb = (long)((n + shift) % N) * H * W;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
@@ -126,86 +126,99 @@ UNFLOW_API int unflow_warp_gray_bwd(const float* d_gray, const float* im, int ld
 
 // ------------------------------------------------------------------ ternary / census loss (losses.py:90-122)
 // t(z) = z / sqrt(0.81 + z^2);  soft Hamming term h(d) = d^2 / (0.1 + d^2), d = t1 - t2.
-__device__ __forceinline__ float census_t(float z) { return z / sqrtf(0.81f + z * z); }
+// 32x8 pixel tiles with a max_distance halo staged in LDS (each gray value is read (2D+1)^2 times); rsq / rcp
+// hardware forms; the forward pass also leaves dL/d(dist) per pixel so the backward pass needs no pow.
+__device__ __forceinline__ float census_t(float z) { return z * fast_rsqrt(0.81f + z * z); }
+
+constexpr int CT_W = 32, CT_H = 8, CT_MAXD = 4;
+constexpr int CT_LW = CT_W + 2 * CT_MAXD, CT_LH = CT_H + 2 * CT_MAXD;
+
+// loads a (CT_W+2D)x(CT_H+2D) tile of a [H,W] plane into LDS (zero outside the image: SAME padding of losses.py:104)
+__device__ __forceinline__ void load_tile(float* __restrict__ lds, const float* __restrict__ plane, int x0, int y0, int D,
+                                          int H, int W) {
+  const int tw = CT_W + 2 * D, th = CT_H + 2 * D;
+  for (int e = threadIdx.x; e < tw * th; e += 256) {
+    const int ly = e / tw, lx = e - ly * tw;
+    const int gy = y0 - D + ly, gx = x0 - D + lx;
+    lds[ly * CT_LW + lx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? plane[(long)gy * W + gx] : 0.f;
+  }
+}
 
 __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                           const float* __restrict__ mask, int n_mask,
-                                                          float* __restrict__ dist_out, float* __restrict__ loss_acc,
+                                                          float* __restrict__ wgt_out, float* __restrict__ loss_acc,
                                                           float scale, int D, int N, int H, int W) {
+  __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW];
   __shared__ float red[4];
-  const long npx = (long)N * H * W;
+  const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
+  const int ntiles = tiles_x * tiles_y * N;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   float local = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const long n = i / ((long)W * H);
-    const float* a = g1 + n * H * W;
-    const float* b = g2 + n * H * W;
-    const float c1 = a[(long)y * W + x], c2 = b[(long)y * W + x];
+  // grid-stride over tiles: one loss atomic per BLOCK, not per tile (49k same-address atomics at 768x1024x16)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_x * tiles_y), tr = tile - n * tiles_x * tiles_y;
+    const int x0 = (tr % tiles_x) * CT_W, y0 = (tr / tiles_x) * CT_H;
+    __syncthreads();   // previous tile fully consumed
+    load_tile(t1, g1 + (long)n * H * W, x0, y0, D, H, W);
+    load_tile(t2, g2 + (long)n * H * W, x0, y0, D, H, W);
+    __syncthreads();
+    const int x = x0 + tx, y = y0 + ty;
+    if (!(x < W && y < H)) continue;
+    {
+    const float c1 = t1[(ty + D) * CT_LW + tx + D], c2 = t2[(ty + D) * CT_LW + tx + D];
     float dist = 0.f;
-    // channel order of the identity-filter conv: dy outer, dx inner (losses.py:101-104); SAME zero padding
-    for (int dy = -D; dy <= D; dy++)
-      for (int dx = -D; dx <= D; dx++) {
-        const int yy = y + dy, xx = x + dx;
-        const bool inb = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const float v1 = inb ? a[(long)yy * W + xx] : 0.f, v2 = inb ? b[(long)yy * W + xx] : 0.f;
-        const float d = census_t(v1 - c1) - census_t(v2 - c2);
+    for (int dy = 0; dy <= 2 * D; dy++)
+      for (int dx = 0; dx <= 2 * D; dx++) {
+        const float d = census_t(t1[(ty + dy) * CT_LW + tx + dx] - c1) - census_t(t2[(ty + dy) * CT_LW + tx + dx] - c2);
         const float d2 = d * d;
-        dist += d2 / (0.1f + d2);
+        dist += d2 * fast_rcp(0.1f + d2);
       }
-    dist_out[i] = dist;
     const bool interior = y >= D && y < H - D && x >= D && x < W - D;
+    float wgt = 0.f;
     if (interior) {
-      const float m = mask[(n % n_mask) * (long)H * W + (long)y * W + x];
-      local += m * powf(dist * dist + CHARB_EPS * CHARB_EPS, CHARB_ALPHA);
+      const float m = mask[(long)(n % n_mask) * H * W + (long)y * W + x];
+      const float a = dist * dist + CHARB_EPS * CHARB_EPS;
+      const float l2 = __builtin_amdgcn_logf(a);
+      local += m * __builtin_amdgcn_exp2f(CHARB_ALPHA * l2);
+      wgt = scale * m * CHARB_ALPHA * __builtin_amdgcn_exp2f((CHARB_ALPHA - 1.f) * l2) * 2.f * dist;
+    }
+    wgt_out[(long)n * H * W + (long)y * W + x] = wgt;
     }
   }
   const float t = block_sum(local, red);
   if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
 }
 
-// dL/d(dist) at a pixel (0 outside the interior mask)
-__device__ __forceinline__ float ternary_wgt(const float* __restrict__ dist, const float* __restrict__ mask_n, int y,
-                                             int x, int D, int H, int W, float scale) {
-  if (!(y >= D && y < H - D && x >= D && x < W - D)) return 0.f;
-  const float d = dist[(long)y * W + x];
-  const float m = mask_n[(long)y * W + x];
-  return scale * m * CHARB_ALPHA * powf(d * d + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * d;
-}
-
 // Gather form: d/dG2(q) = sum_e f(q, q+e) * (Wt(q+e) + Wt(q)), see DESIGN.md (census backward).
 __global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                          const float* __restrict__ mask, int n_mask,
-                                                          const float* __restrict__ dist, float* __restrict__ dg2,
-                                                          float scale, int D, int N, int H, int W) {
-  const long npx = (long)N * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const long n = i / ((long)W * H);
-    const float* a = g1 + n * H * W;
-    const float* b = g2 + n * H * W;
-    const float* dn = dist + n * H * W;
-    const float* mk = mask + (n % n_mask) * (long)H * W;
-    const float q1 = a[(long)y * W + x], q2 = b[(long)y * W + x];
-    const float wq = ternary_wgt(dn, mk, y, x, D, H, W, scale);
-    float grad = 0.f;
-    for (int dy = -D; dy <= D; dy++)
-      for (int dx = -D; dx <= D; dx++) {
-        const int yy = y + dy, xx = x + dx;
-        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-        const float wr = ternary_wgt(dn, mk, yy, xx, D, H, W, scale);
-        const float ws = wr + wq;
-        if (ws == 0.f) continue;
-        // r = q+e as centre with neighbour q: z = G(q) - G(r)
-        const float z1 = q1 - a[(long)yy * W + xx], z2 = q2 - b[(long)yy * W + xx];
-        const float d = census_t(z1) - census_t(z2);
-        const float den = 0.1f + d * d;
-        const float dh = 2.f * d * 0.1f / (den * den);           // dh/dd
-        const float s2 = 0.81f + z2 * z2;
-        const float dt2 = 0.81f / (s2 * sqrtf(s2));             // dt/dz at z2
-        grad += -dh * dt2 * ws;                                  // dd/dt2 = -1, dz2/dG2(q) = +1
-      }
-    dg2[i] = grad;
-  }
+                                                          const float* __restrict__ wgt, float* __restrict__ dg2, int D,
+                                                          int N, int H, int W) {
+  __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW], tw[CT_LH * CT_LW];
+  const int n = blockIdx.z, x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+  load_tile(t1, g1 + (long)n * H * W, x0, y0, D, H, W);
+  load_tile(t2, g2 + (long)n * H * W, x0, y0, D, H, W);
+  load_tile(tw, wgt + (long)n * H * W, x0, y0, D, H, W);   // zero outside the image == "no such centre pixel"
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x = x0 + tx, y = y0 + ty;
+  if (x >= W || y >= H) return;
+  const float q1 = t1[(ty + D) * CT_LW + tx + D], q2 = t2[(ty + D) * CT_LW + tx + D], wq = tw[(ty + D) * CT_LW + tx + D];
+  float grad = 0.f;
+  for (int dy = 0; dy <= 2 * D; dy++)
+    for (int dx = 0; dx <= 2 * D; dx++) {
+      const int yy = y + dy - D, xx = x + dx - D;
+      if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;   // no centre pixel there
+      const float ws = tw[(ty + dy) * CT_LW + tx + dx] + wq;
+      // r = q+e as centre with neighbour q: z = G(q) - G(r)
+      const float z1 = q1 - t1[(ty + dy) * CT_LW + tx + dx], z2 = q2 - t2[(ty + dy) * CT_LW + tx + dx];
+      const float r2 = fast_rsqrt(0.81f + z2 * z2);
+      const float d = census_t(z1) - z2 * r2;
+      const float iden = fast_rcp(0.1f + d * d);
+      const float dh = 2.f * d * 0.1f * iden * iden;        // dh/dd
+      const float dt2 = 0.81f * r2 * r2 * r2;               // dt/dz at z2
+      grad -= dh * dt2 * ws;                                // dd/dt2 = -1, dz2/dG2(q) = +1
+    }
+  dg2[(long)n * H * W + (long)y * W + x] = grad;
 }
 
 UNFLOW_API int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
@@ -213,18 +226,22 @@ UNFLOW_API int unflow_ternary_fwd(const float* gray1, const float* gray2w, const
                                   int N, int H, int W, unflow_stream_t stream) {
   if (!gray1 || !gray2w || !mask || !dist_out) return UNFLOW_ERR_NULL;
   if (N <= 0 || H <= 0 || W <= 0 || n_mask <= 0 || max_distance < 0) return UNFLOW_ERR_SHAPE;
-  ternary_fwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
-      gray1, gray2w, mask, n_mask, dist_out, loss_acc, weight / normalizer, max_distance, N, H, W);
+  if (max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;   // the reference uses 1..3 (unsupervised.py:88)
+  const long ntiles = (long)cdiv(W, CT_W) * cdiv(H, CT_H) * N;
+  ternary_fwd_kernel<<<(int)min(ntiles, (long)2048), 256, 0, as_stream(stream)>>>(gray1, gray2w, mask, n_mask, dist_out, loss_acc,
+                                                          weight / normalizer, max_distance, N, H, W);
   return launch_status();
 }
 
 UNFLOW_API int unflow_ternary_bwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
                                   const float* dist, float* d_gray2w, float weight, float normalizer,
                                   int max_distance, int N, int H, int W, unflow_stream_t stream) {
-  if (!gray1 || !gray2w || !mask || !dist || !d_gray2w) return UNFLOW_ERR_NULL;
-  if (N <= 0 || H <= 0 || W <= 0 || n_mask <= 0 || max_distance < 0) return UNFLOW_ERR_SHAPE;
-  ternary_bwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
-      gray1, gray2w, mask, n_mask, dist, d_gray2w, weight / normalizer, max_distance, N, H, W);
+  if (!gray1 || !gray2w || !dist || !d_gray2w) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || max_distance < 0) return UNFLOW_ERR_SHAPE;
+  if (max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;
+  (void)mask; (void)n_mask; (void)weight; (void)normalizer;   // already folded into `dist` (= dL/d dist) by the forward pass
+  dim3 grid(cdiv(W, CT_W), cdiv(H, CT_H), N);
+  ternary_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(gray1, gray2w, dist, d_gray2w, max_distance, N, H, W);
   return launch_status();
 }
 
@@ -232,9 +249,10 @@ UNFLOW_API int unflow_ternary_bwd(const float* gray1, const float* gray2w, const
 // 4 stencils per flow channel: delta_k(p) = f(p+a_k) + f(p-a_k) - 2 f(p), a = (0,1),(1,0),(1,1),(1,-1) [dy,dx];
 // masks (create_mask, :260-263) zero exactly the pixels whose stencil would leave the image.
 // Charbonnier on each, normaliser N_dir*H*W*4 per channel (charbonnier_loss :311-312).
-__device__ __forceinline__ float charb(float x) { return powf(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA); }
+// ((x*beta)^2 + eps^2)^alpha and its derivative via exp2/log2 (the base is >= 1e-6 > 0)
+__device__ __forceinline__ float charb(float x) { return fast_pow(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA); }
 __device__ __forceinline__ float charb_grad(float x) {
-  return CHARB_ALPHA * powf(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * x;
+  return CHARB_ALPHA * fast_pow(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * x;
 }
 
 __global__ __launch_bounds__(256) void second_order_kernel(const float* __restrict__ flow, float fs,
@@ -319,11 +337,11 @@ __global__ __launch_bounds__(256) void mask_terms_kernel(const float* __restrict
                                                          float* __restrict__ gwarped, int acc, float s_fb, float s_occ,
                                                          float s_sym, int shift, int N, int H, int W) {
   __shared__ float red[4];
-  const long npx = (long)N * H * W;
+  const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const int n = (int)(i / ((long)W * H));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int x = pp.x, y = pp.y, n = pp.n;
     const long pix = (long)y * W + x;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const float ux = f.x * fs, uy = f.y * fs;
@@ -390,11 +408,11 @@ __global__ __launch_bounds__(256) void photometric_kernel(const float* __restric
                                                           float* __restrict__ loss_acc, float* __restrict__ dflow, int acc,
                                                           float scale, int shift, int N, int H, int W) {
   __shared__ float red[4];
-  const long npx = (long)N * H * W;
+  const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const int n = (int)(i / ((long)W * H));
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y, n = pp.n;
     const long sb = (long)((n + shift) % N) * H * W;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const Taps t = iw_taps(px, py, f.x * fs, f.y * fs, H, W);
@@ -407,9 +425,10 @@ __global__ __launch_bounds__(256) void photometric_kernel(const float* __restric
     for (int k = 0; k < 3; k++) {
       const float w = ((t.wa * pa[k] + t.wb * pb[k]) + t.wc * pc[k]) + t.wd * pd[k];
       const float d = (p1[k] - w) * 255.0f;
-      local += m * powf(d * d + CHARB_EPS * CHARB_EPS, CHARB_ALPHA);
+      const float l2 = __builtin_amdgcn_logf(d * d + CHARB_EPS * CHARB_EPS);
+      local += m * __builtin_amdgcn_exp2f(CHARB_ALPHA * l2);
       // d/dw of ((x*beta)^2+eps^2)^alpha with x = im1 - w
-      const float g = -m * CHARB_ALPHA * powf(d * d + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * d * 255.0f;
+      const float g = -m * CHARB_ALPHA * __builtin_amdgcn_exp2f((CHARB_ALPHA - 1.f) * l2) * 2.f * d * 255.0f;
       ga += g * pa[k]; gb += g * pb[k]; gc += g * pc[k]; gd += g * pd[k];
     }
     if (dflow) {
@@ -441,10 +460,11 @@ UNFLOW_API int unflow_photometric_fwd_bwd(const float* im, int ld_im, const floa
 __global__ __launch_bounds__(256) void smooth_1st_kernel(const float* __restrict__ flow, float fs, float* __restrict__ loss_acc,
                                                          float* __restrict__ dflow, int acc, float scale, int N, int H, int W) {
   __shared__ float red[4];
-  const long npx = (long)N * H * W;
+  const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int x = pp.x, y = pp.y;
     const float2* f = reinterpret_cast<const float2*>(flow) + (i - ((long)y * W + x));
     const float2 c = f[(long)y * W + x];
     float gu = 0.f, gv = 0.f;
@@ -501,11 +521,12 @@ __global__ __launch_bounds__(256) void gradient_loss_fwd_kernel(const float* __r
                                                                 int n_mask, float* __restrict__ gdiff,
                                                                 float* __restrict__ loss_acc, float scale, int N, int H, int W) {
   __shared__ float red[4];
-  const long npx = (long)N * H * W;
+  const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const long n = i / ((long)W * H);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int x = pp.x, y = pp.y;
+    const long n = pp.n;
     const float* a = im1 + n * H * W * ld1;
     const float* b = im2w + n * H * W * 3;
     const float m = mask[(n % n_mask) * (long)H * W + (long)y * W + x];

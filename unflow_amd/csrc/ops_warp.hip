@@ -25,19 +25,23 @@ __device__ __forceinline__ BwTaps bw_sample(int px, int py, float u, float v) {
   return t;
 }
 
+template <int CT>
 __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
                                          float* __restrict__ out, int B, int H, int W, int C) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const long b = i / ((long)W * H);
+  const unsigned npx = (unsigned)B * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y;
+    const long b = pp.n;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const BwTaps t = bw_sample(px, py, f.x, f.y);
     const float* base = img + b * H * W * C;
     const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 + 1 >= 0 && t.x0 + 1 < W;
     const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 + 1 >= 0 && t.y0 + 1 < H;
     const long otl = ((long)t.y0 * W + t.x0) * C;
-    for (int c = 0; c < C; c++) {
+    const int CC = CT ? CT : C;
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
       float s = 0.f;
       // each product is rounded before the add (CUDA compiles `sum += a*b*c` of the reference with
       // fma contraction possible; tolerance covers it)
@@ -45,18 +49,20 @@ __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const fl
       if (xr && yt) s += t.wr * t.wt * base[otl + C + c];
       if (xl && yb) s += t.wl * t.wb * base[otl + (long)W * C + c];
       if (xr && yb) s += t.wr * t.wb * base[otl + (long)W * C + C + c];
-      out[i * C + c] = s;
+      out[(size_t)i * C + c] = s;
     }
   }
 }
 
+template <int CT>
 __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ img,
                                          const float* __restrict__ flow, float* __restrict__ dflow, int B,
                                          int H, int W, int C) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const long b = i / ((long)W * H);
+  const unsigned npx = (unsigned)B * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y;
+    const long b = pp.n;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const BwTaps t = bw_sample(px, py, f.x, f.y);
     const float* base = img + b * H * W * C;
@@ -64,8 +70,10 @@ __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const f
     const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 + 1 >= 0 && t.y0 + 1 < H;
     const long otl = ((long)t.y0 * W + t.x0) * C;
     float du = 0.f, dv = 0.f;
-    for (int c = 0; c < C; c++) {
-      const float din = dout[i * C + c];
+    const int CC = CT ? CT : C;
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+      const float din = dout[(size_t)i * C + c];
       float q;
       if (xl && yt) { q = base[otl + c] * din; du -= t.wt * q; dv -= t.wl * q; }
       if (xr && yt) { q = base[otl + C + c] * din; du += t.wt * q; dv -= t.wr * q; }
@@ -92,7 +100,12 @@ UNFLOW_API int unflow_backward_warp_fwd(const float* images, const float* flows,
   if (B < 0 || H < 0 || W < 0 || C < 0) return UNFLOW_ERR_SHAPE;
   const long npx = (long)B * H * W;
   if (npx == 0 || C == 0) return UNFLOW_OK;  // ref: `if (total_count == 0) return;`
-  backward_warp_fwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(images, flows, out, B, H, W, C);
+  switch (C) {
+    case 1: backward_warp_fwd_kernel<1><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(images, flows, out, B, H, W, C); break;
+    case 2: backward_warp_fwd_kernel<2><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(images, flows, out, B, H, W, C); break;
+    case 3: backward_warp_fwd_kernel<3><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(images, flows, out, B, H, W, C); break;
+    default: backward_warp_fwd_kernel<0><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(images, flows, out, B, H, W, C); break;
+  }
   return launch_status();
 }
 
@@ -102,7 +115,12 @@ UNFLOW_API int unflow_backward_warp_bwd(const float* dout, const float* images, 
   if (B < 0 || H < 0 || W < 0 || C < 0) return UNFLOW_ERR_SHAPE;
   const long npx = (long)B * H * W;
   if (npx == 0) return UNFLOW_OK;
-  backward_warp_bwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, images, flows, dflows, B, H, W, C);
+  switch (C) {
+    case 1: backward_warp_bwd_kernel<1><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, images, flows, dflows, B, H, W, C); break;
+    case 2: backward_warp_bwd_kernel<2><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, images, flows, dflows, B, H, W, C); break;
+    case 3: backward_warp_bwd_kernel<3><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, images, flows, dflows, B, H, W, C); break;
+    default: backward_warp_bwd_kernel<0><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, images, flows, dflows, B, H, W, C); break;
+  }
   return launch_status();
 }
 
@@ -140,13 +158,14 @@ __device__ __forceinline__ IwTaps iw_sample(int px, int py, float u, float v, in
   return t;
 }
 
+template <int CT>
 __global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, const float* __restrict__ flow,
                                       float fscale, float* __restrict__ out, int* __restrict__ idx4, int shift,
                                       int B, int H, int W, int C) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const int b = (int)(i / ((long)W * H));
+  const unsigned npx = (unsigned)B * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y, b = pp.n;
     const int bs = (b + shift) % B;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const IwTaps t = iw_sample(px, py, f.x * fscale, f.y * fscale, H, W);
@@ -159,19 +178,22 @@ __global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, c
     const float* pb = im + (sbase + t.ib) * ld_im;
     const float* pc = im + (sbase + t.ic) * ld_im;
     const float* pd = im + (sbase + t.id) * ld_im;
-    for (int c = 0; c < C; c++)
-      out[i * C + c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
+    const int CC = CT ? CT : C;
+#pragma unroll
+    for (int c = 0; c < CC; c++)
+      out[(size_t)i * C + c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
   }
 }
 
+template <int CT>
 __global__ void image_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ im, int ld_im,
                                       const float* __restrict__ flow, float fscale, float* __restrict__ d_im,
                                       float* __restrict__ d_flow, int acc_flow, int shift, int B, int H, int W,
                                       int C) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % W), py = (int)((i / W) % H);
-    const int b = (int)(i / ((long)W * H));
+  const unsigned npx = (unsigned)B * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y, b = pp.n;
     const int bs = (b + shift) % B;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const IwTaps t = iw_sample(px, py, f.x * fscale, f.y * fscale, H, W);
@@ -179,8 +201,10 @@ __global__ void image_warp_bwd_kernel(const float* __restrict__ dout, const floa
     const long oa = (sbase + t.ia) * ld_im, ob = (sbase + t.ib) * ld_im, oc = (sbase + t.ic) * ld_im,
                od = (sbase + t.id) * ld_im;
     float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
-    for (int c = 0; c < C; c++) {
-      const float g = dout[i * C + c];
+    const int CC = CT ? CT : C;
+#pragma unroll
+    for (int c = 0; c < CC; c++) {
+      const float g = dout[(size_t)i * C + c];
       ga += g * im[oa + c];
       gb += g * im[ob + c];
       gc += g * im[oc + c];
@@ -211,8 +235,12 @@ UNFLOW_API int unflow_image_warp_fwd(const float* im, int ld_im, const float* fl
   if (B < 0 || H < 0 || W < 0 || C < 0 || ld_im < C) return UNFLOW_ERR_SHAPE;
   const long npx = (long)B * H * W;
   if (npx == 0 || C == 0) return UNFLOW_OK;
-  image_warp_fwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, out, idx4,
-                                                                         pair_shift, B, H, W, C);
+  switch (C) {
+    case 1: image_warp_fwd_kernel<1><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, out, idx4, pair_shift, B, H, W, C); break;
+    case 2: image_warp_fwd_kernel<2><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, out, idx4, pair_shift, B, H, W, C); break;
+    case 3: image_warp_fwd_kernel<3><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, out, idx4, pair_shift, B, H, W, C); break;
+    default: image_warp_fwd_kernel<0><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, out, idx4, pair_shift, B, H, W, C); break;
+  }
   return launch_status();
 }
 
@@ -223,8 +251,12 @@ UNFLOW_API int unflow_image_warp_bwd(const float* dout, const float* im, int ld_
   if (B < 0 || H < 0 || W < 0 || C < 0 || ld_im < C) return UNFLOW_ERR_SHAPE;
   const long npx = (long)B * H * W;
   if (npx == 0) return UNFLOW_OK;
-  image_warp_bwd_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(
-      dout, im, ld_im, flow, flow_scale, d_im, d_flow, accumulate_d_flow, pair_shift, B, H, W, C);
+  switch (C) {
+    case 1: image_warp_bwd_kernel<1><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, im, ld_im, flow, flow_scale, d_im, d_flow, accumulate_d_flow, pair_shift, B, H, W, C); break;
+    case 2: image_warp_bwd_kernel<2><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, im, ld_im, flow, flow_scale, d_im, d_flow, accumulate_d_flow, pair_shift, B, H, W, C); break;
+    case 3: image_warp_bwd_kernel<3><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, im, ld_im, flow, flow_scale, d_im, d_flow, accumulate_d_flow, pair_shift, B, H, W, C); break;
+    default: image_warp_bwd_kernel<0><<<stream_grid(npx), 256, 0, as_stream(stream)>>>(dout, im, ld_im, flow, flow_scale, d_im, d_flow, accumulate_d_flow, pair_shift, B, H, W, C); break;
+  }
   return launch_status();
 }
 
