@@ -36,20 +36,28 @@ __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const fl
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const BwTaps t = bw_sample(px, py, f.x, f.y);
     const float* base = img + b * H * W * C;
-    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 + 1 >= 0 && t.x0 + 1 < W;
-    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 + 1 >= 0 && t.y0 + 1 < H;
-    const long otl = ((long)t.y0 * W + t.x0) * C;
+    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 >= -1 && t.x0 < W - 1;
+    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 >= -1 && t.y0 < H - 1;
+    // branch-free taps: addresses clamped into the image, out-of-range VALUES replaced by 0 (the reference
+    // skips them, :44-67; adding w*0 is the same number and keeps the four-term order)
+    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0, -1), W - 2) + 1;
+    const int ya = min(max(t.y0, 0), H - 1), yc = min(max(t.y0, -1), H - 2) + 1;
     const int CC = CT ? CT : C;
+    const float* p_tl = base + (size_t)(ya * W + xa) * CC;
+    const float* p_tr = base + (size_t)(ya * W + xb) * CC;
+    const float* p_bl = base + (size_t)(yc * W + xa) * CC;
+    const float* p_br = base + (size_t)(yc * W + xb) * CC;
+    const bool m_tl = xl && yt, m_tr = xr && yt, m_bl = xl && yb, m_br = xr && yb;
+    const float w_tl = t.wl * t.wt, w_tr = t.wr * t.wt, w_bl = t.wl * t.wb, w_br = t.wr * t.wb;
 #pragma unroll
     for (int c = 0; c < CC; c++) {
+      const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
       float s = 0.f;
-      // each product is rounded before the add (CUDA compiles `sum += a*b*c` of the reference with
-      // fma contraction possible; tolerance covers it)
-      if (xl && yt) s += t.wl * t.wt * base[otl + c];
-      if (xr && yt) s += t.wr * t.wt * base[otl + C + c];
-      if (xl && yb) s += t.wl * t.wb * base[otl + (long)W * C + c];
-      if (xr && yb) s += t.wr * t.wb * base[otl + (long)W * C + C + c];
-      out[(size_t)i * C + c] = s;
+      s += m_tl ? w_tl * v_tl : 0.f;
+      s += m_tr ? w_tr * v_tr : 0.f;
+      s += m_bl ? w_bl * v_bl : 0.f;
+      s += m_br ? w_br * v_br : 0.f;
+      out[(size_t)i * CC + c] = s;
     }
   }
 }
@@ -66,19 +74,27 @@ __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const f
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
     const BwTaps t = bw_sample(px, py, f.x, f.y);
     const float* base = img + b * H * W * C;
-    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 + 1 >= 0 && t.x0 + 1 < W;
-    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 + 1 >= 0 && t.y0 + 1 < H;
-    const long otl = ((long)t.y0 * W + t.x0) * C;
-    float du = 0.f, dv = 0.f;
+    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 >= -1 && t.x0 < W - 1;
+    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 >= -1 && t.y0 < H - 1;
+    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0, -1), W - 2) + 1;
+    const int ya = min(max(t.y0, 0), H - 1), yc = min(max(t.y0, -1), H - 2) + 1;
     const int CC = CT ? CT : C;
+    const float* p_tl = base + (size_t)(ya * W + xa) * CC;
+    const float* p_tr = base + (size_t)(ya * W + xb) * CC;
+    const float* p_bl = base + (size_t)(yc * W + xa) * CC;
+    const float* p_br = base + (size_t)(yc * W + xb) * CC;
+    const bool m_tl = xl && yt, m_tr = xr && yt, m_bl = xl && yb, m_br = xr && yb;
+    float du = 0.f, dv = 0.f;
 #pragma unroll
     for (int c = 0; c < CC; c++) {
-      const float din = dout[(size_t)i * C + c];
-      float q;
-      if (xl && yt) { q = base[otl + c] * din; du -= t.wt * q; dv -= t.wl * q; }
-      if (xr && yt) { q = base[otl + C + c] * din; du += t.wt * q; dv -= t.wr * q; }
-      if (xl && yb) { q = base[otl + (long)W * C + c] * din; du -= t.wb * q; dv += t.wl * q; }
-      if (xr && yb) { q = base[otl + (long)W * C + C + c] * din; du += t.wb * q; dv += t.wr * q; }
+      const float din = dout[(size_t)i * CC + c];
+      const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
+      const float q_tl = m_tl ? v_tl * din : 0.f, q_tr = m_tr ? v_tr * din : 0.f;
+      const float q_bl = m_bl ? v_bl * din : 0.f, q_br = m_br ? v_br * din : 0.f;
+      du -= t.wt * q_tl; dv -= t.wl * q_tl;
+      du += t.wt * q_tr; dv -= t.wr * q_tr;
+      du -= t.wb * q_bl; dv += t.wl * q_bl;
+      du += t.wb * q_br; dv += t.wr * q_br;
     }
     reinterpret_cast<float2*>(dflow)[i] = make_float2(du, dv);
   }
@@ -202,18 +218,39 @@ __global__ void image_warp_bwd_kernel(const float* __restrict__ dout, const floa
                od = (sbase + t.id) * ld_im;
     float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
     const int CC = CT ? CT : C;
+    if (CT) {  // all loads first (vectorised), then the scatter
+      float g[CT ? CT : 1];
 #pragma unroll
-    for (int c = 0; c < CC; c++) {
-      const float g = dout[(size_t)i * C + c];
-      ga += g * im[oa + c];
-      gb += g * im[ob + c];
-      gc += g * im[oc + c];
-      gd += g * im[od + c];
+      for (int c = 0; c < CT; c++) g[c] = dout[(size_t)i * CT + c];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        ga += g[c] * im[oa + c];
+        gb += g[c] * im[ob + c];
+        gc += g[c] * im[oc + c];
+        gd += g[c] * im[od + c];
+      }
       if (d_im) {  // gather-gradient = scatter-add (clamped duplicates accumulate)
-        atomicAdd(d_im + oa + c, t.wa * g);
-        atomicAdd(d_im + ob + c, t.wb * g);
-        atomicAdd(d_im + oc + c, t.wc * g);
-        atomicAdd(d_im + od + c, t.wd * g);
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          atomicAdd(d_im + oa + c, t.wa * g[c]);
+          atomicAdd(d_im + ob + c, t.wb * g[c]);
+          atomicAdd(d_im + oc + c, t.wc * g[c]);
+          atomicAdd(d_im + od + c, t.wd * g[c]);
+        }
+      }
+    } else {
+      for (int c = 0; c < CC; c++) {
+        const float g = dout[(size_t)i * C + c];
+        ga += g * im[oa + c];
+        gb += g * im[ob + c];
+        gc += g * im[oc + c];
+        gd += g * im[od + c];
+        if (d_im) {
+          atomicAdd(d_im + oa + c, t.wa * g);
+          atomicAdd(d_im + ob + c, t.wb * g);
+          atomicAdd(d_im + oc + c, t.wc * g);
+          atomicAdd(d_im + od + c, t.wd * g);
+        }
       }
     }
     float du = ((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw) * fscale;
