@@ -26,9 +26,25 @@ def out_hw(H, W, stride):
     return -(-H // stride), -(-W // stride)
 
 
+_WS_SLOT = [1]
+
+
+class ws_slot:
+    """Select the split-K scratch buffer for the calls inside the block (one buffer per concurrently running stream)."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        self.prev, _WS_SLOT[0] = _WS_SLOT[0], self.slot
+
+    def __exit__(self, *exc):
+        _WS_SLOT[0] = self.prev
+
+
 def _ws(device, B, H, W, Cin, Cout, k, stride):
     n = _lib.lib().unflow_conv_workspace_bytes(B, H, W, Cin, Cout, k, stride)
-    t = workspace(n, device, slot=1)
+    t = workspace(n, device, slot=_WS_SLOT[0])
     return ptr(t), csz(t.numel() * 4)
 
 
