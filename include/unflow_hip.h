@@ -262,6 +262,24 @@ int unflow_gradient_loss_bwd(const float* gdiff, float* d_im2_warped, int N, int
 int unflow_prepare_images(const float* im_u8range, float* net_in4, float* out01, const float* mean3, long npix,
                           unflow_stream_t stream);
 
+/* ---- augmentation ---------------------------------------------------------------------- */
+
+/* Spatial-transformer resampling of core/spatial_transformer.py:56-175 as used by random_affine
+ * (core/augment.py:50-55): out[b,i,j,:] = bilinear sample of U[b % n_u] at theta[b % n_theta] @ (x_t, y_t, 1),
+ * x_t/y_t = linspace(-1,1,out_w/out_h), source coords (x_s+1)*W/2, indices clipped to the image BEFORE the
+ * weights are formed (:84-87,113-120).  theta: DEVICE [n_theta,2,3] row-major.  U channels-last with channel
+ * stride ld_u; out with ld_out.  No gradient (the reference wraps the result in stop_gradient, augment.py:54). */
+int unflow_stn_affine_fwd(const float* U, int n_u, int ld_u, const float* theta, int n_theta, float* out, int ld_out,
+                          int B, int H, int W, int C, int out_h, int out_w, unflow_stream_t stream);
+
+/* random_photometric (core/augment.py:78-108) given its draws, fused with the mean subtraction of
+ * core/unsupervised.py:67-68: out[n,y,x,c] = pow(clamp((im*(contrast+1)+brightness)*colour[c], 0, 1), 1/gamma)
+ * + noise - mean3[c]/255, c < 3; channels 3..ld_out-1 are written as 0.  contrast/brightness/gamma/noise: DEVICE
+ * [n_par], colour3: DEVICE [n_par,3]; sample n uses draw n % n_par.  mean3: HOST [3] in [0,255], or NULL. */
+int unflow_photometric_augment(const float* im, int ld_in, float* out, int ld_out, const float* contrast,
+                               const float* brightness, const float* colour3, const float* gamma, const float* noise,
+                               int n_par, const float* mean3, int N, int H, int W, unflow_stream_t stream);
+
 /* Input tensor of a FlowNetS stage (flownet.py:46-59), channels-last with stride ld_out (pad channels untouched):
  * [first, second] (6 ch) when prev_flow2 == NULL, else [first, second, flow, warp(second, flow), |warp - first|]
  * (14 ch) with flow = resize_bilinear(prev_flow2 [N,h,w,2]) * flow_scale (= 4 * FLOW_SCALE).  Forward only: the

@@ -546,11 +546,13 @@ def regularization_loss(P, scale=0.0004):
     return sum(scale * 0.5 * (v * v).sum() for n, v in P.items() if n.endswith('/weights'))
 
 
-def pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params):
-    """unsupervised.py:85-147 (augment=False, full_res off), given un-normalised images in [0,255]."""
-    im1 = im1 / 255.0
-    im2 = im2 / 255.0
-    border_mask = create_border_mask(im1, 0.1)
+def pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params, border_mask=None):
+    """unsupervised.py:85-147 (full_res off), given un-normalised images in [0,255] — or, with `border_mask` given
+    (the augmented per-sample mask of unsupervised.py:39-49), the geometrically augmented images in [0,1]."""
+    if border_mask is None:
+        im1 = im1 / 255.0
+        im2 = im2 / 255.0
+        border_mask = create_border_mask(im1, 0.1)
     layer_weights = [12.7, 4.35, 3.9, 3.4, 1.1]
     layer_patch_distances = [3, 2, 2, 1, 1]
     im1_s, im2_s, mask_s = downsample(im1, 4), downsample(im2, 4), downsample(border_mask, 4)
@@ -576,16 +578,101 @@ def pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params):
     return combined, terms
 
 
-def unsupervised_loss(P, im1, im2, params=None, return_flow=False):
-    """unsupervised.py:27-164 with augment=False.  im1/im2: NHWC in [0,255]."""
+# ----------------------------------------------------------------------------
+# augmentation (core/augment.py, core/spatial_transformer.py) — PARITY UNPINNED: the reference has no test for it
+# ----------------------------------------------------------------------------
+def affine_theta(tx, ty, rot_deg, scale, flip=None):
+    """augment.py:17-48: theta = [[cos,-sin,tx],[sin,cos,ty]] @ diag(scale_x, scale, 1), scale_x = scale*flip.
+    All arguments are [B] tensors (the random draws); flip is +-1 (or None: no horizontal flipping)."""
+    rad = (rot_deg * np.pi) / 180.0
+    sx = scale if flip is None else scale * flip
+    c, s_ = torch.cos(rad), torch.sin(rad)
+    row0 = torch.stack([c * sx, -s_ * scale, tx], 1)
+    row1 = torch.stack([s_ * sx, c * scale, ty], 1)
+    return torch.stack([row0, row1], 1)          # [B,2,3]
+
+
+def stn_transformer(U, theta, out_size=None):
+    """spatial_transformer.py:19-175.  U [B,H,W,C], theta [B,2,3]; bilinear with indices clipped BEFORE the weights
+    are formed (:84-87,113-120), so border samples are not convex combinations."""
+    B, H, W, C = U.shape
+    Ho, Wo = (H, W) if out_size is None else out_size
+    dt = U.dtype
+    lin = lambda n: torch.tensor(-1.0, dtype=dt) + torch.arange(n, dtype=dt) * ((torch.tensor(1.0, dtype=dt) -
+                                                                               torch.tensor(-1.0, dtype=dt)) / (n - 1))
+    x_t = lin(Wo).view(1, 1, Wo).expand(1, Ho, Wo).reshape(1, -1)      # _meshgrid :122-140
+    y_t = lin(Ho).view(1, Ho, 1).expand(1, Ho, Wo).reshape(1, -1)
+    t = theta.to(dt)
+    x_s = t[:, 0, 0:1] * x_t + t[:, 0, 1:2] * y_t + t[:, 0, 2:3]       # theta @ (x_t, y_t, 1) :160-163
+    y_s = t[:, 1, 0:1] * x_t + t[:, 1, 1:2] * y_t + t[:, 1, 2:3]
+    x = (x_s + 1.0) * float(W) / 2.0                                   # :75-76
+    y = (y_s + 1.0) * float(H) / 2.0
+    x0 = torch.floor(x).long()
+    y0 = torch.floor(y).long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
+    y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
+    flat = U.reshape(B, H * W, C)
+    g = lambda yy, xx: torch.gather(flat, 1, (yy * W + xx).unsqueeze(-1).expand(-1, -1, C))
+    Ia, Ib, Ic, Id = g(y0, x0), g(y1, x0), g(y0, x1), g(y1, x1)        # :98-105
+    x0f, x1f, y0f, y1f = x0.to(dt), x1.to(dt), y0.to(dt), y1.to(dt)
+    wa = ((x1f - x) * (y1f - y)).unsqueeze(-1)
+    wb = ((x1f - x) * (y - y0f)).unsqueeze(-1)
+    wc = ((x - x0f) * (y1f - y)).unsqueeze(-1)
+    wd = ((x - x0f) * (y - y0f)).unsqueeze(-1)
+    out = wa * Ia + wb * Ib + wc * Ic + wd * Id
+    return out.reshape(B, Ho, Wo, C)
+
+
+def random_affine_apply(tensors, theta):
+    """augment.py:50-55 with the random draws replaced by a given theta; stop_gradient -> detach."""
+    return [stn_transformer(t_, theta).detach() for t_ in tensors]
+
+
+def random_photometric_apply(ims, contrast, gamma, colour, noise, brightness):
+    """augment.py:78-108 with the draws given: contrast/gamma/noise/brightness [B], colour [B,3].  noise and
+    brightness are one scalar per SAMPLE (shape [num_batch,1], :83-91), not per pixel."""
+    out = []
+    v = lambda t_: t_.view(-1, 1, 1, 1)
+    for im in ims:
+        r = (im * (v(contrast) + 1.0) + v(brightness)) * colour.view(-1, 1, 1, 3)
+        r = torch.clamp(r, 0.0, 1.0)
+        r = torch.pow(r, v(1.0 / gamma))
+        out.append((r + v(noise)).detach())
+    return out
+
+
+def augment_apply(im1, im2, aug):
+    """unsupervised.py:31-60 with augment=True and the random draws supplied in `aug` (dict with theta_global,
+    theta_local [B,2,3], contrast, gamma, noise, brightness [B], colour [B,3]).  im1/im2 in [0,255].
+    Returns (im1_geo, im2_geo, border_mask [B,H,W,1], im1_photo, im2_photo), images in [0,1]."""
+    im1 = im1 / 255.0
+    im2 = im2 / 255.0
+    border = create_border_mask(im1, 0.1).expand(im1.shape[0], -1, -1, -1)
+    im1_geo, im2_geo, mask_g = random_affine_apply([im1, im2, border], aug['theta_global'])
+    im2_geo, mask_l = random_affine_apply([im2_geo, border], aug['theta_local'])
+    mask = mask_l * mask_g
+    p1, p2 = random_photometric_apply([im1_geo, im2_geo], aug['contrast'], aug['gamma'], aug['colour'],
+                                      aug['noise'], aug['brightness'])
+    return im1_geo, im2_geo, mask, p1, p2
+
+
+def unsupervised_loss(P, im1, im2, params=None, return_flow=False, augment=None):
+    """unsupervised.py:27-164.  im1/im2: NHWC in [0,255].  augment: None (augment=False) or the dict of
+    augment_apply."""
     params = dict(DEFAULT_PARAMS) if params is None else params
     mean = torch.tensor(CHANNEL_MEAN, dtype=im1.dtype) / 255.0
-    a = im1 / 255.0 - mean
-    b = im2 / 255.0 - mean
+    border_mask = None
+    if augment is None:
+        a = im1 / 255.0 - mean
+        b = im2 / 255.0 - mean
+    else:
+        im1, im2, border_mask, p1, p2 = augment_apply(im1, im2, augment)   # losses see the geo images (:63-65)
+        a, b = p1 - mean, p2 - mean                                         # the network the photo ones (:67-68)
     flows_fw, flows_bw = flownet(P, a, b, flownet_spec=params.get('flownet', 'S'), backward_flow=True,
                                  train_all=bool(params.get('train_all')))
     flows_fw, flows_bw = flows_fw[-1], flows_bw[-1]
-    combined, terms = pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params)
+    combined, terms = pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params, border_mask=border_mask)
     final_loss = combined + regularization_loss(P)
     if not return_flow:
         return final_loss

@@ -219,3 +219,94 @@ def test_flownet_s_and_stacks_vs_oracle(spec, dev):
             # |.|, leaky kinks) amplifies that noise ~10x per stage
             tol = 3e-4 * 10 ** (len(spec) - 1) if len(spec) < 3 else 1e-2
             assert _rel(got[k], gref) < tol, (k, _rel(got[k], gref))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# augmentation: core/augment.py + core/spatial_transformer.py.  PARITY UNPINNED in the reference
+# (no test there); the oracle restates the cited lines.
+# ---------------------------------------------------------------------------------------------------------------
+def _draws(B, seed):
+    from unflow_amd.core import augment as A
+    g = torch.Generator().manual_seed(seed)
+    aug = A.draw_training_augmentation(B, g)
+    # make the geometric part non-trivial (the training ranges have no rotation / translation)
+    aug['theta_global'] = A.draw_affine(B, max_translation_x=0.15, max_translation_y=0.1, max_rotation=20.0,
+                                        min_scale=0.8, max_scale=1.2, horizontal_flipping=True, generator=g)
+    return aug
+
+
+@pytest.mark.parametrize("C", [1, 3, 5])
+def test_stn_affine_vs_oracle(C, dev):
+    from unflow_amd.core import augment as A
+    from oracle import model_ref as M
+    B, H, W = 3, 40, 56
+    g = torch.Generator().manual_seed(C)
+    U = torch.rand(B, H, W, C, generator=g)
+    theta = _draws(B, 10 + C)['theta_global']
+    ref = M.stn_transformer(U, theta)
+    got = A.transformer(U.to(dev), theta)
+    # same fp32 operations in the same order; a floor() flip at an exact cell boundary would show as an O(1) error
+    assert (got.cpu() - ref).abs().max().item() < 1e-5
+    # identity theta is NOT the identity map in the reference's transformer (grid maps to [0, W] not [0, W-1]; the last
+    # row / column come out as 0 because both clipped taps coincide) — reproduce that quirk
+    eye = torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]]).expand(B, 2, 3)
+    got_i = A.transformer(U.to(dev), eye).cpu()
+    assert (got_i - M.stn_transformer(U, eye)).abs().max().item() < 1e-6
+    assert got_i[:, -1].abs().max().item() < 1e-6 and got_i[:, :, -1].abs().max().item() < 1e-6
+    # shared source (one border mask for all samples): n_u = 1, n_theta = B
+    if C == 1:
+        one = A.transformer(U[:1].to(dev), theta, n_samples=B).cpu()
+        assert (one - M.stn_transformer(U[:1].expand(B, H, W, 1), theta)).abs().max().item() < 1e-5
+
+
+def test_photometric_vs_oracle(dev):
+    from unflow_amd.core import augment as A
+    from oracle import model_ref as M
+    B, H, W = 4, 24, 40
+    g = torch.Generator().manual_seed(5)
+    im = torch.rand(B, H, W, 3, generator=g)
+    im[0, :2] = 0.0          # pow(0, 1/gamma) = 0
+    d = _draws(B, 6)
+    ref = M.random_photometric_apply([im], d['contrast'], d['gamma'], d['colour'], d['noise'], d['brightness'])[0]
+    got = A.photometric(im.to(dev), d)
+    assert (got.cpu() - ref).abs().max().item() < 2e-6
+    out4 = torch.full((B, H, W, 4), 7.0, device=dev)
+    A.photometric(im.to(dev), d, out=out4, mean=[104.920005, 110.1753, 114.785955])
+    mean = torch.tensor([104.920005, 110.1753, 114.785955]) / 255.0
+    assert (out4[..., :3].cpu() - (ref - mean)).abs().max().item() < 2e-6
+    assert out4[..., 3].abs().max().item() == 0.0
+
+
+def test_augmented_step_vs_oracle(dev):
+    """unsupervised_loss(augment=True) with replayed draws: loss, flows and gradients vs the oracle."""
+    from unflow_amd.core.engine import FlowNetCEngine
+    from oracle import model_ref as M
+    B, H, W = 2, 128, 128
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
+    tf_params = eng.init_params(seed=5)
+    g = torch.Generator().manual_seed(8)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.roll(im1, shifts=(2, -1), dims=(1, 2)) * 0.9 + torch.rand(B, H, W, 3, generator=g) * 20
+    from unflow_amd.core import augment as A
+    aug = A.draw_training_augmentation(B, torch.Generator().manual_seed(9))
+    P = {k: v.clone().double().requires_grad_() for k, v in tf_params.items()}
+    aug64 = {k: v.double() for k, v in aug.items()}
+    loss_ref, ffw, fbw, _ = M.unsupervised_loss(P, im1.double(), im2.double(), return_flow=True, augment=aug64)
+    loss_ref.backward()
+    eng.set_input(im1.to(dev), im2.to(dev), augment=aug)
+    eng.forward_net()
+    loss = eng.forward_loss(with_grad=True)
+    eng.backward_net()
+    torch.cuda.synchronize()
+    assert eng.lv[0]['n_mask'] == B
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    fw, bw = eng.final_flows()
+    assert (fw.cpu().double() - ffw).abs().max().item() < 1e-3
+    got = eng.export_tf_grads()
+    for k, v in P.items():
+        l2 = 0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0
+        # (fp32 resampling on the GPU vs fp64 in the oracle moves a few leaky-ReLU kinks: 1e-3 instead of 2e-4)
+        assert _rel(got[k], v.grad - l2) < 1e-3, k
+    # switching augmentation off again restores the static border-mask pyramid
+    eng.set_input(im1.to(dev), im2.to(dev))
+    assert eng.lv[0]['n_mask'] == 1

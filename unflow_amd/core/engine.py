@@ -406,24 +406,61 @@ class FlowNetEngine:
         sz = int(math.ceil(min(H, W) * 0.1))
         m = torch.zeros(1, H, W, 1, device=self.dev)
         m[:, sz:H - sz, sz:W - sz] = 1.0
+        self.border0, self._aug, self._mask_aug = m, None, False
         ones = torch.ones(1, H, W, 1, device=self.dev)
         use_border = bool(self.params.get('border_mask'))
         cur = ops.downsample(m, 4)
         cur1 = ops.downsample(ones, 4)
         for i, lv in enumerate(self.lv):
             lv['mask'] = (cur if use_border else cur1).reshape(1, lv['h'], lv['w']).contiguous()
+            lv['mask_static'], lv['n_mask'] = lv['mask'], 1
             if i + 1 < len(self.lv):
                 cur = ops.downsample(cur, 2)
                 cur1 = ops.downsample(cur1, 2)
 
     # ------------------------------------------------------------------ forward
-    def set_input(self, im1, im2):
-        """im1, im2: [B,H,W,3] float32 in [0,255] (what the reference's input queue delivers)."""
-        B = self.B
+    def set_input(self, im1, im2, augment=None):
+        """im1, im2: [B,H,W,3] float32 in [0,255] (what the reference's input queue delivers).
+        augment: None (augment=False) or the draws of core.augment.draw_training_augmentation — then the step sees
+        what unsupervised.py:37-68 builds: geometrically augmented images for the losses, photometrically augmented
+        mean-free ones for the network, and a per-sample border mask (product of the two warped masks)."""
+        B, N, H, W = self.B, self.N, self.H, self.W
+        lib = _lib.lib()
         self.raw[:B].copy_(im1)
         self.raw[B:].copy_(im2)
-        check(_lib.lib().unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(self.im01),
-                                               self.mean_host, cl(self.N * self.H * self.W), stream()), "prepare_images")
+        if augment is None:
+            check(lib.unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(self.im01),
+                                            self.mean_host, cl(N * H * W), stream()), "prepare_images")
+            if self._mask_aug:
+                for lv in self.lv:
+                    lv['mask'], lv['n_mask'] = lv['mask_static'], 1
+                self._mask_aug = False
+            return
+        from . import augment as A
+        if self._aug is None:
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
+            self._aug = dict(tmp=z(N, H, W, 3), mg=z(B, H, W, 1), ml=z(B, H, W, 1),
+                             masks=[z(B, lv['h'], lv['w'], 1) for lv in self.lv])
+        a = self._aug
+        check(lib.unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(a['tmp']), self.mean_host, cl(N * H * W),
+                                        stream()), "prepare_images")
+        tg, tl = augment['theta_global'], augment['theta_local']
+        A.transformer(a['tmp'], tg, out=self.im01, n_samples=N)            # im1_geo, first pass of im2 (:40-44)
+        A.transformer(self.im01[B:], tl, out=a['tmp'][B:], n_samples=B)    # im2 locally (:47-50)
+        self.im01[B:].copy_(a['tmp'][B:])
+        if self.params.get('border_mask'):
+            A.transformer(self.border0, tg, out=a['mg'], n_samples=B)
+            A.transformer(self.border0, tl, out=a['ml'], n_samples=B)
+            a['mg'].mul_(a['ml'])                                          # border_mask_local * global (:51)
+            from .. import ops
+            cur = ops.downsample(a['mg'], 4)
+            for i, lv in enumerate(self.lv):
+                a['masks'][i].copy_(cur)
+                lv['mask'], lv['n_mask'] = a['masks'][i].view(B, lv['h'], lv['w']), B
+                if i + 1 < len(self.lv):
+                    cur = ops.downsample(cur, 2)
+            self._mask_aug = True
+        A.photometric(self.im01, augment, out=self.x0, mean=CHANNEL_MEAN)  # im*_photo - channel_mean (:53-57,67-68)
 
     def forward_net(self):
         """flownet(im1, im2, spec, backward_flow=True) (flownet.py:14-81): every stage in order; a refinement stage
@@ -480,7 +517,7 @@ class FlowNetEngine:
                 gflow.zero_()
                 wrote[0] = True
             # ---- masks, fb / occ / sym
-            mask, n_mask = lv['mask'], 1
+            mask, n_mask = lv['mask'], lv['n_mask']
             if need_mask_terms:
                 self._level_extra(lv)
                 warped = fwm = None
@@ -495,7 +532,8 @@ class FlowNetEngine:
                     check(lib.unflow_forward_warp_fwd(ptr(lv['fscaled']), ptr(fwm), N, h, w, 1, ptr(ws),
                                                       _lib.csz(ws.numel() * 4), st), "forward_warp")
                 a = acc() if (with_grad and wt('fb')) else 0
-                check(lib.unflow_mask_terms(ptr(flow), ptr(warped), ptr(fwm), ptr(lv['mask'] if use_border else None), 1,
+                check(lib.unflow_mask_terms(ptr(flow), ptr(warped), ptr(fwm), ptr(lv['mask'] if use_border else None),
+                                            lv['n_mask'],
                                             cf(fs), occl, ptr(lv['maskN']), ptr(self.loss_acc),
                                             gf if wt('fb') else ptr(None), ptr(lv['gwarped']), a, cf(lw * wt('fb')),
                                             cf(lw * wt('occ')), cf(lw * wt('sym')), B, B, N, h, w, st), "mask_terms")

@@ -6,13 +6,12 @@ from .flownet import get_engine
 
 
 def unsupervised_loss(batch, params, normalization=None, augment=True, return_flow=False, engine=None,
-                      backward=False):
+                      backward=False, generator=None):
     """batch = (im1, im2), NHWC float32 in [0,255].  `normalization` is accepted for signature compatibility; the
-    channel means are the reference's (core/input.py:45).  augment=True (random affine + photometric,
-    unsupervised.py:39-60) is §8f "next" and not implemented.  With backward=True the parameter gradients are
-    left in engine.G (what opt.compute_gradients would return)."""
-    if augment:
-        raise NotImplementedError("augment=True is not implemented yet (SURVEY 8f rank 1)")
+    channel means are the reference's (core/input.py:45).  augment: True draws the random affine + photometric
+    augmentation of unsupervised.py:39-58 (host RNG `generator`), a dict replays given draws
+    (core.augment.draw_training_augmentation), False/None disables it.  With backward=True the parameter
+    gradients are left in engine.G (what opt.compute_gradients would return)."""
     if normalization is not None:
         mean = [float(v) for v in normalization[0]]
         if max(abs(a - b) for a, b in zip(mean, CHANNEL_MEAN)) > 1e-3:
@@ -20,7 +19,10 @@ def unsupervised_loss(batch, params, normalization=None, augment=True, return_fl
     im1, im2 = batch
     B, H, W, _ = im1.shape
     eng = engine or get_engine(B, H, W, params=params, device=im1.device)
-    eng.set_input(im1, im2)
+    if augment is True:
+        from .augment import draw_training_augmentation
+        augment = draw_training_augmentation(B, generator)
+    eng.set_input(im1, im2, augment=augment or None)
     eng.forward_net()
     loss = eng.forward_loss(with_grad=backward)
     if backward:
