@@ -210,8 +210,11 @@ def measure_roofline(eng, args):
         torch.cuda.synchronize()
         events.clear()
         for _ in range(reps):
+            # park the GPU behind a ~15 ms spin so the host has enqueued the whole step before the first kernel starts:
+            # the event pairs then bracket GPU execution only, not Python launch gaps (this loop is not graph-captured)
+            torch.cuda._sleep(int(3.5e7))
             eng.fwd_bwd()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in events) / reps
         launches = len(events) // reps
     finally:
@@ -221,8 +224,22 @@ def measure_roofline(eng, args):
     return {"bound": "mfma", "kernel": "igemm_gather_kernel + igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32 conv family, "
                                        "%d launches/step incl. split-K reduces)" % launches,
             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            **(_pmc_traffic() if (eng.B, eng.H, eng.W, eng.spec) == (4, 384, 512, 'C') else {"traffic": None}),
             "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
+
+
+def _pmc_traffic():
+    """HBM-side bytes of the conv family per step from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction, WRITE_SIZE; both calibrated to 1.00 on the Adam kernel in the same trace, tools/pmc_traffic.py).
+    PMC needs its own rocprofv3 runs, so this is read from profiles/, not collected inside bench.py."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return {"traffic": None}
+    d = json.load(open(files[-1]))
+    return {"traffic": d['conv_family']['total_bytes'], "traffic_unit": "bytes/step over the kernel class "
+            "(B=4 384x512 only)", "traffic_source": 'profiles/' + os.path.basename(files[-1])}
 
 
 def measure_cpu_baseline(H, W):
