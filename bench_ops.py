@@ -100,6 +100,19 @@ def main():
     gf = torch.empty_like(f)
     us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco), 441, ptr(f), ptr(f), 256, 4, ptr(gf), ptr(None), 256, 1, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
     report("correlation_nhwc_bwd 441ch N=8 (fused g0+g1)", 8 * 18.0e6, us, {"GFLOP_algorithmic": 11.1, "TFLOP/s": round(11.1e3 / us, 1)})
+    # the north star's +-4-displacement 81-channel cost volume (HBM-bound: AI = 17.5 FLOP/B), 1/8 resolution of 768x1024
+    N2, h2, w2 = 16, 96, 128
+    f2 = torch.randn(N2, h2, w2, 256, generator=g).to(dev)
+    co2 = torch.empty(N2, h2, w2, 84, device=dev)
+    nb = N2 * h2 * w2 * (2 * 256 + 81) * 4
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f2), ptr(f2), 256, N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+    gfl = 2 * 81 * 256 * N2 * h2 * w2 / 1e9
+    report("correlation_nhwc_fwd 81ch (md=4, stride_2=1) N=16 96x128", nb, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
+    gco2 = torch.randn(N2, h2, w2, 84, generator=g).to(dev)
+    gf2 = torch.empty_like(f2)
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco2), 84, ptr(f2), ptr(f2), 256, N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+    nbb = N2 * h2 * w2 * (81 + 2 * 256 + 256) * 4
+    report("correlation_nhwc_bwd 81ch N=16 96x128 (fused g0+g1)", nbb, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
 
 
 if __name__ == "__main__":

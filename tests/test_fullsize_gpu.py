@@ -1,0 +1,135 @@
+"""-m gpu: size-independent properties at BASELINE.json's full sizes (configs[1]: B=4, 384x512; warps at the
+768x1024 of configs[3]), where the CPU oracle is too slow to be the checker.
+
+  * ops: integer-flow backward_warp is an exact shift (bit-exact), forward_warp of zero flow has the analytic
+    interior value, downsample preserves constants and means, correlation of x with itself at zero displacement
+    is mean_c(x^2), correlation(a, b) and correlation(b, a) are mirror images of each other;
+  * step: gradients are bit-reproducible run to run (no float atomics on the parameter-gradient path), the
+    analytic gradient matches a central finite difference of the loss along a random direction, and the gradient of
+    a batch equals the mean of the gradients of its two halves (the data-parallel identity of SURVEY 8e at full size).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_backward_warp_integer_shift_exact_fullres(dev):
+    from unflow_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 768, 1024
+    im = torch.rand(B, H, W, 3, generator=g).to(dev)
+    fl = torch.zeros(B, H, W, 2, device=dev)
+    fl[..., 0], fl[..., 1] = 7.0, -5.0
+    out = ops.backward_warp(im, fl)
+    ref = torch.zeros_like(im)
+    ref[:, 5:, :W - 7] = im[:, :H - 5, 7:]                # out[y,x] = im[y-5, x+7], zero outside (zero padding)
+    assert torch.equal(out, ref)
+    xy = ops.backward_warp_indices(fl)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
+    assert torch.equal(xy[0, ..., 0], (xs + 7).int()) and torch.equal(xy[0, ..., 1], (ys - 5).int())
+
+
+def test_forward_warp_zero_flow_and_downsample_fullres(dev):
+    from unflow_amd import ops
+    B, H, W = 2, 768, 1024
+    fw = ops.forward_warp(torch.zeros(B, H, W, 2, device=dev))
+    interior = fw[:, 4:H - 4, 4:W - 4]
+    assert (interior - 6.283148).abs().max().item() < 2e-5      # sum_{|dx|,|dy|<=4} exp(-(dx^2+dy^2)/2)
+    g = torch.Generator().manual_seed(2)
+    im = torch.rand(B, H, W, 3, generator=g).to(dev)
+    for s in (2, 4):
+        d = ops.downsample(im, s)
+        assert tuple(d.shape) == (B, H // s, W // s, 3)
+        assert abs(d.double().mean().item() - im.double().mean().item()) < 1e-6      # box mean preserves the mean
+        ref = im.view(B, H // s, s, W // s, s, 3).double().mean((2, 4))
+        assert (d.double() - ref).abs().max().item() < 1e-6
+    c = ops.downsample(torch.full((1, H, W, 3), 0.3, device=dev), 4)
+    assert (c - 0.3).abs().max().item() < 1e-7
+
+
+def test_correlation_identities_full(dev):
+    from unflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 4, 256, 48, 64
+    a = torch.randn(B, C, H, W, generator=g).to(dev)
+    b = torch.randn(B, C, H, W, generator=g).to(dev)
+    attrs = dict(pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
+    caa = ops.correlation(a, a, **attrs)
+    centre = 10 * 21 + 10
+    ref = (a.double() ** 2).mean(1)
+    assert (caa[:, centre].double() - ref).abs().max().item() < 1e-4
+    cab = ops.correlation(a, b, **attrs)
+    cba = ops.correlation(b, a, **attrs)
+    # out_ab[p, o](y, x) = <a(y, x), b(y+2p, x+2o)> = out_ba[-p, -o](y+2p, x+2o)
+    for (p, o) in [(3, -4), (-10, 10), (0, 7), (-2, 0)]:
+        ch, chm = (p + 10) * 21 + (o + 10), (-p + 10) * 21 + (-o + 10)
+        y0, y1 = max(0, -2 * p), min(H, H - 2 * p)
+        x0, x1 = max(0, -2 * o), min(W, W - 2 * o)
+        lhs = cab[:, ch, y0:y1, x0:x1]
+        rhs = cba[:, chm, y0 + 2 * p:y1 + 2 * p, x0 + 2 * o:x1 + 2 * o]
+        assert (lhs - rhs).abs().max().item() < 2e-5
+    # linear in the first argument
+    c2 = ops.correlation(2.0 * a + b, b, **attrs)
+    assert (c2 - (2.0 * cab + ops.correlation(b, b, **attrs))).abs().max().item() < 2e-4
+
+
+def _images(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.roll(im1, shifts=(2, -3), dims=(1, 2)) * 0.9 + torch.rand(B, H, W, 3, generator=g) * 25
+    return im1, im2
+
+
+def test_step_reproducible_and_finite_difference_full(dev):
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 4, 384, 512
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=11)
+    im1, im2 = _images(B, H, W, 12)
+    im1, im2 = im1.to(dev), im2.to(dev)
+    l0 = eng.fwd_bwd(im1, im2).item()
+    g0 = eng.G.clone()
+    l1 = eng.fwd_bwd(im1, im2).item()
+    assert torch.equal(eng.G, g0)                      # parameter gradients: bit-identical run to run
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)              # the loss scalar is a float-atomic sum of block partials
+    assert torch.isfinite(g0).all()
+    # directional derivative of the DATA loss (the engine's G excludes the L2 term, which adam_step adds)
+    gen = torch.Generator().manual_seed(13)
+    d = torch.randn(eng.n_params, generator=gen).to(dev)
+    d[eng.n_weights:] = 0                               # move weights only (biases start at zero -> kinks)
+    d *= eng.P.abs().mean() / d.abs().mean()           # same scale as the weights
+    P0 = eng.P.clone()
+    l2 = lambda: 0.0004 * 0.5 * (eng.P[:eng.n_weights].double() ** 2).sum().item()
+    eps = 2e-3
+    vals = []
+    for sgn in (+1, -1):
+        eng.P.copy_(P0 + sgn * eps * d)
+        eng.set_input(im1, im2)
+        eng.forward_net()
+        vals.append(eng.forward_loss(with_grad=False).item() - l2())
+    eng.P.copy_(P0)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = (g0.double() * d.double()).sum().item()
+    assert abs(fd - an) <= 0.03 * abs(an) + 1e-3, (fd, an)
+
+
+def test_batch_halves_average_to_full_batch_gradient(dev):
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 4, 384, 512
+    im1, im2 = _images(B, H, W, 21)
+    full = FlowNetCEngine(B, H, W, device=dev, seed=22)
+    lf = full.fwd_bwd(im1.to(dev), im2.to(dev)).item()
+    gf = full.G.clone()
+    half = FlowNetCEngine(B // 2, H, W, device=dev, seed=None)
+    half.P.copy_(full.P)
+    acc = torch.zeros_like(gf)
+    ls = []
+    for s in (slice(0, 2), slice(2, 4)):
+        ls.append(half.fwd_bwd(im1[s].to(dev), im2[s].to(dev)).item())
+        acc += half.G
+    acc *= 0.5
+    reg = 0.0004 * 0.5 * (full.P[:full.n_weights].double() ** 2).sum().item()
+    assert abs((lf - reg) - (sum(ls) / 2 - reg)) <= 2e-5 * abs(lf)
+    scale = gf.abs().max().item()
+    assert (acc - gf).abs().max().item() <= 2e-4 * scale
