@@ -180,49 +180,59 @@ def main():
 
 
 def measure_roofline(eng, args):
-    """Dominant kernel class = the fp32-MFMA implicit-GEMM conv family (igemm_gather_kernel /
-    igemm_wgrad_kernel): algorithmic FLOPs of those launches / their summed duration, the duration
-    measured with HIP events recorded on the launch stream around every conv-family call of a step."""
+    """Dominant kernel class = the conv / conv_transpose layers (fp32-MFMA implicit GEMM igemm_gather_kernel /
+    igemm_wgrad_kernel + their split-K reduces + the Cout=2 flow-head kernels): algorithmic FLOPs of those layers per
+    step / the GPU time of exactly those launches.  The launches of one step are recorded, captured alone into a
+    hipGraph (so the measurement has the same back-to-back dispatch as the benchmarked step, no Python launch gaps)
+    and its replay is timed live with HIP events on the replay stream."""
     import torch
     from unflow_amd.core import layers as L
     gflop, _ = conv_family_gflop(eng)
     names = ["conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_filter", "conv2d_transpose_fwd",
              "conv2d_transpose_bwd_data", "conv2d_transpose_bwd_filter"]
     orig = {n: getattr(L, n) for n in names}
-    events = []
+    calls = []
 
     def wrap(fn):
         def inner(*a, **k):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()            # current stream == the stream the kernels are launched on (_lib.stream())
-            r = fn(*a, **k)
-            e1.record()
-            events.append((e0, e1))
-            return r
+            calls.append((fn, a, k))
+            return fn(*a, **k)
         return inner
 
-    reps = 3
     try:
         for n in names:
             setattr(L, n, wrap(orig[n]))
-        eng.fwd_bwd()              # warm
+        eng.fwd_bwd()              # records the conv-family calls of one step
         torch.cuda.synchronize()
-        events.clear()
-        for _ in range(reps):
-            # park the GPU behind a ~15 ms spin so the host has enqueued the whole step before the first kernel starts:
-            # the event pairs then bracket GPU execution only, not Python launch gaps (this loop is not graph-captured)
-            torch.cuda._sleep(int(3.5e7))
-            eng.fwd_bwd()
-            torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in events) / reps
-        launches = len(events) // reps
     finally:
         for n in names:
             setattr(L, n, orig[n])
+    launches = len(calls)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for f, a, k in calls:      # warm on the capture stream
+            f(*a, **k)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for f, a, k in calls:
+                f(*a, **k)
+        graph.replay()
+        torch.cuda.synchronize()
+        reps = 5
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+    torch.cuda.current_stream().wait_stream(side)
     achieved = gflop / ms            # GFLOP / ms == TFLOP/s
-    return {"bound": "mfma", "kernel": "igemm_gather_kernel + igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32 conv family, "
-                                       "%d launches/step incl. split-K reduces)" % launches,
+    return {"bound": "mfma", "kernel": "igemm_gather_kernel + igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM) incl. "
+                                       "their split-K reduces and the Cout=2 flow-head kernels: %d layer launches/step" % launches,
             "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             **(_pmc_traffic() if (eng.B, eng.H, eng.W, eng.spec) == (4, 384, 512, 'C') else {"traffic": None}),

@@ -660,6 +660,271 @@ __global__ __launch_bounds__(64) void skinny_conv_wgrad3_kernel(const SkinnyWgra
   }
 }
 
+// ------------------------------------------------------------------ strip kernels for the large flow heads
+// k = 3, stride 1, Cout = 2 (flow2 / flow3 at 384x512: >= 24k pixels).  The per-pixel kernels above re-read the 14-28 KB
+// filter from L1 for EVERY pixel (L1-bandwidth bound: 21 KB per output pixel through a 64 B/clk port).  Here a lane owns
+// one channel quad and keeps its 9 x 4 x 2 filter values in registers while the wave walks a strip of S pixels of one
+// image row, so the filter is read once per strip and every input quad once per (row, strip).
+// Explicit fmaf here (the file is built with -ffp-contract=off): these kernels are VALU-bound, the fused form halves
+// the instruction count and is the more accurate of the two roundings.
+constexpr int SK_S = 8;   // pixels per strip (W % SK_S == 0 is a dispatch condition)
+
+__device__ __forceinline__ void load_head_weights(const float* __restrict__ w, int Cin, int c4, bool active,
+                                                  float (&wr)[9][8]) {
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (active) {
+      const float* wp = w + ((size_t)t * Cin + c4 * 4) * 2;   // [tap][ci][co], 8 contiguous floats for the quad
+      a = ldg4(wp);
+      b = ldg4(wp + 4);
+    }
+    wr[t][0] = a.x; wr[t][1] = a.y; wr[t][2] = a.z; wr[t][3] = a.w;
+    wr[t][4] = b.x; wr[t][5] = b.y; wr[t][6] = b.z; wr[t][7] = b.w;
+  }
+}
+
+// y[b, yy, x0+o, co] = bias + sum_{ky,kx,c} x[b, yy-1+ky, x0+o-1+kx, c] * w[ky,kx,c,co]
+__global__ __launch_bounds__(256) void head3_fwd_strip_kernel(const SkinnyParams p) {
+  const int lane = threadIdx.x & 63;
+  const int strips = p.W / SK_S;
+  const long njobs = (long)p.B * p.H * strips;
+  const long job = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
+  if (job >= njobs) return;
+  const int xs = (int)(job % strips);
+  const long row = job / strips;
+  const int yy = (int)(row % p.H);
+  const long b = row / p.H;
+  const int x0 = xs * SK_S;
+  const int Cq = p.Cin >> 2;
+  float acc[2 * SK_S];   // [o][co]
+#pragma unroll
+  for (int o = 0; o < 2 * SK_S; o++) acc[o] = 0.f;
+  for (int g0 = 0; g0 < Cq; g0 += 64) {
+    const bool active = g0 + lane < Cq;
+    const int c4 = min(g0 + lane, Cq - 1);          // clamped: every load below is unconditional and in range
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int iy = yy - 1 + ky;
+      if ((unsigned)iy >= (unsigned)p.H) continue;   // wave-uniform
+      float wr[3][8];                                // this filter row only: 24 registers instead of 72
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const float* wp = p.w + ((size_t)(ky * 3 + kx) * p.Cin + c4 * 4) * 2;
+        const float4 wa = ldg4(wp), wb = ldg4(wp + 4);
+        wr[kx][0] = wa.x; wr[kx][1] = wa.y; wr[kx][2] = wa.z; wr[kx][3] = wa.w;
+        wr[kx][4] = wb.x; wr[kx][5] = wb.y; wr[kx][6] = wb.z; wr[kx][7] = wb.w;
+      }
+      const float* xrow = p.x + ((b * p.H + iy) * p.W) * p.ldx + c4 * 4;
+      float4 xv[SK_S + 2];
+#pragma unroll
+      for (int i = 0; i < SK_S + 2; i++) {
+        const int ix = x0 - 1 + i;
+        const float4 t = ldg4(xrow + (long)min(max(ix, 0), p.W - 1) * p.ldx);
+        const bool ok = active && (unsigned)ix < (unsigned)p.W;
+        xv[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      }
+#pragma unroll
+      for (int o = 0; o < SK_S; o++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const float4 v = xv[o + kx];
+          const float* q = wr[kx];
+          acc[2 * o] = fmaf(v.x, q[0], acc[2 * o]); acc[2 * o + 1] = fmaf(v.x, q[1], acc[2 * o + 1]);
+          acc[2 * o] = fmaf(v.y, q[2], acc[2 * o]); acc[2 * o + 1] = fmaf(v.y, q[3], acc[2 * o + 1]);
+          acc[2 * o] = fmaf(v.z, q[4], acc[2 * o]); acc[2 * o + 1] = fmaf(v.z, q[5], acc[2 * o + 1]);
+          acc[2 * o] = fmaf(v.w, q[6], acc[2 * o]); acc[2 * o + 1] = fmaf(v.w, q[7], acc[2 * o + 1]);
+        }
+    }
+  }
+  // 16 wave sums as one halving butterfly (8+4+2+1 exchanges + 2 plain steps = 17 shuffles instead of 96): after the
+  // xor-32 step a lane keeps half of the values, ... after xor-4 exactly one: value id = lane bits 5..2.
+  float v8[8], v4[4], v2[2], v1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const bool hi = lane & 32;
+    const float keep = hi ? acc[8 + i] : acc[i], send = hi ? acc[i] : acc[8 + i];
+    v8[i] = keep + __shfl_xor(send, 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool hi = lane & 16;
+    const float keep = hi ? v8[4 + i] : v8[i], send = hi ? v8[i] : v8[4 + i];
+    v4[i] = keep + __shfl_xor(send, 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const bool hi = lane & 8;
+    const float keep = hi ? v4[2 + i] : v4[i], send = hi ? v4[i] : v4[2 + i];
+    v2[i] = keep + __shfl_xor(send, 8);
+  }
+  {
+    const bool hi = lane & 4;
+    const float keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
+    v1 = keep + __shfl_xor(send, 4);
+  }
+  v1 += __shfl_xor(v1, 2);
+  v1 += __shfl_xor(v1, 1);
+  if ((lane & 3) == 0) {
+    // id bits: lane bit5 -> 8, bit4 -> 4, bit3 -> 2, bit2 -> 1
+    const int id = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int o = id >> 1, co = id & 1;
+    p.y[((b * p.H + yy) * p.W + x0 + o) * p.ldy + co] = v1 + (p.bias ? p.bias[co] : 0.f);
+  }
+}
+
+// One row of the wave-uniform dz window (columns x0-1 .. x0+S, 2 channels = 2*(S+2) floats, zero outside the image):
+// lane l < 2*(S+2) loads element l in ONE coalesced instruction; consumers broadcast with v_readlane (an SGPR operand).
+__device__ __forceinline__ float load_dz_window_row(const float* __restrict__ dz, int lddz, long b, int oy, int x0, int H,
+                                                    int W, int lane) {
+  const int col = lane >> 1, co = lane & 1;
+  const int ox = x0 - 1 + col;
+  const bool ok = lane < 2 * (SK_S + 2) && (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+  const float v = dz[((b * H + (ok ? oy : 0)) * W + (ok ? ox : 0)) * lddz + co];
+  return ok ? v : 0.f;
+}
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+// dx[b, yy, x0+o, ci] (+)= sum_{ky,kx,co} dz[b, yy+1-ky, x0+o+1-kx, co] * w[ky,kx,ci,co]; wave = (row, strip, quad group);
+// the dz window of the strip is wave-uniform (scalar loads), lanes differ only in the channel quad.
+__global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdParams p) {
+  const int lane = threadIdx.x & 63;
+  const int strips = p.W / SK_S;
+  const int Cq = p.Cin >> 2, groups = (Cq + 63) / 64;
+  const long njobs = (long)p.B * p.H * strips * groups;
+  const long job = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
+  if (job >= njobs) return;
+  const int g = (int)(job % groups);
+  const long j2 = job / groups;
+  const int xs = (int)(j2 % strips);
+  const long row = j2 / strips;
+  const int yy = (int)(row % p.H);
+  const long b = row / p.H;
+  const int x0 = xs * SK_S;
+  const int c4 = g * 64 + lane;
+  const bool active = c4 < Cq;
+  float wr[9][8];
+  load_head_weights(p.w, p.Cin, c4, active, wr);
+  // dz window: rows yy-1..yy+1, columns x0-1..x0+S, 2 channels; zero outside the image
+  float dzv[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) dzv[r] = load_dz_window_row(p.dz, p.lddz, b, yy - 1 + r, x0, p.H, p.W, lane);
+  float dzw[3][SK_S + 2][2];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int i = 0; i < SK_S + 2; i++) {
+      dzw[r][i][0] = lane_bcast(dzv[r], 2 * i);
+      dzw[r][i][1] = lane_bcast(dzv[r], 2 * i + 1);
+    }
+  if (!active) return;
+#pragma unroll
+  for (int o = 0; o < SK_S; o++) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        // oy = yy + 1 - ky -> window row 2 - ky;  ox = x0 + o + 1 - kx -> window column o + 2 - kx
+        const float g0 = dzw[2 - ky][o + 2 - kx][0], g1 = dzw[2 - ky][o + 2 - kx][1];
+        const float* q = wr[ky * 3 + kx];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a[j] = fmaf(g0, q[2 * j], a[j]); a[j] = fmaf(g1, q[2 * j + 1], a[j]); }
+      }
+    const long pxl = (b * p.H + yy) * p.W + x0 + o;
+    float* d = p.dx + pxl * p.lddx + c4 * 4;
+    float4 v = make_float4(a[0], a[1], a[2], a[3]);
+    if (p.accumulate) {
+      const float4 e = ldg4(d);
+      v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    if (p.act_src) {
+      const int n = c4 * 4;
+      if (n + 3 >= p.act_lo && n < p.act_hi) {
+        const float4 s = ldg4(p.act_src + pxl * p.ld_act + n);
+        if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(s.x);
+        if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(s.y);
+        if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(s.z);
+        if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(s.w);
+      }
+    }
+    *reinterpret_cast<float4*>(d) = v;
+  }
+}
+
+// dw[ky,kx,ci,co] partials = sum over a chunk of strips of x[b,iy,ix,ci] * dz[b, iy+1-ky, ix+1-kx, co].
+// block = 4 waves x the same 64 channel quads; each wave walks its own strips, then the four register tiles are
+// summed through LDS in a fixed order (deterministic) and the block writes ONE partial.
+__global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgradParams p, int strips_per_wave) {
+  __shared__ float red[72 * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Cq = p.Cin >> 2;
+  const int c4 = blockIdx.x * 64 + lane;
+  const bool active = c4 < Cq;
+  const int cc = min(c4, Cq - 1);   // clamped: loads are unconditional, inactive lanes contribute zeros
+  const int strips = p.W / SK_S;
+  const long nstrips = (long)p.B * p.H * strips;
+  const long s0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.y * 4 + wv) * strips_per_wave));
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[t][j] = 0.f;
+  for (long sidx = s0; sidx < min(nstrips, s0 + strips_per_wave); sidx++) {
+    const int xs = (int)(sidx % strips);
+    const long row = sidx / strips;
+    const int iy = (int)(row % p.H);
+    const long b = row / p.H;
+    const int x0 = xs * SK_S;
+    float4 xv[SK_S];
+    const float* xrow = p.x + ((b * p.H + iy) * p.W + x0) * p.ldx + cc * 4;
+#pragma unroll
+    for (int i = 0; i < SK_S; i++) {
+      const float4 t = ldg4(xrow + (long)i * p.ldx);
+      xv[i] = make_float4(active ? t.x : 0.f, active ? t.y : 0.f, active ? t.z : 0.f, active ? t.w : 0.f);
+    }
+    float dzv[3];   // window rows iy+1, iy, iy-1 for ky = 0, 1, 2
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) dzv[ky] = load_dz_window_row(p.dz, p.lddz, b, iy + 1 - ky, x0, p.H, p.W, lane);
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+        for (int i = 0; i < SK_S; i++) {
+          // ox = x0 + i + 1 - kx -> window column i + 2 - kx
+          const float g0 = lane_bcast(dzv[ky], 2 * (i + 2 - kx)), g1 = lane_bcast(dzv[ky], 2 * (i + 2 - kx) + 1);
+          float* a = acc[ky * 3 + kx];
+          a[0] = fmaf(xv[i].x, g0, a[0]); a[1] = fmaf(xv[i].x, g1, a[1]);
+          a[2] = fmaf(xv[i].y, g0, a[2]); a[3] = fmaf(xv[i].y, g1, a[3]);
+          a[4] = fmaf(xv[i].z, g0, a[4]); a[5] = fmaf(xv[i].z, g1, a[5]);
+          a[6] = fmaf(xv[i].w, g0, a[6]); a[7] = fmaf(xv[i].w, g1, a[7]);
+        }
+  }
+  // fixed-order cross-wave sum: wave 0 stores, waves 1..3 add in turn
+  for (int turn = 0; turn < 4; turn++) {
+    if (wv == turn) {
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          float* r = red + (t * 8 + j) * 64 + lane;
+          *r = (turn == 0 ? 0.f : *r) + acc[t][j];
+        }
+    }
+    __syncthreads();
+  }
+  // partial layout [chunk][tap][Cin][2]: the quad's 8 values per tap are contiguous
+  float* o = p.partial + (size_t)blockIdx.y * 9 * p.Cin * 2;
+  for (int e = threadIdx.x; e < 72 * 64; e += 256) {
+    const int ln = e & 63, tj = e >> 6, t = tj >> 3, j = tj & 7;
+    const int cq = blockIdx.x * 64 + ln;
+    if (cq < Cq) o[((size_t)t * p.Cin + cq * 4) * 2 + j] = red[e];
+  }
+}
+
 // ------------------------------------------------------------------ tiny deconv (flowN_upM: 2 -> 2 channels, k4 s2)
 // y[b,oy,ox,co] = bias + sum over the <=4 valid taps: oy = 2*iy + ky - 1.
 template <int CI, int CO>
@@ -1034,6 +1299,21 @@ inline int skinny_wgrad_chunks(long npix, int Cin) {
   return (int)min(c, (long)1024);
 }
 
+// the strip kernels take over when the level is big enough to fill the chip with (row, strip) waves
+inline bool head_strip_ok(int B, int H, int W, int k, int Cout) {
+  return k == 3 && Cout == 2 && W % SK_S == 0 && (long)B * H * W >= 16384;
+}
+// blocks (= partials) of head3_wgrad_strip_kernel per channel-quad group: >= 4 strips per wave, <= 1024 blocks
+inline int head_wgrad_blocks(int B, int H, int W, int Cin, int* strips_per_wave) {
+  const long nstrips = (long)B * H * (W / SK_S);
+  const long colblocks = (Cin / 4 + 63) / 64;
+  long blocks = min((long)1024, max((long)1, 1024 / colblocks));
+  long spw = max((long)4, (nstrips + blocks * 4 - 1) / (blocks * 4));
+  blocks = (nstrips + spw * 4 - 1) / (spw * 4);
+  *strips_per_wave = (int)spw;
+  return (int)blocks;
+}
+
 constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)REDUCE_FAN * C * sizeof(float) + 512; }
 
 // ---- launchers
@@ -1198,6 +1478,11 @@ UNFLOW_API int unflow_conv2d_fwd(const float* x, int ldx, const float* w, const 
     same_pads(H, k, 1, &pt, &Ho);
     same_pads(W, k, 1, &pl, &Wo);
     SkinnyParams p{x, ldx, w, bias, y, ldy, B, H, W, Cin, k, pt, pl};
+    if (head_strip_ok(B, H, W, k, Cout)) {
+      const long jobs = (long)B * H * (W / SK_S);
+      head3_fwd_strip_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+      return launch_status();
+    }
     const long waves = (long)B * H * W;
     const int grid = (int)min((long)4096, (waves + 3) / 4);
     if (Cout == 2) skinny_conv_fwd_kernel<2><<<grid, 256, 0, st>>>(p);
@@ -1228,6 +1513,11 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
     same_pads(H, k, 1, &pt, &Ho);
     same_pads(W, k, 1, &pl, &Wo);
     SkinnyBwdParams p{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, k, pt, pl};
+    if (head_strip_ok(B, H, W, k, Cout) && lddx % 4 == 0 && (!act_src || ld_act % 4 == 0)) {
+      const long jobs = (long)B * H * (W / SK_S) * cdiv(Cin / 4, 64);
+      head3_dgrad_strip_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+      return launch_status();
+    }
     const long total = (long)B * H * W * (Cin / 4);
     if (Cout == 2) skinny_conv_dgrad_kernel<2><<<stream_grid(total), 256, 0, st>>>(p);
     else if (Cout == 1) skinny_conv_dgrad_kernel<1><<<stream_grid(total), 256, 0, st>>>(p);
@@ -1260,12 +1550,15 @@ UNFLOW_API int unflow_conv2d_bwd_filter(const float* x, int ldx, const float* dz
     if (stride != 1 || k != 3 || Cout != 2) return UNFLOW_ERR_UNSUPPORTED;
     const long npix = (long)B * H * W;
     const size_t wsz = (size_t)9 * Cin * Cout;
-    const int chunks = skinny_wgrad_chunks(npix, Cin);
+    const bool strip = head_strip_ok(B, H, W, k, Cout);
+    int spw = 1;
+    const int chunks = strip ? head_wgrad_blocks(B, H, W, Cin, &spw) : skinny_wgrad_chunks(npix, Cin);
     used = (size_t)chunks * wsz * sizeof(float) + reduce_scratch_bytes(wsz, chunks);
     if (!workspace || workspace_bytes < used) return UNFLOW_ERR_WORKSPACE;
     SkinnyWgradParams p{x, ldx, dz, lddz, reinterpret_cast<float*>(workspace), B, H, W, Cin, pt, pl};
     dim3 grid(cdiv(Cin / 4, 64), chunks);
-    skinny_conv_wgrad3_kernel<2><<<grid, 64, 0, st>>>(p);
+    if (strip) head3_wgrad_strip_kernel<<<grid, 256, 0, st>>>(p, spw);
+    else skinny_conv_wgrad3_kernel<2><<<grid, 64, 0, st>>>(p);
     const int rc = reduce_partials(p.partial, p.partial + (size_t)chunks * wsz, dw, wsz, chunks, st);
     if (rc != UNFLOW_OK) return rc;
   } else {
