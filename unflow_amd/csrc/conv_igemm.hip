@@ -20,6 +20,7 @@
 // Deep layers (M = 384..6144 sites) use split-K so the launch covers the 256 CUs; partials go to a
 // caller workspace and a fixed-order reduce applies the epilogue (deterministic, no float atomics).
 #include <stdlib.h>
+#include <cstdint>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     }
 }
 
-// Fixed-order sum of the split-K partials + the epilogue.
-__global__ void splitk_reduce_epilogue_kernel(const GatherParams p) {
+// Scalar fallback of the kernel below for destinations whose rows are not 16-byte aligned.
+__global__ void splitk_reduce_epilogue_scalar_kernel(const GatherParams p) {
   const size_t npix = (size_t)p.B * p.Hd * p.Wd;
   const size_t total = npix * p.N;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -329,6 +330,44 @@ __global__ void splitk_reduce_epilogue_kernel(const GatherParams p) {
     float* d = p.dst + px * p.ldd + n;
     if (p.accumulate) v += *d;
     if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[px * p.ld_act + n]);
+    *d = v;
+  }
+}
+
+// Fixed-order sum of the split-K partials + the epilogue.  One float4 (4 consecutive output channels) per thread; the
+// split loop is unrolled so its loads are in flight together (the kernel is a pure HBM/L2 stream).
+__global__ void splitk_reduce_epilogue_kernel(const GatherParams p) {
+  const size_t npix = (size_t)p.B * p.Hd * p.Wd;
+  const size_t total = npix * p.N;
+  const unsigned nq = (unsigned)(p.N >> 2);
+  const size_t totq = total >> 2;          // N % 4 == 0 (checked by the launchers)
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < totq; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = q / nq;
+    const int n = (int)(q - px * nq) * 4;
+    const float4* src = reinterpret_cast<const float4*>(p.partial) + q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int s = 0; s < p.nsplit; s++) {
+      const float4 t = src[(size_t)s * totq];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
+    float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
+    if (p.accumulate) {
+      const float4 e = *d;
+      v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
+      const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
+      if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
+      if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
+      if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
+      if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
+    }
     *d = v;
   }
 }
@@ -488,8 +527,27 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, float* __
     const size_t g = t / n, e = t - g * n;
     const int k1 = min(S, (int)(g + 1) * fan);
     float v = 0.f;
+#pragma unroll 8
     for (int k = (int)g * fan; k < k1; k++) v += partial[(size_t)k * n + e];
     out[g * n + e] = v;
+  }
+}
+
+// float4 variant (n % 4 == 0): same fixed order per element, a quarter of the threads, 8 loads in flight.
+__global__ void sum_partials4_kernel(const float4* __restrict__ partial, float4* __restrict__ out, size_t nq, int S,
+                                     int fan) {
+  const int G = (S + fan - 1) / fan;
+  const size_t total = nq * (size_t)G;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = t / nq, e = t - g * nq;
+    const int k1 = min(S, (int)(g + 1) * fan);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = (int)g * fan; k < k1; k++) {
+      const float4 a = partial[(size_t)k * nq + e];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    out[g * nq + e] = v;
   }
 }
 
@@ -1030,15 +1088,40 @@ __global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __r
     }
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  static_assert(NV == 64, "the transpose-reduce below maps value index == lane");
+  // 64 wave sums as ONE halving butterfly (63 independent-per-level exchanges instead of 64 x 6 dependent ones, which
+  // made this kernel ~20 us whatever the image size): afterwards lane l holds the wave total of value l.
+  float v32[32], v16[16], v8[8], v4[4], v2[2];
+  {
+    const float* f = &acc[0][0][0];
+    const bool hi = lane & 32;
 #pragma unroll
-  for (int t = 0; t < 16; t++)
+    for (int i = 0; i < 32; i++) v32[i] = (hi ? f[32 + i] : f[i]) + __shfl_xor(hi ? f[i] : f[32 + i], 32);
+  }
+  {
+    const bool hi = lane & 16;
 #pragma unroll
-    for (int a = 0; a < CO; a++)
+    for (int i = 0; i < 16; i++) v16[i] = (hi ? v32[16 + i] : v32[i]) + __shfl_xor(hi ? v32[i] : v32[16 + i], 16);
+  }
+  {
+    const bool hi = lane & 8;
 #pragma unroll
-      for (int c = 0; c < CI; c++) {
-        const float s = wave_sum(acc[t][a][c]);
-        if (lane == 0) red[wid][(t * CO + a) * CI + c] = s;
-      }
+    for (int i = 0; i < 8; i++) v8[i] = (hi ? v16[8 + i] : v16[i]) + __shfl_xor(hi ? v16[i] : v16[8 + i], 8);
+  }
+  {
+    const bool hi = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v4[i] = (hi ? v8[4 + i] : v8[i]) + __shfl_xor(hi ? v8[i] : v8[4 + i], 4);
+  }
+  {
+    const bool hi = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) v2[i] = (hi ? v4[2 + i] : v4[i]) + __shfl_xor(hi ? v4[i] : v4[2 + i], 2);
+  }
+  {
+    const bool hi = lane & 1;
+    red[wid][lane] = (hi ? v2[1] : v2[0]) + __shfl_xor(hi ? v2[0] : v2[1], 1);
+  }
   __syncthreads();
   if (threadIdx.x < NV)
     partial[(size_t)blockIdx.x * NV + threadIdx.x] =
@@ -1318,16 +1401,25 @@ constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)REDUCE_FAN * C * s
 
 // ---- launchers
 // out[e] = sum_s partial[s][e]; `scratch` (reduce_scratch_bytes) is used when S > REDUCE_FAN.
+inline void launch_sum_partials(const float* partial, float* out, size_t n, int S, int G, hipStream_t st) {
+  const bool vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec)
+    sum_partials4_kernel<<<stream_grid((long)(n / 4 * G)), 256, 0, st>>>(reinterpret_cast<const float4*>(partial),
+                                                                        reinterpret_cast<float4*>(out), n / 4, S, REDUCE_FAN);
+  else
+    sum_partials_kernel<<<stream_grid((long)(n * G)), 256, 0, st>>>(partial, out, n, S, REDUCE_FAN);
+}
+
 inline int reduce_partials(const float* partial, float* scratch, float* out, size_t n, int S, hipStream_t st) {
   while (S > REDUCE_FAN) {
     const int G = (S + REDUCE_FAN - 1) / REDUCE_FAN;
-    sum_partials_kernel<<<stream_grid((long)(n * G)), 256, 0, st>>>(partial, scratch, n, S, REDUCE_FAN);
+    launch_sum_partials(partial, scratch, n, S, G, st);
     // next level reads `scratch`; its output must not alias: levels alternate between scratch halves
     partial = scratch;
     scratch = scratch + (size_t)G * n;
     S = G;
   }
-  sum_partials_kernel<<<stream_grid((long)n), 256, 0, st>>>(partial, out, n, S, REDUCE_FAN);
+  launch_sum_partials(partial, out, n, S, 1, st);
   return launch_status();
 }
 
@@ -1369,7 +1461,11 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1) {
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
-    splitk_reduce_epilogue_kernel<<<stream_grid((long)total), 256, 0, st>>>(p);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
+                         reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.act_src);
+    const bool vec = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0;
+    if (vec) splitk_reduce_epilogue_kernel<<<stream_grid((long)(total / 4)), 256, 0, st>>>(p);
+    else splitk_reduce_epilogue_scalar_kernel<<<stream_grid((long)total), 256, 0, st>>>(p);
     return launch_status();
   }
   return UNFLOW_OK;
@@ -1621,7 +1717,7 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const
   hipStream_t st = as_stream(stream);
   size_t used = 0;
   if (Cin == 2 && Cout == 2) {
-    const int blocks = (int)min((long)128, ((long)B * H * W + 255) / 256);
+    const int blocks = (int)min((long)32, ((long)B * H * W + 255) / 256);   // <= 32 partials: the 1-block final sum stays short
     if (!workspace || workspace_bytes < (size_t)blocks * 64 * sizeof(float)) return UNFLOW_ERR_WORKSPACE;
     float* part = reinterpret_cast<float*>(workspace);
     tiny_deconv_wgrad_kernel<2, 2><<<blocks, 256, 0, st>>>(x, ldx, dz, lddz, part, B, H, W);
