@@ -82,6 +82,7 @@ def main():
 
     B, H, W = args.batch, args.height, args.width
     eng = FlowNetCEngine(B, H, W, device=dev, seed=0)            # same weights on every rank
+    eng.defer_l2 = True      # the L2 term of the loss is accumulated by the Adam kernel's pass over the parameters
     g = torch.Generator().manual_seed(1234 + rank)               # distinct shard per rank
     im1 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
     im2 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)

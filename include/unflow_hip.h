@@ -297,6 +297,13 @@ int unflow_resize_bilinear_tf1(const float* in, float* out, int B, int H, int W,
 int unflow_adam_step(float* p, const float* grad, float* m, float* v, long n, long n_regularized, float grad_scale,
                      float l2_scale, float lr_t, float beta1, float beta2, float eps, unflow_stream_t stream);
 
+/* Same update, and additionally loss_acc[0] += l2_scale * 0.5 * sum(p[0:n_regularized]^2) of the PRE-update
+ * parameters: the regularisation term of this step's loss (unsupervised.py:149) rides on the pass Adam makes over
+ * the parameters anyway, instead of a separate unflow_l2_loss launch. */
+int unflow_adam_step_regloss(float* p, const float* grad, float* m, float* v, long n, long n_regularized,
+                             float grad_scale, float l2_scale, float lr_t, float beta1, float beta2, float eps,
+                             float* loss_acc, unflow_stream_t stream);
+
 /* loss_acc[0] += scale * 0.5 * sum(p[0:n]^2)  (tf.nn.l2_loss via slim.l2_regularizer). */
 int unflow_l2_loss(const float* p, long n, float scale, float* loss_acc, unflow_stream_t stream);
 

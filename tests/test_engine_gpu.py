@@ -316,3 +316,25 @@ def test_augmented_step_vs_oracle(dev):
     # switching augmentation off again restores the static border-mask pyramid
     eng.set_input(im1.to(dev), im2.to(dev))
     assert eng.lv[0]['n_mask'] == 1
+
+
+def test_train_step_defers_l2_into_adam(dev):
+    """train_step lets the Adam kernel accumulate the 0.0004*sum(w^2)/2 term (unflow_adam_step_regloss): same loss and
+    bit-identical parameters as forward_loss's own unflow_l2_loss followed by unflow_adam_step."""
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 1, 128, 128
+    g = torch.Generator().manual_seed(31)
+    im1 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
+    im2 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
+    a = FlowNetCEngine(B, H, W, device=dev, seed=7)
+    b = FlowNetCEngine(B, H, W, device=dev, seed=7)
+    for _ in range(2):
+        la = a.fwd_bwd(im1, im2).item()
+        a.adam_step(1e-4)
+        lb_t = b.train_step(im1, im2, 1e-4)
+        torch.cuda.synchronize()
+        lb = lb_t.item()
+        # thousands of per-block partials are atomically added into one fp32 scalar of magnitude ~700 (ulp 6e-5)
+        assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+        assert torch.equal(a.P, b.P) and torch.equal(a.M, b.M) and torch.equal(a.V, b.V)
+    assert b.defer_l2 is False

@@ -308,6 +308,7 @@ class FlowNetEngine:
         self._build_masks()
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
+        self.defer_l2 = False      # True: forward_loss leaves the L2 term to adam_step (train_step / bench)
         # optional second HIP stream for the filter gradients (see _Stage._bwd).  Measured on MI355X at B=4 384x512:
         # 397 pairs/s with it vs 405 without (both kernels already fill the chip and then share LDS/occupancy), so
         # it is off unless UNFLOW_SIDE_STREAM=1
@@ -578,7 +579,8 @@ class FlowNetEngine:
             for lv in self.lv[1:]:
                 lv['gflow'].zero_()
         # regularisation term (value only; its gradient is fused into adam_step)
-        check(lib.unflow_l2_loss(ptr(self.P), cl(self.n_weights), cf(L2_SCALE), ptr(self.loss_acc), st), "l2_loss")
+        if not self.defer_l2:
+            check(lib.unflow_l2_loss(ptr(self.P), cl(self.n_weights), cf(L2_SCALE), ptr(self.loss_acc), st), "l2_loss")
         return self.loss_acc
 
     def _level_extra(self, lv):
@@ -635,6 +637,12 @@ class FlowNetEngine:
         self.step_count += 1
         t = self.step_count
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        if self.defer_l2:   # the loss of THIS step gets its regularisation term from the pre-update parameters here
+            check(_lib.lib().unflow_adam_step_regloss(ptr(self.P), ptr(self.G), ptr(self.M), ptr(self.V),
+                                                      cl(self.n_params), cl(self.n_weights), cf(grad_scale), cf(L2_SCALE),
+                                                      cf(lr_t), cf(beta1), cf(beta2), cf(eps), ptr(self.loss_acc),
+                                                      stream()), "adam")
+            return
         check(_lib.lib().unflow_adam_step(ptr(self.P), ptr(self.G), ptr(self.M), ptr(self.V), cl(self.n_params),
                                           cl(self.n_weights), cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1),
                                           cf(beta2), cf(eps), stream()), "adam")
@@ -649,8 +657,14 @@ class FlowNetEngine:
         return loss
 
     def train_step(self, im1, im2, lr):
-        loss = self.fwd_bwd(im1, im2)
-        self.adam_step(lr)
+        """One optimisation step; returns the loss tensor [1] (complete once the Adam kernel has run: the 0.0004*sum(w^2)/2
+        term is accumulated by the pass Adam makes over the parameters, not by a separate reduction)."""
+        prev, self.defer_l2 = self.defer_l2, True
+        try:
+            loss = self.fwd_bwd(im1, im2)
+            self.adam_step(lr)
+        finally:
+            self.defer_l2 = prev
         return loss
 
     def final_flows(self):

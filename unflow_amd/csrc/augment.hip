@@ -37,7 +37,7 @@ __global__ void stn_affine_kernel(const float* __restrict__ U, int n_u, int ld_u
     const float* pd = base + (size_t)(y1 * W + x1) * ld_u;
     float* o = out + (size_t)i * ld_out;
     const int CC = CT ? CT : C;
-#pragma unroll
+#pragma unroll 4
     for (int c = 0; c < CC; c++) o[c] = ((wa * pa[c] + wb * pb[c]) + wc * pc[c]) + wd * pd[c];   // add_n order (:121)
   }
 }

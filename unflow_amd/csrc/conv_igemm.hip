@@ -351,9 +351,8 @@ __global__ void splitk_reduce_epilogue_kernel(const GatherParams p) {
       const float4 t = src[(size_t)s * totq];
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
-    if (p.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (p.bias) {   // bias vectors are not necessarily 16-byte aligned: scalar loads (L1-resident)
+      v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3];
     }
     if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
     float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
@@ -1462,7 +1461,7 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (p.nsplit > 1) {
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
     const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
-                         reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.act_src);
+                         reinterpret_cast<uintptr_t>(p.act_src);
     const bool vec = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0;
     if (vec) splitk_reduce_epilogue_kernel<<<stream_grid((long)(total / 4)), 256, 0, st>>>(p);
     else splitk_reduce_epilogue_scalar_kernel<<<stream_grid((long)total), 256, 0, st>>>(p);

@@ -85,7 +85,7 @@ __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const f
     const float* p_br = base + (size_t)(yc * W + xb) * CC;
     const bool m_tl = xl && yt, m_tr = xr && yt, m_bl = xl && yb, m_br = xr && yb;
     float du = 0.f, dv = 0.f;
-#pragma unroll
+#pragma unroll 4
     for (int c = 0; c < CC; c++) {
       const float din = dout[(size_t)i * CC + c];
       const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
@@ -195,7 +195,7 @@ __global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, c
     const float* pc = im + (sbase + t.ic) * ld_im;
     const float* pd = im + (sbase + t.id) * ld_im;
     const int CC = CT ? CT : C;
-#pragma unroll
+#pragma unroll 4
     for (int c = 0; c < CC; c++)
       out[(size_t)i * C + c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
   }

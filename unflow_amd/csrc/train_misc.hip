@@ -75,9 +75,12 @@ UNFLOW_API int unflow_resize_bilinear_tf1(const float* in, float* out, int B, in
 }
 
 // Fused Adam (TF form, epsilon outside the bias correction) + L2-regulariser gradient.
+template <bool REG_LOSS>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, long n_reg, float gscale, float l2, float lr_t, float b1,
-                            float b2, float eps) {
+                            float b2, float eps, float* __restrict__ loss_acc) {
+  __shared__ float red[4];
+  float sq = 0.f;   // REG_LOSS: sum of squares of the PRE-update regularised parameters (this step's L2 loss term)
   const long n4 = n >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -91,7 +94,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     for (int j = 0; j < 4; j++) {
       const long idx = 4 * i + j;
       float gr = ga[j] * gscale;
-      if (idx < n_reg) gr += l2 * pa[j];
+      if (idx < n_reg) {
+        gr += l2 * pa[j];
+        if (REG_LOSS) sq += pa[j] * pa[j];
+      }
       ma[j] = b1 * ma[j] + (1.f - b1) * gr;
       va[j] = b2 * va[j] + (1.f - b2) * (gr * gr);
       pa[j] = pa[j] - lr_t * ma[j] / (sqrtf(va[j]) + eps);
@@ -104,12 +110,19 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const long t0 = n4 << 2;
   for (long idx = t0 + blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
     float gr = g[idx] * gscale;
-    if (idx < n_reg) gr += l2 * p[idx];
+    if (idx < n_reg) {
+      gr += l2 * p[idx];
+      if (REG_LOSS) sq += p[idx] * p[idx];
+    }
     const float mn = b1 * m[idx] + (1.f - b1) * gr;
     const float vn = b2 * v[idx] + (1.f - b2) * (gr * gr);
     m[idx] = mn;
     v[idx] = vn;
     p[idx] = p[idx] - lr_t * mn / (sqrtf(vn) + eps);
+  }
+  if (REG_LOSS) {
+    const float t = block_sum(sq, red);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, t * 0.5f * l2);
   }
 }
 
@@ -118,8 +131,18 @@ UNFLOW_API int unflow_adam_step(float* p, const float* grad, float* m, float* v,
                                 unflow_stream_t stream) {
   if (!p || !grad || !m || !v) return UNFLOW_ERR_NULL;
   if (n <= 0) return UNFLOW_OK;
-  adam_kernel<<<stream_grid(n / 4 + 1), 256, 0, as_stream(stream)>>>(p, grad, m, v, n, n_regularized, grad_scale,
-                                                                      l2_scale, lr_t, beta1, beta2, eps);
+  adam_kernel<false><<<stream_grid(n / 4 + 1), 256, 0, as_stream(stream)>>>(p, grad, m, v, n, n_regularized, grad_scale,
+                                                                             l2_scale, lr_t, beta1, beta2, eps, nullptr);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_adam_step_regloss(float* p, const float* grad, float* m, float* v, long n, long n_regularized,
+                                        float grad_scale, float l2_scale, float lr_t, float beta1, float beta2,
+                                        float eps, float* loss_acc, unflow_stream_t stream) {
+  if (!p || !grad || !m || !v || !loss_acc) return UNFLOW_ERR_NULL;
+  if (n <= 0) return UNFLOW_OK;
+  adam_kernel<true><<<stream_grid(n / 4 + 1), 256, 0, as_stream(stream)>>>(p, grad, m, v, n, n_regularized, grad_scale,
+                                                                            l2_scale, lr_t, beta1, beta2, eps, loss_acc);
   return launch_status();
 }
 
