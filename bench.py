@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="image pairs per GPU")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--flownet", default="C", help="network spec: C (the benchmarked config), S, CS, CSS (BASELINE configs[3] "
+                    "with --batch 2 --height 768 --width 1024); non-default specs print the line without roofline/cpu_baseline")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -81,7 +83,8 @@ def main():
     torch.cuda.set_device(dev)
 
     B, H, W = args.batch, args.height, args.width
-    eng = FlowNetCEngine(B, H, W, device=dev, seed=0)            # same weights on every rank
+    from unflow_amd.core.engine import DEFAULT_PARAMS
+    eng = FlowNetCEngine(B, H, W, params=dict(DEFAULT_PARAMS, flownet=args.flownet), device=dev, seed=0)   # same weights on every rank
     eng.defer_l2 = True      # the L2 term of the loss is accumulated by the Adam kernel's pass over the parameters
     g = torch.Generator().manual_seed(1234 + rank)               # distinct shard per rank
     im1 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
@@ -157,20 +160,21 @@ def main():
     pairs_per_s = world * B * args.steps / dt
 
     out = {
-        "metric": "image-pairs/s (fwd+bwd) FlowNetC 384x512", "value": round(pairs_per_s, 3), "unit": "image-pairs/s",
+        "metric": "image-pairs/s (fwd+bwd) FlowNet%s %dx%d" % (args.flownet, H, W), "value": round(pairs_per_s, 3), "unit": "image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "FlowNetC unsupervised step: bidirectional fwd + census/2nd-order loss pyramid + bwd + "
+        "config": {"workload": "FlowNet%s unsupervised step: bidirectional fwd + census/2nd-order loss pyramid + bwd + "
                                "L2/Adam%s, %d pairs/GPU, %dx%d, 441-ch correlation (BASELINE configs[%d])"
-                               % (" + RCCL grad all-reduce" if world > 1 else "", B, H, W, 2 if world > 1 else 1),
+                               % (args.flownet, " + RCCL grad all-reduce" if world > 1 else "", B, H, W,
+                                  3 if args.flownet != "C" else (2 if world > 1 else 1)),
                    "global_batch": world * B, "height": H, "width": W, "parallelism": "dp%d" % world,
                    "hipgraph": graphs is not None, "final_loss": round(loss, 4)},
-        "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W) == (384, 512) else None,
+        "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W, args.flownet) == (384, 512, "C") else None,
     }
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and args.flownet == 'C':
         out["roofline"] = measure_roofline(eng, args)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.flownet == 'C':
         out["cpu_baseline"] = measure_cpu_baseline(H, W)
         if out["cpu_baseline"]["value"]:
             out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
