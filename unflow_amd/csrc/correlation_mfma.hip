@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma_kernel(const CorrMfmaParams
         const float* src = p.in1 + (((size_t)n1 * p.H + (bok ? y2 : 0)) * p.W + (bok ? xb : 0)) * p.ld_in + 4 * h;
 #pragma unroll
         for (int q8 = 0; q8 < C / 8; q8++) {
-          const float4 v = bok ? ldg4(src + 8 * q8) : make_float4(0, 0, 0, 0);
+          float4 v = ldg4(src + 8 * q8);      // src is clamped into the image: unconditional load, masked by selects
+          v.x = bok ? v.x : 0.f; v.y = bok ? v.y : 0.f; v.z = bok ? v.z : 0.f; v.w = bok ? v.w : 0.f;
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8], v.x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8 + 1], v.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8 + 2], v.z, acc, 0, 0, 0);
@@ -123,50 +124,62 @@ __global__ __launch_bounds__(256) void corr_bwd_mfma_kernel(const CorrMfmaParams
 #pragma unroll
     for (int r_ = 0; r_ < 16; r_++) acc[c][r_] = 0.f;
 
-  for (int role = role_lo; role <= role_hi; role++) {
+  // Iteration space: (role, displacement row, neighbour tile).  All 16 + 16*CT operand values of an iteration
+  // are loaded first — unconditional loads from clamped addresses, masked by selects: a load under `ok ? :` becomes a
+  // branch per load and serialises load -> wait -> MFMA (that form ran at 405 us) — then the 16*CT MFMAs are issued.
+  auto load_operands = [&](int role, int pi, int t, float (&av)[16], float (&bvv)[16][CT]) -> bool {
     // role 0: s is the FIRST input of pair (s, s+shift): band rows = own sites, source = in1[(s+shift)%B] at y + s2*p
     // role 1: s is the SECOND input of pair (s-shift, s): band cols = own sites, source = in0[(s-shift)%B] at y - s2*p
     const int nd = role == 0 ? s : ((s - p.shift) % p.B + p.B) % p.B;  // sample whose dOut is read
     const int ns = role == 0 ? (s + p.shift) % p.B : nd;              // sample whose features are the B operand
     const float* srcbase = role == 0 ? p.in1 : p.in0;
-    for (int pi = 0; pi < p.gw; pi++) {
-      const int dyp = p.s2 * (pi - p.r);
-      const int ysrc = role == 0 ? y + dyp : y - dyp;            // feature row multiplied in
-      const int oy = (role == 0 ? y : y - dyp) - p.off;          // output row whose dOut is used
-      if ((unsigned)ysrc >= (unsigned)p.H || (unsigned)oy >= (unsigned)p.oh) continue;
-      const float* drow = p.dout + ((size_t)nd * p.oh + oy) * p.ow * p.ld_dout + pi * p.gw + p.r;
-      const float* srow = srcbase + ((size_t)ns * p.H + ysrc) * p.W * p.ld_in + c0 + l31;
-      for (int t = -p.T; t <= p.T; t++) {
-        const int k0 = i0 + 32 * t;  // first contracted site index
-        // is any contracted site inside the image?  (wave-uniform)
-        const int xk_lo = q + p.off + p.s2 * k0, xk_hi = q + p.off + p.s2 * (k0 + 31);
-        if (xk_hi < 0 || xk_lo >= p.W) continue;
-        float av[16];
+    const int dyp = p.s2 * (pi - p.r);
+    const int ysrc = role == 0 ? y + dyp : y - dyp;            // feature row multiplied in
+    const int oy = (role == 0 ? y : y - dyp) - p.off;          // output row whose dOut is used
+    if ((unsigned)ysrc >= (unsigned)p.H || (unsigned)oy >= (unsigned)p.oh) return false;
+    const int k0 = i0 + 32 * t;  // first contracted site index
+    const int xk_lo = q + p.off + p.s2 * k0, xk_hi = q + p.off + p.s2 * (k0 + 31);
+    if (xk_hi < 0 || xk_lo >= p.W) return false;               // no contracted site inside the image (wave-uniform)
+    const float* drow = p.dout + ((size_t)nd * p.oh + oy) * p.ow * p.ld_dout + pi * p.gw + p.r;
+    const float* srow = srcbase + ((size_t)ns * p.H + ysrc) * p.W * p.ld_in + c0 + l31;
 #pragma unroll
-        for (int st = 0; st < 16; st++) {
-          const int k = k0 + 2 * st + h;      // contracted site
-          const int own = i0 + l31;           // this lane's own site (row of the MFMA tile)
-          // role 0: band element dOut[ox(own), o = k - own]; role 1: dOut[ox(k), o = own - k]
-          const int site = role == 0 ? own : k;
-          const int o = role == 0 ? k - own : own - k;
-          const int ox = q + p.s2 * site;
-          const bool ok = o >= -p.r && o <= p.r && (unsigned)ox < (unsigned)p.ow;
-          av[st] = ok ? drow[(size_t)ox * p.ld_dout + o] : 0.f;
-        }
+    for (int st = 0; st < 16; st++) {
+      const int k = k0 + 2 * st + h;      // contracted site
+      const int own = i0 + l31;           // this lane's own site (row of the MFMA tile)
+      // role 0: band element dOut[ox(own), o = k - own]; role 1: dOut[ox(k), o = own - k]
+      const int site = role == 0 ? own : k;
+      const int o = role == 0 ? k - own : own - k;
+      const int ox = q + p.s2 * site;
+      const bool ok = o >= -p.r && o <= p.r && (unsigned)ox < (unsigned)p.ow;
+      const float v = drow[(size_t)(ok ? ox : 0) * p.ld_dout + (ok ? o : 0)];
+      av[st] = ok ? v : 0.f;
+    }
 #pragma unroll
-        for (int st = 0; st < 16; st++) {
-          const int xs = q + p.off + p.s2 * (k0 + 2 * st + h);
-          const bool ok = (unsigned)xs < (unsigned)p.W;
-          const float* sp = srow + (size_t)(ok ? xs : 0) * p.ld_in;
+    for (int st = 0; st < 16; st++) {
+      const int xs = q + p.off + p.s2 * (k0 + 2 * st + h);
+      const bool ok = (unsigned)xs < (unsigned)p.W;
+      const float* sp = srow + (size_t)(ok ? xs : 0) * p.ld_in;
 #pragma unroll
-          for (int c = 0; c < CT; c++) {
-            const float bv = ok ? sp[32 * c] : 0.f;
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv, acc[c], 0, 0, 0);
-          }
-        }
+      for (int c = 0; c < CT; c++) {
+        const float tv = sp[32 * c];
+        bvv[st][c] = ok ? tv : 0.f;
       }
     }
-  }
+    return true;
+  };
+
+  // (Loading the operands of iteration it+1 before the MFMAs of iteration it was measured SLOWER — 305 vs 243 us at
+  // the FlowNetC shape: the second operand set costs a wave of occupancy.  Three resident waves per SIMD overlap instead.)
+  for (int role = role_lo; role <= role_hi; role++)
+    for (int pi = 0; pi < p.gw; pi++)
+      for (int t = -p.T; t <= p.T; t++) {
+        float av[16], bvv[16][CT];
+        if (!load_operands(role, pi, t, av, bvv)) continue;
+#pragma unroll
+        for (int st = 0; st < 16; st++)
+#pragma unroll
+          for (int c = 0; c < CT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bvv[st][c], acc[c], 0, 0, 0);
+      }
   float* gout = (p.fuse || blockIdx.y == 0) ? p.g0 : p.g1;
   const float cf = (float)p.C;
 #pragma unroll
