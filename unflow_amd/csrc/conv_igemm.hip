@@ -1336,8 +1336,13 @@ inline GatherPlan plan_gather(const GatherParams& p) {
     const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
     if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
   }
-  const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
-  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : 6);
+  // N <= 64 with a long M: a 256x64 tile (four 64x64 wave tiles stacked along M: 4 accumulators per wave, the MFMA :
+  // LDS-read ratio of the 128x128 tile) instead of 128x64.  Measured on conv1 fwd / conv2 dgrad: no gain (438 vs 441
+  // pairs/s), so it stays behind the knob.
+  static const int tall = getenv("UNFLOW_GATHER_TALL") ? atoi(getenv("UNFLOW_GATHER_TALL")) : 0;   // tuning knob
+  if (pl.cfg == 1 && tall && M * p.ncls >= 256L * 768) pl.cfg = 3;
+  const int bm = pl.cfg == 2 ? 64 : pl.cfg == 3 ? 256 : 128, bn = pl.cfg == 0 ? 128 : 64;
+  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : pl.cfg == 3 ? 3 : 6);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
   return pl;
@@ -1455,6 +1460,7 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   switch (pl.cfg) {
     case 0: code = launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st); break;
     case 1: code = launch_gather_cfg<128, 64, 64, 32, B_NK>(p, st); break;
+    case 3: code = launch_gather_cfg<256, 64, 64, 64, B_NK>(p, st); break;
     default: code = launch_gather_cfg<64, 64, 32, 32, B_NK>(p, st); break;
   }
   if (code != UNFLOW_OK) return code;
