@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64) void skinny_conv_wgrad3_kernel(const SkinnyWgra
 // image row, so the filter is read once per strip and every input quad once per (row, strip).
 // Explicit fmaf here (the file is built with -ffp-contract=off): these kernels are VALU-bound, the fused form halves
 // the instruction count and is the more accurate of the two roundings.
-constexpr int SK_S = 8;   // pixels per strip (W % SK_S == 0 is a dispatch condition)
+// S = pixels per strip: 8 on the large levels, 4 on the small ones (W % S == 0 is a dispatch condition)
 
 __device__ __forceinline__ void load_head_weights(const float* __restrict__ w, int Cin, int c4, bool active,
                                                   float (&wr)[9][8]) {
@@ -742,22 +742,25 @@ __device__ __forceinline__ void load_head_weights(const float* __restrict__ w, i
 }
 
 // y[b, yy, x0+o, co] = bias + sum_{ky,kx,c} x[b, yy-1+ky, x0+o-1+kx, c] * w[ky,kx,c,co]
+// WSPLIT (small levels): one strip per BLOCK, the four waves split the channel-quad groups and their sums meet in LDS.
+template <int S, bool WSPLIT>
 __global__ __launch_bounds__(256) void head3_fwd_strip_kernel(const SkinnyParams p) {
-  const int lane = threadIdx.x & 63;
-  const int strips = p.W / SK_S;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int strips = p.W / S;
   const long njobs = (long)p.B * p.H * strips;
-  const long job = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
+  const long job = WSPLIT ? (long)blockIdx.x
+                          : (long)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
   if (job >= njobs) return;
   const int xs = (int)(job % strips);
   const long row = job / strips;
   const int yy = (int)(row % p.H);
   const long b = row / p.H;
-  const int x0 = xs * SK_S;
+  const int x0 = xs * S;
   const int Cq = p.Cin >> 2;
-  float acc[2 * SK_S];   // [o][co]
+  float acc[2 * S];   // [o][co]
 #pragma unroll
-  for (int o = 0; o < 2 * SK_S; o++) acc[o] = 0.f;
-  for (int g0 = 0; g0 < Cq; g0 += 64) {
+  for (int o = 0; o < 2 * S; o++) acc[o] = 0.f;
+  for (int g0 = WSPLIT ? 64 * wv : 0; g0 < Cq; g0 += WSPLIT ? 256 : 64) {
     const bool active = g0 + lane < Cq;
     const int c4 = min(g0 + lane, Cq - 1);          // clamped: every load below is unconditional and in range
 #pragma unroll
@@ -773,16 +776,16 @@ __global__ __launch_bounds__(256) void head3_fwd_strip_kernel(const SkinnyParams
         wr[kx][4] = wb.x; wr[kx][5] = wb.y; wr[kx][6] = wb.z; wr[kx][7] = wb.w;
       }
       const float* xrow = p.x + ((b * p.H + iy) * p.W) * p.ldx + c4 * 4;
-      float4 xv[SK_S + 2];
+      float4 xv[S + 2];
 #pragma unroll
-      for (int i = 0; i < SK_S + 2; i++) {
+      for (int i = 0; i < S + 2; i++) {
         const int ix = x0 - 1 + i;
         const float4 t = ldg4(xrow + (long)min(max(ix, 0), p.W - 1) * p.ldx);
         const bool ok = active && (unsigned)ix < (unsigned)p.W;
         xv[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
       }
 #pragma unroll
-      for (int o = 0; o < SK_S; o++)
+      for (int o = 0; o < S; o++)
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
           const float4 v = xv[o + kx];
@@ -794,49 +797,81 @@ __global__ __launch_bounds__(256) void head3_fwd_strip_kernel(const SkinnyParams
         }
     }
   }
-  // 16 wave sums as one halving butterfly (8+4+2+1 exchanges + 2 plain steps = 17 shuffles instead of 96): after the
-  // xor-32 step a lane keeps half of the values, ... after xor-4 exactly one: value id = lane bits 5..2.
-  float v8[8], v4[4], v2[2], v1;
+  // 2S wave sums as one halving butterfly (S=8: 8+4+2+1 exchanges + 2 plain steps = 17 shuffles instead of 96): after
+  // the xor-32 step a lane keeps half of the values, ... until exactly one is left: value id = the top bits of the lane.
+  constexpr int NV = 2 * S;
+  constexpr int LG = NV == 16 ? 4 : NV == 8 ? 3 : 2;
+  static_assert(NV == 16 || NV == 8 || NV == 4, "S in {8, 4, 2}");
+  float v1;
+  if constexpr (NV == 16) {
+    float v8[8], v4[4], v2[2];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const bool hi = lane & 32;
-    const float keep = hi ? acc[8 + i] : acc[i], send = hi ? acc[i] : acc[8 + i];
-    v8[i] = keep + __shfl_xor(send, 32);
-  }
+    for (int i = 0; i < 8; i++) {
+      const bool hi = lane & 32;
+      v8[i] = (hi ? acc[8 + i] : acc[i]) + __shfl_xor(hi ? acc[i] : acc[8 + i], 32);
+    }
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const bool hi = lane & 16;
-    const float keep = hi ? v8[4 + i] : v8[i], send = hi ? v8[i] : v8[4 + i];
-    v4[i] = keep + __shfl_xor(send, 16);
-  }
+    for (int i = 0; i < 4; i++) {
+      const bool hi = lane & 16;
+      v4[i] = (hi ? v8[4 + i] : v8[i]) + __shfl_xor(hi ? v8[i] : v8[4 + i], 16);
+    }
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const bool hi = lane & 8;
-    const float keep = hi ? v4[2 + i] : v4[i], send = hi ? v4[i] : v4[2 + i];
-    v2[i] = keep + __shfl_xor(send, 8);
-  }
-  {
+    for (int i = 0; i < 2; i++) {
+      const bool hi = lane & 8;
+      v2[i] = (hi ? v4[2 + i] : v4[i]) + __shfl_xor(hi ? v4[i] : v4[2 + i], 8);
+    }
     const bool hi = lane & 4;
-    const float keep = hi ? v2[1] : v2[0], send = hi ? v2[0] : v2[1];
-    v1 = keep + __shfl_xor(send, 4);
+    v1 = (hi ? v2[1] : v2[0]) + __shfl_xor(hi ? v2[0] : v2[1], 4);
+  } else if constexpr (NV == 8) {
+    float v4[4], v2[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bool hi = lane & 32;
+      v4[i] = (hi ? acc[4 + i] : acc[i]) + __shfl_xor(hi ? acc[i] : acc[4 + i], 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const bool hi = lane & 16;
+      v2[i] = (hi ? v4[2 + i] : v4[i]) + __shfl_xor(hi ? v4[i] : v4[2 + i], 16);
+    }
+    const bool hi = lane & 8;
+    v1 = (hi ? v2[1] : v2[0]) + __shfl_xor(hi ? v2[0] : v2[1], 8);
+  } else {
+    float v2[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const bool hi = lane & 32;
+      v2[i] = (hi ? acc[2 + i] : acc[i]) + __shfl_xor(hi ? acc[i] : acc[2 + i], 32);
+    }
+    const bool hi = lane & 16;
+    v1 = (hi ? v2[1] : v2[0]) + __shfl_xor(hi ? v2[0] : v2[1], 16);
   }
-  v1 += __shfl_xor(v1, 2);
-  v1 += __shfl_xor(v1, 1);
-  if ((lane & 3) == 0) {
-    // id bits: lane bit5 -> 8, bit4 -> 4, bit3 -> 2, bit2 -> 1
-    const int id = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    const int o = id >> 1, co = id & 1;
-    p.y[((b * p.H + yy) * p.W + x0 + o) * p.ldy + co] = v1 + (p.bias ? p.bias[co] : 0.f);
+#pragma unroll
+  for (int m = 32 >> LG; m >= 1; m >>= 1) v1 += __shfl_xor(v1, m);
+  const int id = lane >> (6 - LG);      // value index = [o][co]
+  const bool holder = (lane & ((64 >> LG) - 1)) == 0;
+  if (WSPLIT) {
+    __shared__ float red[4][NV];
+    if (holder) red[wv][id] = v1;
+    __syncthreads();
+    if (threadIdx.x < NV) {
+      const int t = threadIdx.x;
+      const float sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      p.y[((b * p.H + yy) * p.W + x0 + (t >> 1)) * p.ldy + (t & 1)] = sum + (p.bias ? p.bias[t & 1] : 0.f);
+    }
+  } else if (holder) {
+    p.y[((b * p.H + yy) * p.W + x0 + (id >> 1)) * p.ldy + (id & 1)] = v1 + (p.bias ? p.bias[id & 1] : 0.f);
   }
 }
 
 // One row of the wave-uniform dz window (columns x0-1 .. x0+S, 2 channels = 2*(S+2) floats, zero outside the image):
 // lane l < 2*(S+2) loads element l in ONE coalesced instruction; consumers broadcast with v_readlane (an SGPR operand).
+template <int S>
 __device__ __forceinline__ float load_dz_window_row(const float* __restrict__ dz, int lddz, long b, int oy, int x0, int H,
                                                     int W, int lane) {
   const int col = lane >> 1, co = lane & 1;
   const int ox = x0 - 1 + col;
-  const bool ok = lane < 2 * (SK_S + 2) && (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+  const bool ok = lane < 2 * (S + 2) && (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
   const float v = dz[((b * H + (ok ? oy : 0)) * W + (ok ? ox : 0)) * lddz + co];
   return ok ? v : 0.f;
 }
@@ -846,9 +881,10 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 
 // dx[b, yy, x0+o, ci] (+)= sum_{ky,kx,co} dz[b, yy+1-ky, x0+o+1-kx, co] * w[ky,kx,ci,co]; wave = (row, strip, quad group);
 // the dz window of the strip is wave-uniform (scalar loads), lanes differ only in the channel quad.
+template <int S>
 __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdParams p) {
   const int lane = threadIdx.x & 63;
-  const int strips = p.W / SK_S;
+  const int strips = p.W / S;
   const int Cq = p.Cin >> 2, groups = (Cq + 63) / 64;
   const long njobs = (long)p.B * p.H * strips * groups;
   const long job = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
@@ -859,7 +895,7 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
   const long row = j2 / strips;
   const int yy = (int)(row % p.H);
   const long b = row / p.H;
-  const int x0 = xs * SK_S;
+  const int x0 = xs * S;
   const int c4 = g * 64 + lane;
   const bool active = c4 < Cq;
   float wr[9][8];
@@ -867,18 +903,18 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
   // dz window: rows yy-1..yy+1, columns x0-1..x0+S, 2 channels; zero outside the image
   float dzv[3];
 #pragma unroll
-  for (int r = 0; r < 3; r++) dzv[r] = load_dz_window_row(p.dz, p.lddz, b, yy - 1 + r, x0, p.H, p.W, lane);
-  float dzw[3][SK_S + 2][2];
+  for (int r = 0; r < 3; r++) dzv[r] = load_dz_window_row<S>(p.dz, p.lddz, b, yy - 1 + r, x0, p.H, p.W, lane);
+  float dzw[3][S + 2][2];
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int i = 0; i < SK_S + 2; i++) {
+    for (int i = 0; i < S + 2; i++) {
       dzw[r][i][0] = lane_bcast(dzv[r], 2 * i);
       dzw[r][i][1] = lane_bcast(dzv[r], 2 * i + 1);
     }
   if (!active) return;
 #pragma unroll
-  for (int o = 0; o < SK_S; o++) {
+  for (int o = 0; o < S; o++) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 3; ky++)
@@ -914,6 +950,7 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
 // dw[ky,kx,ci,co] partials = sum over a chunk of strips of x[b,iy,ix,ci] * dz[b, iy+1-ky, ix+1-kx, co].
 // block = 4 waves x the same 64 channel quads; each wave walks its own strips, then the four register tiles are
 // summed through LDS in a fixed order (deterministic) and the block writes ONE partial.
+template <int S>
 __global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgradParams p, int strips_per_wave) {
   __shared__ float red[72 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -921,7 +958,7 @@ __global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgra
   const int c4 = blockIdx.x * 64 + lane;
   const bool active = c4 < Cq;
   const int cc = min(c4, Cq - 1);   // clamped: loads are unconditional, inactive lanes contribute zeros
-  const int strips = p.W / SK_S;
+  const int strips = p.W / S;
   const long nstrips = (long)p.B * p.H * strips;
   const long s0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.y * 4 + wv) * strips_per_wave));
   float acc[9][8];
@@ -934,23 +971,23 @@ __global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgra
     const long row = sidx / strips;
     const int iy = (int)(row % p.H);
     const long b = row / p.H;
-    const int x0 = xs * SK_S;
-    float4 xv[SK_S];
+    const int x0 = xs * S;
+    float4 xv[S];
     const float* xrow = p.x + ((b * p.H + iy) * p.W + x0) * p.ldx + cc * 4;
 #pragma unroll
-    for (int i = 0; i < SK_S; i++) {
+    for (int i = 0; i < S; i++) {
       const float4 t = ldg4(xrow + (long)i * p.ldx);
       xv[i] = make_float4(active ? t.x : 0.f, active ? t.y : 0.f, active ? t.z : 0.f, active ? t.w : 0.f);
     }
     float dzv[3];   // window rows iy+1, iy, iy-1 for ky = 0, 1, 2
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++) dzv[ky] = load_dz_window_row(p.dz, p.lddz, b, iy + 1 - ky, x0, p.H, p.W, lane);
+    for (int ky = 0; ky < 3; ky++) dzv[ky] = load_dz_window_row<S>(p.dz, p.lddz, b, iy + 1 - ky, x0, p.H, p.W, lane);
 #pragma unroll
     for (int ky = 0; ky < 3; ky++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++)
 #pragma unroll
-        for (int i = 0; i < SK_S; i++) {
+        for (int i = 0; i < S; i++) {
           // ox = x0 + i + 1 - kx -> window column i + 2 - kx
           const float g0 = lane_bcast(dzv[ky], 2 * (i + 2 - kx)), g1 = lane_bcast(dzv[ky], 2 * (i + 2 - kx) + 1);
           float* a = acc[ky * 3 + kx];
@@ -1386,16 +1423,20 @@ inline int skinny_wgrad_chunks(long npix, int Cin) {
   return (int)min(c, (long)1024);
 }
 
-// the strip kernels take over when the level is big enough to fill the chip with (row, strip) waves
-inline bool head_strip_ok(int B, int H, int W, int k, int Cout) {
-  return k == 3 && Cout == 2 && W % SK_S == 0 && (long)B * H * W >= 16384;
+// strip size of the flow-head kernels: 8 when the level fills the chip with (row, strip) waves, else 4 (then the forward
+// kernel also splits the channel groups over the 4 waves of a block); 0 = use the per-pixel kernels
+inline int head_strip(int B, int H, int W, int k, int Cout) {
+  if (k != 3 || Cout != 2) return 0;
+  if (W % 8 == 0 && (long)B * H * W >= 16384) return 8;
+  return W % 4 == 0 ? 4 : 0;
 }
-// blocks (= partials) of head3_wgrad_strip_kernel per channel-quad group: >= 4 strips per wave, <= 1024 blocks
-inline int head_wgrad_blocks(int B, int H, int W, int Cin, int* strips_per_wave) {
-  const long nstrips = (long)B * H * (W / SK_S);
+// blocks (= partials) of head3_wgrad_strip_kernel per channel-quad group: <= 1024 blocks, >= 4 strips per wave when
+// there are enough strips
+inline int head_wgrad_blocks(int B, int H, int W, int Cin, int S, int* strips_per_wave) {
+  const long nstrips = (long)B * H * (W / S);
   const long colblocks = (Cin / 4 + 63) / 64;
   long blocks = min((long)1024, max((long)1, 1024 / colblocks));
-  long spw = max((long)4, (nstrips + blocks * 4 - 1) / (blocks * 4));
+  long spw = max((long)(nstrips >= 4096 ? 4 : 1), (nstrips + blocks * 4 - 1) / (blocks * 4));
   blocks = (nstrips + spw * 4 - 1) / (spw * 4);
   *strips_per_wave = (int)spw;
   return (int)blocks;
@@ -1579,9 +1620,14 @@ UNFLOW_API int unflow_conv2d_fwd(const float* x, int ldx, const float* w, const 
     same_pads(H, k, 1, &pt, &Ho);
     same_pads(W, k, 1, &pl, &Wo);
     SkinnyParams p{x, ldx, w, bias, y, ldy, B, H, W, Cin, k, pt, pl};
-    if (head_strip_ok(B, H, W, k, Cout)) {
-      const long jobs = (long)B * H * (W / SK_S);
-      head3_fwd_strip_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+    const int S = head_strip(B, H, W, k, Cout);
+    if (S == 8) {
+      const long jobs = (long)B * H * (W / 8);
+      head3_fwd_strip_kernel<8, false><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+      return launch_status();
+    }
+    if (S == 4) {
+      head3_fwd_strip_kernel<4, true><<<B * H * (W / 4), 256, 0, st>>>(p);
       return launch_status();
     }
     const long waves = (long)B * H * W;
@@ -1614,9 +1660,11 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
     same_pads(H, k, 1, &pt, &Ho);
     same_pads(W, k, 1, &pl, &Wo);
     SkinnyBwdParams p{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, k, pt, pl};
-    if (head_strip_ok(B, H, W, k, Cout) && lddx % 4 == 0 && (!act_src || ld_act % 4 == 0)) {
-      const long jobs = (long)B * H * (W / SK_S) * cdiv(Cin / 4, 64);
-      head3_dgrad_strip_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+    const int S = (lddx % 4 == 0 && (!act_src || ld_act % 4 == 0)) ? head_strip(B, H, W, k, Cout) : 0;
+    if (S) {
+      const long jobs = (long)B * H * (W / S) * cdiv(Cin / 4, 64);
+      if (S == 8) head3_dgrad_strip_kernel<8><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+      else head3_dgrad_strip_kernel<4><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
       return launch_status();
     }
     const long total = (long)B * H * W * (Cin / 4);
@@ -1651,14 +1699,16 @@ UNFLOW_API int unflow_conv2d_bwd_filter(const float* x, int ldx, const float* dz
     if (stride != 1 || k != 3 || Cout != 2) return UNFLOW_ERR_UNSUPPORTED;
     const long npix = (long)B * H * W;
     const size_t wsz = (size_t)9 * Cin * Cout;
-    const bool strip = head_strip_ok(B, H, W, k, Cout);
+    const int S = head_strip(B, H, W, k, Cout);
+    const bool strip = S != 0;
     int spw = 1;
-    const int chunks = strip ? head_wgrad_blocks(B, H, W, Cin, &spw) : skinny_wgrad_chunks(npix, Cin);
+    const int chunks = strip ? head_wgrad_blocks(B, H, W, Cin, S, &spw) : skinny_wgrad_chunks(npix, Cin);
     used = (size_t)chunks * wsz * sizeof(float) + reduce_scratch_bytes(wsz, chunks);
     if (!workspace || workspace_bytes < used) return UNFLOW_ERR_WORKSPACE;
     SkinnyWgradParams p{x, ldx, dz, lddz, reinterpret_cast<float*>(workspace), B, H, W, Cin, pt, pl};
     dim3 grid(cdiv(Cin / 4, 64), chunks);
-    if (strip) head3_wgrad_strip_kernel<<<grid, 256, 0, st>>>(p, spw);
+    if (S == 8) head3_wgrad_strip_kernel<8><<<grid, 256, 0, st>>>(p, spw);
+    else if (S == 4) head3_wgrad_strip_kernel<4><<<grid, 256, 0, st>>>(p, spw);
     else skinny_conv_wgrad3_kernel<2><<<grid, 64, 0, st>>>(p);
     const int rc = reduce_partials(p.partial, p.partial + (size_t)chunks * wsz, dw, wsz, chunks, st);
     if (rc != UNFLOW_OK) return rc;
