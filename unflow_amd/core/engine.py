@@ -202,7 +202,8 @@ class _Stage:
         # The filter gradient only needs dz (final at this point) and the stored activation: it runs on the side
         # stream, concurrently with the data-gradient chain on the main stream (its tail waves and the latency-bound
         # flow-head kernels fill the CUs the other kernel leaves idle).  Own split-K scratch (slot 3).
-        side = e.side
+        # ('small': only the latency-bound layers, the Cout = 2 flow heads and the 2->2 deconvs)
+        side = e.side if (e.side_all or l.cout <= 4) else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), L.ws_slot(3):
@@ -309,10 +310,12 @@ class FlowNetEngine:
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
         self.defer_l2 = False      # True: forward_loss leaves the L2 term to adam_step (train_step / bench)
-        # optional second HIP stream for the filter gradients (see _Stage._bwd).  Measured on MI355X at B=4 384x512:
-        # 397 pairs/s with it vs 405 without (both kernels already fill the chip and then share LDS/occupancy), so
-        # it is off unless UNFLOW_SIDE_STREAM=1
-        self.side = torch.cuda.Stream(self.dev) if os.environ.get('UNFLOW_SIDE_STREAM', '0') == '1' else None
+        # optional second HIP stream for filter gradients (see _Stage._bwd), off by default: both variants measured
+        # slower inside the captured graph on MI355X — 'all' 397 vs 405 pairs/s, 'small' (only the latency-bound flow
+        # heads / 2->2 deconvs) 438.6 vs 445.2
+        mode = os.environ.get('UNFLOW_SIDE_STREAM', '0')      # '0' (default) | 'small' | '1' / 'all'
+        self.side = torch.cuda.Stream(self.dev) if mode != '0' else None
+        self.side_all = mode in ('1', 'all')
         if seed is not None:
             self.init_params(seed)
 
