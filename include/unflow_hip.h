@@ -287,6 +287,13 @@ int unflow_photometric_augment(const float* im, int ld_in, float* out, int ld_ou
 int unflow_stack_input(const float* net_in4, const float* prev_flow2, float* out, int ld_out, int pair_shift, int N,
                        int H, int W, int h, int w, float flow_scale, unflow_stream_t stream);
 
+/* Gradient of unflow_stack_input wrt prev_flow2 for train_all (flownet.py:51-54 without the stop_gradient): d_out is
+ * the gradient wrt the 14-channel stage input (channel stride ld_out); d_prev_flow2 [N,h,w,2] is ACCUMULATED with
+ * float atomics (zero it first).  The images receive no gradient (they are data). */
+int unflow_stack_input_bwd(const float* d_out, int ld_out, const float* net_in4, const float* prev_flow2,
+                           float* d_prev_flow2, int pair_shift, int N, int H, int W, int h, int w, float flow_scale,
+                           unflow_stream_t stream);
+
 /* tf.image.resize_bilinear (TF1 legacy, align_corners=False) * scale (unsupervised.py:103-104). */
 int unflow_resize_bilinear_tf1(const float* in, float* out, int B, int H, int W, int C, int out_h, int out_w,
                                float scale, unflow_stream_t stream);

@@ -340,3 +340,41 @@ def test_train_step_defers_l2_into_adam(dev):
         assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
         assert torch.equal(a.P, b.P) and torch.equal(a.M, b.M) and torch.equal(a.V, b.V)
     assert b.defer_l2 is False
+
+
+def test_train_all_stack_vs_oracle(dev):
+    """params['train_all'] (flownet.py:51-54 without the stop_gradient, train.py:29-37): the gradient of the last network's
+    loss reaches the first network through the stage input (upsampled flow, warp, |warp - first|).  CS vs the fp64 oracle."""
+    from unflow_amd.core.engine import FlowNetEngine
+    from oracle import model_ref as M
+    B, H, W = 1, 128, 128
+    spec = 'CS'
+    params = dict(flownet=spec, train_all=True, pyramid_loss=True, border_mask=True, ternary_weight=1.0,
+                  smooth_2nd_weight=3.0)
+    eng = FlowNetEngine(B, H, W, params=params, device=dev, seed=None)
+    tf_params = M.init_params_spec(spec, seed=17)
+    eng.load_tf_params(tf_params)
+    g = torch.Generator().manual_seed(18)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.roll(im1, shifts=(1, 2), dims=(1, 2)) * 0.9 + torch.rand(B, H, W, 3, generator=g) * 25
+    P64 = {k: v.clone().double().requires_grad_() for k, v in tf_params.items()}
+    loss_ref = M.unsupervised_loss(P64, im1.double(), im2.double(), params)
+    loss_ref.backward()
+    loss = eng.fwd_bwd(im1.to(dev), im2.to(dev))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    got = eng.export_tf_grads()
+    first_net = 0
+    for k, v in P64.items():
+        l2 = 0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0
+        gref = v.grad - l2
+        if not k.startswith('stack_1_'):
+            first_net += 1
+            assert gref.abs().max().item() > 0, k            # the oracle really trains the first network here
+        a = got[k].detach().cpu().double()
+        # two networks of fp32-vs-fp64 noise + |.| and leaky kinks: loose on the worst element, tight on the mean
+        assert _rel(a, gref) < 5e-2, (k, _rel(a, gref))
+        if a.numel() >= 1024:
+            assert ((a - gref).abs().mean() / (gref.abs().mean() + 1e-30)).item() < 5e-3, k
+    assert first_net > 20
+    assert eng.grad_buckets()[0] == []

@@ -133,6 +133,8 @@ class _Stage:
         for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):
             a['flow%d' % lvl] = z(N, H // d, W // d, 2)
         self.grad = {k: torch.zeros_like(v) for k, v in a.items() if k != 'x0s'} if self.trainable else {}
+        if self.kind == 'S' and self.index > 0 and e.train_all:
+            self.grad['x0s'] = torch.zeros_like(a['x0s'])      # d loss / d stage input -> the previous network
 
     def _sl(self, name, lo, hi):
         return self.act[name][..., lo:hi]
@@ -274,14 +276,17 @@ class _Stage:
             x_in = a['x0s']
         self._bwd('conv3', s('cat2', 0, 128), g['c3'], gs('cat2', 0, 128), True, s('cat2', 0, 128), 0, 128)
         self._bwd('conv2', a['c1'], gs('cat2', 0, 128), g['c1'], False, a['c1'], 0, 64)
-        self._bwd('conv1', x_in, g['c1'], None)   # inputs are data (or stop_gradient, flownet.py:51-54)
+        # inputs are data (or behind stop_gradient, flownet.py:51-54) unless train_all reaches a refinement stage
+        self._bwd('conv1', x_in, g['c1'], g.get('x0s'))
 
 
 class FlowNetEngine:
     """Bidirectional forward / loss / backward / Adam of a FlowNet spec on one GPU, fixed (B, H, W).
     params['flownet']: 'C', 'S' or a stack 'CS', 'CSS', 'SS' ... (flownet.py:14-81).  In a stack only the last network
-    is trained (train_all is not implemented); the earlier ones run forward only and — exactly as in the reference,
-    whose regulariser and optimizer span all variables — still receive the L2 gradient in the Adam update."""
+    is trained unless params['train_all'] (flownet.py:51-54, train.py:29-37); frozen stages run forward only and —
+    exactly as in the reference, whose regulariser and optimizer span all variables — still receive the L2 gradient in
+    the Adam update.  With train_all the gradient also flows back through every inter-stage input (upsampled flow, warp,
+    |warp - first|) into the earlier networks."""
 
     def __init__(self, batch, height, width, params=None, device=None, seed=0):
         assert height % 64 == 0 and width % 64 == 0, "FlowNet needs H, W divisible by 64"
@@ -291,8 +296,7 @@ class FlowNetEngine:
         spec = self.params.get('flownet', 'C')
         if not spec or any(ch not in 'CS' for ch in spec) or 'C' in spec[1:]:
             raise ValueError("flownet spec must be 'C' or 'S' followed by 'S' refinement nets (full-size nets only)")
-        if self.params.get('train_all') and len(spec) > 1:
-            raise NotImplementedError("train_all for stacked networks is not implemented")
+        self.train_all = bool(self.params.get('train_all')) and len(spec) > 1     # train.py:29-37, flownet.py:51-54
         if self.params.get('full_res'):
             raise NotImplementedError("full_res decoder is not implemented")
         self.spec = spec
@@ -301,7 +305,7 @@ class FlowNetEngine:
         self.dev = torch.device('cuda:0') if device is None else device
         self.stages = [_Stage(self, k, i) for i, k in enumerate(spec)]
         for st in self.stages[:-1]:
-            st.trainable = False
+            st.trainable = self.train_all
         self.layers = [l for st in self.stages for l in st.layers]
         self.by_name = self.stages[-1].by_name
         self._alloc_params()
@@ -601,12 +605,31 @@ class FlowNetEngine:
         part 0 / 1: the two halves used to overlap the data-parallel all-reduce (see grad_buckets)."""
         self.stages[-1].backward(part)
         if part in (None, 1):
+            if self.train_all:
+                for i in range(len(self.stages) - 1, 0, -1):
+                    self._stack_backward(self.stages[i], self.stages[i - 1])
+                    self.stages[i - 1].backward()
             self._bias_grads()
+
+    def _stack_backward(self, st, prev):
+        """d loss / d (flow2 of the previous network) through the stage input of `st` (train_all).  The previous
+        network's coarser flows do not reach the loss directly (only flows[-1] enters it, unsupervised.py:82-83)."""
+        for lvl in (3, 4, 5, 6):
+            prev.grad['flow%d' % lvl].zero_()
+        g2 = prev.grad['flow2']
+        g2.zero_()
+        pf = prev.act['flow2']
+        dx = st.grad['x0s']
+        check(_lib.lib().unflow_stack_input_bwd(ptr(dx), dx.shape[3], ptr(self.x0), ptr(pf), ptr(g2), self.B, self.N,
+                                                self.H, self.W, pf.shape[1], pf.shape[2], cf(4 * FLOW_SCALE), stream()),
+              "stack_input_bwd")
 
     def grad_buckets(self):
         """Flat ranges of self.G: (early, late).  `early` = the weights whose gradients are complete after
         backward_net(0) (conv4 .. flow2 of the trained network: a contiguous tail of the weight region);
         `late` = everything else (conv1 .. conv3_1 weights, all biases, and the never-written zeros of frozen stages)."""
+        if self.train_all:      # earlier networks are still accumulating until the very end
+            return [], [(0, self.n_params)]
         st = self.stages[-1]
         first = st.by_name['conv4']
         lo = first.dw.data_ptr() - self.G.data_ptr()
@@ -618,20 +641,24 @@ class FlowNetEngine:
         import ctypes
         lib = _lib.lib()
         if self._bias_plan is None:
-            jobs = self._bias_jobs
-            n = len(jobs)
-            xs = (ctypes.c_void_p * n)(*[dz.data_ptr() for dz, _ in jobs])
-            lds = (ctypes.c_int * n)(*[dz.stride(2) for dz, _ in jobs])
-            npx = (ctypes.c_long * n)(*[dz.shape[0] * dz.shape[1] * dz.shape[2] for dz, _ in jobs])
-            cs = (ctypes.c_int * n)(*[l.cout for _, l in jobs])
-            outs = (ctypes.c_void_p * n)(*[l.db.data_ptr() for _, l in jobs])
             lib.unflow_colsum_batched_workspace_bytes.restype = ctypes.c_size_t
-            nbytes = lib.unflow_colsum_batched_workspace_bytes(n, cs)
-            ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.dev)
-            self._bias_plan = (n, xs, lds, npx, cs, outs, ws)
-        n, xs, lds, npx, cs, outs, ws = self._bias_plan
-        check(lib.unflow_colsum_batched(n, xs, lds, npx, cs, outs, ptr(ws), _lib.csz(ws.numel() * 4), stream()),
-              "colsum_batched")
+            plan = []
+            MAXB = 32        # descriptors per launch (MAX_COLSUM in csrc/conv_igemm.hip); train_all stacks have more layers
+            for j0 in range(0, len(self._bias_jobs), MAXB):
+                jobs = self._bias_jobs[j0:j0 + MAXB]
+                n = len(jobs)
+                xs = (ctypes.c_void_p * n)(*[dz.data_ptr() for dz, _ in jobs])
+                lds = (ctypes.c_int * n)(*[dz.stride(2) for dz, _ in jobs])
+                npx = (ctypes.c_long * n)(*[dz.shape[0] * dz.shape[1] * dz.shape[2] for dz, _ in jobs])
+                cs = (ctypes.c_int * n)(*[l.cout for _, l in jobs])
+                outs = (ctypes.c_void_p * n)(*[l.db.data_ptr() for _, l in jobs])
+                nbytes = lib.unflow_colsum_batched_workspace_bytes(n, cs)
+                ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.dev)
+                plan.append((n, xs, lds, npx, cs, outs, ws))
+            self._bias_plan = plan
+        for n, xs, lds, npx, cs, outs, ws in self._bias_plan:
+            check(lib.unflow_colsum_batched(n, xs, lds, npx, cs, outs, ptr(ws), _lib.csz(ws.numel() * 4), stream()),
+                  "colsum_batched")
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -163,6 +163,74 @@ UNFLOW_API int unflow_l2_loss(const float* p, long n, float scale, float* loss_a
   return launch_status();
 }
 
+// Backward of stack_input_kernel wrt the coarse flow (train_all, flownet.py:51-54 without the stop_gradient): the flow
+// reaches the stage input three times — as channels 6..7, through the warp (8..10) and through |warp - first| (11..13).
+// Per full-resolution pixel the gradient of the upsampled flow is formed (image_warp's flow gradient, image_warp.py:26-73
+// by the chain rule; d|x| = sign(x), 0 at 0) and scattered to the <= 4 coarse pixels of the TF1 bilinear upsample.
+// d_prev is accumulated with float atomics (caller zeroes it): this optional path is not bit-reproducible.
+__global__ void stack_input_bwd_kernel(const float* __restrict__ dout, int ldo, const float* __restrict__ im,
+                                       const float* __restrict__ prev, float* __restrict__ d_prev, int shift, int N,
+                                       int H, int W, int h, int w, float fscale) {
+  const long npx = (long)N * H * W;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int n = (int)(i / ((long)W * H));
+    const long sb = (long)((n + shift) % N) * H * W;
+    const float4 a = reinterpret_cast<const float4*>(im)[i];
+    const float fy = (float)y * sy, fx = (float)x * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float2* pf = reinterpret_cast<const float2*>(prev) + (long)n * h * w;
+    const float2 tl = pf[(long)y0 * w + x0], tr = pf[(long)y0 * w + x1], bl = pf[(long)y1 * w + x0], br = pf[(long)y1 * w + x1];
+    const float tu = tl.x + (tr.x - tl.x) * lx, bu = bl.x + (br.x - bl.x) * lx;
+    const float tv = tl.y + (tr.y - tl.y) * lx, bv = bl.y + (br.y - bl.y) * lx;
+    const float u = (tu + (bu - tu) * ly) * fscale, v = (tv + (bv - tv) * ly) * fscale;
+    const float fu = floorf(u), fv = floorf(v);
+    const float xw = u - fu, yw = v - fv;
+    const float wa = (1.f - xw) * (1.f - yw), wb = (1.f - xw) * yw, wc = xw * (1.f - yw), wd = xw * yw;
+    const int xi = x + (int)fu, yi = y + (int)fv;
+    const int xa = min(max(xi, 0), W - 1), xb = min(max(xi + 1, 0), W - 1);
+    const int ya = min(max(yi, 0), H - 1), yb = min(max(yi + 1, 0), H - 1);
+    const float4 Ia = reinterpret_cast<const float4*>(im)[sb + (long)ya * W + xa];
+    const float4 Ib = reinterpret_cast<const float4*>(im)[sb + (long)yb * W + xa];
+    const float4 Ic = reinterpret_cast<const float4*>(im)[sb + (long)ya * W + xb];
+    const float4 Id = reinterpret_cast<const float4*>(im)[sb + (long)yb * W + xb];
+    const float* g = dout + i * ldo;
+    const float ia[3] = {Ia.x, Ia.y, Ia.z}, ib[3] = {Ib.x, Ib.y, Ib.z}, ic[3] = {Ic.x, Ic.y, Ic.z}, id[3] = {Id.x, Id.y, Id.z};
+    const float first[3] = {a.x, a.y, a.z};
+    float du = g[6], dv = g[7];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float wv = ((wa * ia[c] + wb * ib[c]) + wc * ic[c]) + wd * id[c];
+      const float df = wv - first[c];
+      const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+      const float gc = g[8 + c] + sg * g[11 + c];
+      du += gc * ((ic[c] - ia[c]) * (1.f - yw) + (id[c] - ib[c]) * yw);
+      dv += gc * ((ib[c] - ia[c]) * (1.f - xw) + (id[c] - ic[c]) * xw);
+    }
+    du *= fscale;
+    dv *= fscale;
+    float* dp = d_prev + (long)n * h * w * 2;
+    const float wtl = (1.f - lx) * (1.f - ly), wtr = lx * (1.f - ly), wbl = (1.f - lx) * ly, wbr = lx * ly;
+    atomicAdd(dp + ((long)y0 * w + x0) * 2, du * wtl); atomicAdd(dp + ((long)y0 * w + x0) * 2 + 1, dv * wtl);
+    atomicAdd(dp + ((long)y0 * w + x1) * 2, du * wtr); atomicAdd(dp + ((long)y0 * w + x1) * 2 + 1, dv * wtr);
+    atomicAdd(dp + ((long)y1 * w + x0) * 2, du * wbl); atomicAdd(dp + ((long)y1 * w + x0) * 2 + 1, dv * wbl);
+    atomicAdd(dp + ((long)y1 * w + x1) * 2, du * wbr); atomicAdd(dp + ((long)y1 * w + x1) * 2 + 1, dv * wbr);
+  }
+}
+
+UNFLOW_API int unflow_stack_input_bwd(const float* d_out, int ld_out, const float* net_in4, const float* prev_flow2,
+                                      float* d_prev_flow2, int pair_shift, int N, int H, int W, int h, int w,
+                                      float flow_scale, unflow_stream_t stream) {
+  if (!d_out || !net_in4 || !prev_flow2 || !d_prev_flow2) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || ld_out < 14) return UNFLOW_ERR_SHAPE;
+  stack_input_bwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
+      d_out, ld_out, net_in4, prev_flow2, d_prev_flow2, pair_shift, N, H, W, h, w, flow_scale);
+  return launch_status();
+}
+
 __global__ void flow_error_sums_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                        const float* __restrict__ mask, float* __restrict__ out2, long npix) {
   __shared__ float red[4];
