@@ -178,10 +178,19 @@ def main():
         out["cpu_baseline"] = measure_cpu_baseline(H, W)
         if out["cpu_baseline"]["value"]:
             out["speedup_vs_cpu_baseline"] = round(pairs_per_s / out["cpu_baseline"]["value"], 1)
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1 or force_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    # The JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which is block-buffered
+    # when stdout is a pipe/file and would otherwise be flushed after Python's line at exit.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def measure_roofline(eng, args):
