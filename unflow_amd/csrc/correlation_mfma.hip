@@ -53,20 +53,24 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma_kernel(const CorrMfmaParams
   const int n1 = (n + p.shift) % p.B;
   const int y0 = oy + p.off;
 
-  float a[C / 2];
+  // f0 fragment source (clamped; masked by a select): it is RE-READ from L1/L2 in NCH chunks per Gram instead of
+  // living in C/2 registers for the whole kernel — 244 VGPRs allowed only 2 waves per SIMD, i.e. 1.5 rounds for the
+  // 3072 waves of the FlowNetC shape.
+  constexpr int NCH = C >= 128 ? 2 : 1;        // channel chunks per Gram
+  constexpr int CQ = C / 8 / NCH;              // float4 loads per chunk
+  const float* asrc;
+  bool aok;
   {
     const int ox = q + p.s2 * (i0 + l31), x0 = ox + p.off;
-    const bool ok = ox < p.ow && (unsigned)x0 < (unsigned)p.W && (unsigned)y0 < (unsigned)p.H;
-    const float* src = p.in0 + (((size_t)n * p.H + (ok ? y0 : 0)) * p.W + (ok ? x0 : 0)) * p.ld_in + 4 * h;
-#pragma unroll
-    for (int q8 = 0; q8 < C / 8; q8++) {
-      const float4 v = ok ? ldg4(src + 8 * q8) : make_float4(0, 0, 0, 0);
-      a[4 * q8] = v.x; a[4 * q8 + 1] = v.y; a[4 * q8 + 2] = v.z; a[4 * q8 + 3] = v.w;
-    }
+    aok = ox < p.ow && (unsigned)x0 < (unsigned)p.W && (unsigned)y0 < (unsigned)p.H;
+    asrc = p.in0 + (((size_t)n * p.H + (aok ? y0 : 0)) * p.W + (aok ? x0 : 0)) * p.ld_in + 4 * h;
   }
   const float cf = (float)C;
   const int per = (p.gw + 3) >> 2;
-  const int pa = pg * per, pb = min(p.gw, pa + per);
+  // the short last share (gw = 21: 6,6,6,3) rotates over the waves — wave w of every block sits on SIMD w, a fixed
+  // assignment would leave one SIMD of each CU with half the work
+  const int share = (pg + (int)blockIdx.x) & 3;
+  const int pa = share * per, pb = min(p.gw, pa + per);
   for (int pi = pa; pi < pb; pi++) {
     const int y2 = y0 + p.s2 * (pi - p.r);
     const bool rowok = (unsigned)y2 < (unsigned)p.H;
@@ -79,14 +83,24 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma_kernel(const CorrMfmaParams
       for (int r_ = 0; r_ < 16; r_++) acc[r_] = 0.f;
       if (__any(bok)) {
         const float* src = p.in1 + (((size_t)n1 * p.H + (bok ? y2 : 0)) * p.W + (bok ? xb : 0)) * p.ld_in + 4 * h;
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ch++) {
+          float4 a[CQ];
 #pragma unroll
-        for (int q8 = 0; q8 < C / 8; q8++) {
-          float4 v = ldg4(src + 8 * q8);      // src is clamped into the image: unconditional load, masked by selects
-          v.x = bok ? v.x : 0.f; v.y = bok ? v.y : 0.f; v.z = bok ? v.z : 0.f; v.w = bok ? v.w : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8], v.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8 + 1], v.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8 + 2], v.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q8 + 3], v.w, acc, 0, 0, 0);
+          for (int q8 = 0; q8 < CQ; q8++) {
+            a[q8] = ldg4(asrc + 8 * (ch * CQ + q8));
+            a[q8].x = aok ? a[q8].x : 0.f; a[q8].y = aok ? a[q8].y : 0.f;
+            a[q8].z = aok ? a[q8].z : 0.f; a[q8].w = aok ? a[q8].w : 0.f;
+          }
+#pragma unroll
+          for (int q8 = 0; q8 < CQ; q8++) {
+            float4 v = ldg4(src + 8 * (ch * CQ + q8));      // clamped address: unconditional load, masked by selects
+            v.x = bok ? v.x : 0.f; v.y = bok ? v.y : 0.f; v.z = bok ? v.z : 0.f; v.w = bok ? v.w : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q8].x, v.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q8].y, v.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q8].z, v.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q8].w, v.w, acc, 0, 0, 0);
+          }
         }
       }
       // band extraction: acc[r_] of lane (col j = l31, half h) is G[(r_&3) + 8*(r_>>2) + 4*h][j]
