@@ -269,7 +269,8 @@ def _pmc_traffic():
 def measure_cpu_baseline(H, W):
     """The reference's step on the host cores: the literal TF graph cannot run (no TensorFlow, GPU-only ops),
     so this times the CPU oracle restatement (oracle/model_ref.py: torch-CPU convs, C ops) — kind "port".
-    Bounded sample: 1 image pair, one warm-up + one timed fwd+bwd step."""
+    Bounded sample: 1 image pair per step, one warm-up + timed fwd+bwd steps until ~12 s of CPU work (<= 24 steps,
+    hard stop at 40 s)."""
     import torch
     try:
         from oracle import model_ref as M
@@ -282,14 +283,14 @@ def measure_cpu_baseline(H, W):
         im1 = torch.rand(1, H, W, 3, generator=g) * 255
         im2 = torch.rand(1, H, W, 3, generator=g) * 255
         times = []
-        for it in range(5):
+        for it in range(25):
             for v in P.values():
                 v.grad = None
             t0 = time.perf_counter()
             loss = M.unsupervised_loss(P, im1, im2)
             loss.backward()
             times.append(time.perf_counter() - t0)
-            if sum(times) > 40.0 and it >= 1:     # hard bound on the CPU leg
+            if it >= 1 and (sum(times) > 12.0 or sum(times) + times[-1] > 40.0):   # bounded CPU leg
                 break
         t = sum(times[1:]) / len(times[1:])
         return {"value": round(1.0 / t, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
