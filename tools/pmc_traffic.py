@@ -46,7 +46,7 @@ def main():
             continue
         out['kernels'][k] = dict(launches_per_step=round(fc[k] / nsteps, 2), read_MB=round(r / 1e6, 1),
                                  write_MB=round(ww / 1e6, 1))
-        if 'igemm' in k or 'splitk' in k or 'sum_partials' in k:
+        if any(f in k for f in ('igemm', 'splitk', 'sum_partials', 'head3_', 'skinny_conv', 'tiny_deconv')):   # bench.py's roofline class
             fam_r += r
             fam_w += ww
             fam_n += fc[k]
