@@ -213,6 +213,16 @@ int unflow_ternary_bwd(const float* gray1, const float* gray2w, const float* mas
                        const float* dist, float* d_gray2w, float weight, float normalizer, int max_distance,
                        int N, int H, int W, unflow_stream_t stream);
 
+/* Fused forms the step driver uses (same arithmetic, fewer launches per pyramid level):
+ * unflow_gray_pair        = unflow_rgb_to_gray255(im) + unflow_warp_gray_fwd(im, flow) in one launch;
+ * unflow_ternary_warp_bwd = unflow_ternary_bwd followed by unflow_warp_gray_bwd, without materialising d_gray2w
+ *                           (`dist` = the per-pixel weights left by unflow_ternary_fwd). */
+int unflow_gray_pair(const float* im, int ld_im, const float* flow, float flow_scale, float* gray1, float* gray2w,
+                     int pair_shift, int N, int H, int W, unflow_stream_t stream);
+int unflow_ternary_warp_bwd(const float* gray1, const float* gray2w, const float* dist, const float* im, int ld_im,
+                            const float* flow, float flow_scale, float* d_flow, int accumulate, int pair_shift,
+                            int max_distance, int N, int H, int W, unflow_stream_t stream);
+
 /* second_order_loss (losses.py:258-295) on flow*flow_scale; loss_acc[0] += weight * sum/normalizer;
  * d_flow (+)= gradient wrt the raw flow (includes flow_scale).  Either output may be NULL. */
 int unflow_second_order_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow,

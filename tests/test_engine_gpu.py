@@ -55,6 +55,15 @@ def test_loss_kernels_vs_oracle(D, dev):
     check(lib.unflow_warp_gray_bwd(ptr(dgray), ptr(imd), 3, ptr(fd), cf(fs), ptr(gflow), 1, B, N, h, w, st))
     assert abs(acc.item() - total.item()) <= 1e-5 * abs(total.item())
     assert _rel(gflow, fl.grad) < 2e-4
+    # the fused entry points the step driver uses are the same arithmetic: bit-identical results
+    g1f, g2f = torch.empty_like(gray1), torch.empty_like(gray2)
+    check(lib.unflow_gray_pair(ptr(imd), 3, ptr(fd), cf(fs), ptr(g1f), ptr(g2f), B, N, h, w, st))
+    assert torch.equal(g1f, gray1) and torch.equal(g2f, gray2)
+    gflow2 = torch.full((N, h, w, 2), 9.0, device=dev)
+    acc2 = torch.zeros(1, device=dev)
+    check(lib.unflow_second_order_fwd_bwd(ptr(fd), cf(fs), ptr(acc2), ptr(gflow2), 0, cf(lw * sw), cf(B * h * w * 4), N, h, w, st))
+    check(lib.unflow_ternary_warp_bwd(ptr(gray1), ptr(gray2), ptr(dist), ptr(imd), 3, ptr(fd), cf(fs), ptr(gflow2), 1, B, D, N, h, w, st))
+    assert torch.equal(gflow2, gflow)
 
 
 def _oracle_step(tf_params, im1, im2, dtype=torch.float32):

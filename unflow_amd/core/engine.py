@@ -556,17 +556,14 @@ class FlowNetEngine:
             # ---- data terms
             if wt('ternary'):
                 D = LAYER_PATCH_DISTANCES[i]
-                check(lib.unflow_rgb_to_gray255(ptr(lv['im']), 3, ptr(lv['gray1']), cl(N * h * w), st), "gray")
-                check(lib.unflow_warp_gray_fwd(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(lv['gray2w']), B, N, h, w, st),
-                      "warp_gray")
+                check(lib.unflow_gray_pair(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(lv['gray1']), ptr(lv['gray2w']), B, N, h,
+                                           w, st), "gray_pair")
                 check(lib.unflow_ternary_fwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(mask), n_mask, ptr(lv['dist']),
                                              ptr(self.loss_acc), cf(lw * wt('ternary')), cf(n1), D, N, h, w, st), "ternary")
                 if with_grad:
-                    check(lib.unflow_ternary_bwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(mask), n_mask, ptr(lv['dist']),
-                                                 ptr(lv['dgray']), cf(lw * wt('ternary')), cf(n1), D, N, h, w, st),
-                          "ternary_bwd")
-                    check(lib.unflow_warp_gray_bwd(ptr(lv['dgray']), ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(gflow), 1, B,
-                                                   N, h, w, st), "warp_gray_bwd")
+                    check(lib.unflow_ternary_warp_bwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(lv['dist']), ptr(lv['im']),
+                                                      3, ptr(flow), cf(fs), ptr(gflow), 1, B, D, N, h, w, st),
+                          "ternary_warp_bwd")
             if wt('photo'):
                 check(lib.unflow_photometric_fwd_bwd(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(mask), n_mask,
                                                      ptr(self.loss_acc), gf, 1, cf(lw * wt('photo')), cf(n1 * 3), B, N, h,

@@ -71,37 +71,66 @@ __global__ void warp_gray_fwd_kernel(const float* __restrict__ im, int ld, const
   }
 }
 
+// gray(im1) and gray(image_warp(im2, flow)) of a pyramid level in ONE launch (the two planes the census loss compares).
+__global__ void gray_pair_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow, float fscale,
+                                 float* __restrict__ gray1, float* __restrict__ gray2w, int shift, int N, int H, int W) {
+  const unsigned npx = (unsigned)N * H * W;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(i, W, H);
+    const int px = pp.x, py = pp.y, n = pp.n;
+    const long sb = (long)((n + shift) % N) * H * W;
+    const float* own = im + (size_t)i * ld;
+    gray1[i] = gray255(own[0], own[1], own[2]);
+    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
+    const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
+                *pd = im + (sb + t.id) * ld;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = ((t.wa * pa[k] + t.wb * pb[k]) + t.wc * pc[k]) + t.wd * pd[k];
+    gray2w[i] = gray255(c[0], c[1], c[2]);
+  }
+}
+
+// flow gradient of gray(image_warp(im, flow)) at one pixel, given d(loss)/d(gray) there (shared by warp_gray_bwd_kernel
+// and the fused census backward)
+__device__ __forceinline__ void warp_gray_bwd_pixel(float dg, const float* __restrict__ im, int ld,
+                                                    const float* __restrict__ flow, float fscale,
+                                                    float* __restrict__ dflow, int acc, int shift, int N, int H, int W,
+                                                    unsigned i, int px, int py, int n) {
+  const long sb = (long)((n + shift) % N) * H * W;
+  const float2 f = reinterpret_cast<const float2*>(flow)[i];
+  const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
+  const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
+              *pd = im + (sb + t.id) * ld;
+  const float g = dg * 255.0f;
+  const float gw[3] = {g * 0.2989f, g * 0.5870f, g * 0.1140f};
+  float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    ga += gw[k] * pa[k];
+    gb += gw[k] * pb[k];
+    gc += gw[k] * pc[k];
+    gd += gw[k] * pd[k];
+  }
+  float du = ((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw) * fscale;
+  float dv = ((gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw) * fscale;
+  float2* o = reinterpret_cast<float2*>(dflow) + i;
+  if (acc) {
+    const float2 e = *o;
+    du += e.x;
+    dv += e.y;
+  }
+  *o = make_float2(du, dv);
+}
+
 __global__ void warp_gray_bwd_kernel(const float* __restrict__ dgray, const float* __restrict__ im, int ld,
                                      const float* __restrict__ flow, float fscale, float* __restrict__ dflow, int acc,
                                      int shift, int N, int H, int W) {
   const unsigned npx = (unsigned)N * H * W;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
     const Pix pp = decode_pix(i, W, H);
-    const int px = pp.x, py = pp.y, n = pp.n;
-    const long sb = (long)((n + shift) % N) * H * W;
-    const float2 f = reinterpret_cast<const float2*>(flow)[i];
-    const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
-    const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
-                *pd = im + (sb + t.id) * ld;
-    const float g = dgray[i] * 255.0f;
-    const float gw[3] = {g * 0.2989f, g * 0.5870f, g * 0.1140f};
-    float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      ga += gw[k] * pa[k];
-      gb += gw[k] * pb[k];
-      gc += gw[k] * pc[k];
-      gd += gw[k] * pd[k];
-    }
-    float du = ((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw) * fscale;
-    float dv = ((gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw) * fscale;
-    float2* o = reinterpret_cast<float2*>(dflow) + i;
-    if (acc) {
-      const float2 e = *o;
-      du += e.x;
-      dv += e.y;
-    }
-    *o = make_float2(du, dv);
+    warp_gray_bwd_pixel(dgray[i], im, ld, flow, fscale, dflow, acc, shift, N, H, W, i, pp.x, pp.y, pp.n);
   }
 }
 
@@ -121,6 +150,15 @@ UNFLOW_API int unflow_warp_gray_bwd(const float* d_gray, const float* im, int ld
   if (N <= 0 || H <= 0 || W <= 0 || ld_im < 3) return UNFLOW_ERR_SHAPE;
   warp_gray_bwd_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(
       d_gray, im, ld_im, flow, flow_scale, d_flow, accumulate, pair_shift, N, H, W);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_gray_pair(const float* im, int ld_im, const float* flow, float flow_scale, float* gray1,
+                                float* gray2w, int pair_shift, int N, int H, int W, unflow_stream_t stream) {
+  if (!im || !flow || !gray1 || !gray2w) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || ld_im < 3) return UNFLOW_ERR_SHAPE;
+  gray_pair_kernel<<<stream_grid((long)N * H * W), 256, 0, as_stream(stream)>>>(im, ld_im, flow, flow_scale, gray1,
+                                                                                gray2w, pair_shift, N, H, W);
   return launch_status();
 }
 
@@ -190,9 +228,13 @@ __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restric
 }
 
 // Gather form: d/dG2(q) = sum_e f(q, q+e) * (Wt(q+e) + Wt(q)), see DESIGN.md (census backward).
+// With `im` non-null the pixel's d(loss)/d(gray2w) goes straight into the flow gradient (warp_gray_bwd_pixel) instead of
+// (or in addition to) the dg2 plane: one launch and one [N,H,W] round trip less per pyramid level.
 __global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                           const float* __restrict__ wgt, float* __restrict__ dg2, int D,
-                                                          int N, int H, int W) {
+                                                          int N, int H, int W, const float* __restrict__ im, int ld,
+                                                          const float* __restrict__ flow, float fscale,
+                                                          float* __restrict__ dflow, int acc, int shift) {
   __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW], tw[CT_LH * CT_LW];
   const int n = blockIdx.z, x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
   load_tile(t1, g1 + (long)n * H * W, x0, y0, D, H, W);
@@ -218,7 +260,9 @@ __global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restric
       const float dt2 = 0.81f * r2 * r2 * r2;               // dt/dz at z2
       grad -= dh * dt2 * ws;                                // dd/dt2 = -1, dz2/dG2(q) = +1
     }
-  dg2[(long)n * H * W + (long)y * W + x] = grad;
+  const unsigned i = (unsigned)(((long)n * H + y) * W + x);
+  if (dg2) dg2[i] = grad;
+  if (im) warp_gray_bwd_pixel(grad, im, ld, flow, fscale, dflow, acc, shift, N, H, W, i, x, y, n);
 }
 
 UNFLOW_API int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
@@ -241,7 +285,20 @@ UNFLOW_API int unflow_ternary_bwd(const float* gray1, const float* gray2w, const
   if (max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;
   (void)mask; (void)n_mask; (void)weight; (void)normalizer;   // already folded into `dist` (= dL/d dist) by the forward pass
   dim3 grid(cdiv(W, CT_W), cdiv(H, CT_H), N);
-  ternary_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(gray1, gray2w, dist, d_gray2w, max_distance, N, H, W);
+  ternary_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(gray1, gray2w, dist, d_gray2w, max_distance, N, H, W, nullptr, 0,
+                                                          nullptr, 0.f, nullptr, 0, 0);
+  return launch_status();
+}
+
+UNFLOW_API int unflow_ternary_warp_bwd(const float* gray1, const float* gray2w, const float* dist, const float* im,
+                                       int ld_im, const float* flow, float flow_scale, float* d_flow, int accumulate,
+                                       int pair_shift, int max_distance, int N, int H, int W, unflow_stream_t stream) {
+  if (!gray1 || !gray2w || !dist || !im || !flow || !d_flow) return UNFLOW_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || max_distance < 0 || ld_im < 3) return UNFLOW_ERR_SHAPE;
+  if (max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;
+  dim3 grid(cdiv(W, CT_W), cdiv(H, CT_H), N);
+  ternary_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(gray1, gray2w, dist, nullptr, max_distance, N, H, W, im, ld_im,
+                                                          flow, flow_scale, d_flow, accumulate, pair_shift);
   return launch_status();
 }
 
