@@ -1019,6 +1019,69 @@ __global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgra
   }
 }
 
+// ------------------------------------------------------------------ 1x1 conv, 32 output channels: data gradient
+// conv_redir (flownet.py:224, 256 -> 32, k1): dx[px, ci] (+)= sum_co dz[px, co] * w[ci, co].  K = 32 is ONE K-tile of the
+// implicit-GEMM kernel, which then is all prologue + epilogue (55 us, 7 TFLOP/s); this op is a stream over dx.  A lane owns
+// a channel quad with its 4 x 32 filter values in registers; the wave walks PW_S pixels whose dz rows are wave-uniform
+// (one coalesced 128-byte load + v_readlane broadcasts).
+constexpr int PW_S = 8, PW_CO = 32;
+__global__ __launch_bounds__(256) void pointwise32_dgrad_kernel(const SkinnyBwdParams p) {
+  const int lane = threadIdx.x & 63;
+  const int Cq = p.Cin >> 2, groups = (Cq + 63) / 64;
+  const long npix = (long)p.B * p.H * p.W;
+  const long nstrips = (npix + PW_S - 1) / PW_S;
+  const long job = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
+  if (job >= nstrips * groups) return;
+  const int g = (int)(job % groups);
+  const long p0 = (job / groups) * PW_S;
+  const bool active = g * 64 + lane < Cq;
+  const int c4 = min(g * 64 + lane, Cq - 1);
+  float wr[4][PW_CO];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int c = 0; c < PW_CO; c += 4) {
+      const float4 t = ldg4(p.w + (size_t)(c4 * 4 + j) * PW_CO + c);
+      wr[j][c] = t.x; wr[j][c + 1] = t.y; wr[j][c + 2] = t.z; wr[j][c + 3] = t.w;
+    }
+  float dzv[PW_S];
+#pragma unroll
+  for (int i = 0; i < PW_S; i++) {
+    const long px = min(p0 + i, npix - 1);
+    dzv[i] = p.dz[px * p.lddz + (lane & (PW_CO - 1))];
+  }
+#pragma unroll
+  for (int i = 0; i < PW_S; i++) {
+    if (p0 + i >= npix) break;     // wave-uniform
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < PW_CO; c++) {
+      const float gz = lane_bcast(dzv[i], c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) a[j] = fmaf(gz, wr[j][c], a[j]);
+    }
+    if (!active) continue;
+    const long pxl = p0 + i;
+    float* d = p.dx + pxl * p.lddx + c4 * 4;
+    float4 v = make_float4(a[0], a[1], a[2], a[3]);
+    if (p.accumulate) {
+      const float4 e = ldg4(d);
+      v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    if (p.act_src) {
+      const int n = c4 * 4;
+      if (n + 3 >= p.act_lo && n < p.act_hi) {
+        const float4 sa = ldg4(p.act_src + pxl * p.ld_act + n);
+        if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(sa.x);
+        if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(sa.y);
+        if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(sa.z);
+        if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(sa.w);
+      }
+    }
+    *reinterpret_cast<float4*>(d) = v;
+  }
+}
+
 // ------------------------------------------------------------------ tiny deconv (flowN_upM: 2 -> 2 channels, k4 s2)
 // y[b,oy,ox,co] = bias + sum over the <=4 valid taps: oy = 2*iy + ky - 1.
 template <int CI, int CO>
@@ -1675,6 +1738,14 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
     return launch_status();
   }
   if (Cout % 4 != 0 || lddz % 4 != 0) return UNFLOW_ERR_UNSUPPORTED;
+  if (k == 1 && stride == 1 && Cout == PW_CO && lddx % 4 == 0 && (!act_src || ld_act % 4 == 0) &&
+      (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(act_src) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    SkinnyBwdParams sp{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, 1, 0, 0};
+    const long jobs = (((long)B * H * W + PW_S - 1) / PW_S) * cdiv(Cin / 4, 64);
+    pointwise32_dgrad_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(sp);
+    return launch_status();
+  }
   GatherParams p{};
   const int bc = build_conv_dgrad(p, B, H, W, Cin, Cout, k, stride);
   if (bc != UNFLOW_OK) return bc;
