@@ -210,3 +210,22 @@ def test_warp_linearity_full_size(dev):
     assert (lhs - rhs).abs().max().item() < 1e-5
     ident = image_warp(a, torch.zeros_like(fl))
     assert torch.equal(ident, a)     # zero flow is the identity, bit-exact
+
+
+def test_empty_batch_is_a_no_op(dev):
+    """Empty inputs (B = 0): outputs of the right shape, nothing launched, no error."""
+    from unflow_amd import ops
+    im = torch.zeros(0, 8, 12, 3, device=dev)
+    fl = torch.zeros(0, 8, 12, 2, device=dev)
+    assert tuple(ops.backward_warp(im, fl).shape) == (0, 8, 12, 3)
+    assert tuple(ops.forward_warp(fl).shape) == (0, 8, 12, 1)
+    assert tuple(ops.downsample(im, 2).shape) == (0, 4, 6, 3)
+    from unflow_amd import _lib
+    from unflow_amd._lib import ptr, stream
+    lib = _lib.lib()
+    one = torch.zeros(4, device=dev)
+    # the C ABI itself: zero-sized problems return UNFLOW_OK before touching memory
+    assert lib.unflow_backward_warp_fwd(ptr(one), ptr(one), ptr(one), 0, 8, 12, 3, stream()) == 0
+    assert lib.unflow_downsample_fwd(ptr(one), ptr(one), 0, 8, 12, 3, 2, stream()) == 0
+    assert lib.unflow_adam_step(ptr(one), ptr(one), ptr(one), ptr(one), _lib.cl(0), _lib.cl(0), _lib.cf(1.0),
+                                _lib.cf(0.0), _lib.cf(1e-3), _lib.cf(0.9), _lib.cf(0.999), _lib.cf(1e-8), stream()) == 0

@@ -140,6 +140,8 @@ class _BackwardWarp(torch.autograd.Function):
 
 
 def backward_warp(images, flows):
+    if images.numel() == 0:      # empty batch: nothing to launch (the reference's kernel launch would cover 0 elements)
+        return torch.empty_like(images)
     return _BackwardWarp.apply(_dev(images, 'images'), _dev(flows, 'flows'))
 
 
@@ -181,6 +183,8 @@ class _ForwardWarp(torch.autograd.Function):
 
 def forward_warp(flows, deterministic=True):
     """ops.forward_warp (ops.py:75).  deterministic=False reproduces the reference's float-atomic scatter."""
+    if flows.numel() == 0:
+        return flows.new_empty(tuple(flows.shape[:3]) + (1,))
     return _ForwardWarp.apply(_dev(flows, 'flows'), deterministic)
 
 
@@ -198,6 +202,8 @@ def downsample(images, scale=2):
     B, H, W, C = images.shape
     if scale <= 0 or H % scale or W % scale:
         raise _lib.UnflowError(-4, "downsample")
+    if images.numel() == 0:
+        return images.new_empty((B, H // scale, W // scale, C))
     out = torch.empty((B, H // scale, W // scale, C), dtype=torch.float32, device=images.device)
     check(_lib.lib().unflow_downsample_fwd(ptr(images), ptr(out), B, H, W, C, int(scale), stream()), "downsample")
     return out
