@@ -245,6 +245,26 @@ int unflow_mask_terms(const float* flow, const float* warped_other, const float*
                       float* d_warped, int accumulate, float fb_weight, float occ_weight, float sym_weight,
                       int batch_per_direction, int pair_shift, int N, int H, int W, unflow_stream_t stream);
 
+/* compute_losses with the DEFAULT terms (ternary/census + second-order smoothness, config.ini [train]) over the whole
+ * loss pyramid (unsupervised.py:85-147) in four launches instead of four per level.  Same arithmetic as
+ * unflow_second_order_fwd_bwd + unflow_gray_pair + unflow_ternary_fwd + unflow_ternary_warp_bwd per level.
+ * ternary_scale / smooth_scale are the complete factors layer_weight * term_weight / normaliser of the level.
+ * loss_acc[0] += the weighted loss; with_grad: d_flow of every level is OVERWRITTEN with d loss / d flow. */
+#define UNFLOW_MAX_PYR_LEVELS 7
+typedef struct unflow_pyr_level {
+  const float* im;      /* [N,H,W,3] images in [0,1] of this level */
+  const float* flow;    /* [N,H,W,2] raw network flow of this level */
+  float* gray1;         /* [N,H,W] scratch */
+  float* gray2w;        /* [N,H,W] scratch */
+  const float* mask;    /* [n_mask,H,W] */
+  float* dist;          /* [N,H,W] scratch (per-pixel census weights) */
+  float* d_flow;        /* [N,H,W,2] out (may be NULL when with_grad == 0) */
+  int H, W, n_mask, max_distance;
+  float flow_scale, ternary_scale, smooth_scale;
+} unflow_pyr_level;
+int unflow_loss_pyramid_default(const unflow_pyr_level* levels, int n_levels, int N, int pair_shift, float* loss_acc,
+                                int with_grad, unflow_stream_t stream);
+
 /* photometric_loss (losses.py:198-199): charbonnier(im1 - image_warp(im2, flow), mask, beta=255), fused with the warp;
  * loss_acc[0] += weight*sum/normalizer; d_flow (+)= gradient wrt the raw flow.  mask: [n_mask,H,W]. */
 int unflow_photometric_fwd_bwd(const float* im, int ld_im, const float* flow, float flow_scale, const float* mask,

@@ -387,3 +387,26 @@ def test_train_all_stack_vs_oracle(dev):
             assert ((a - gref).abs().mean() / (gref.abs().mean() + 1e-30)).item() < 5e-3, k
     assert first_net > 20
     assert eng.grad_buckets()[0] == []
+
+
+def test_fused_loss_pyramid_equals_per_level_path(dev):
+    """unflow_loss_pyramid_default (four launches for all levels) vs the per-level entry points: same arithmetic, so the
+    flow gradients are bit-identical and the loss agrees to the order of its float-atomic block sums."""
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 2, 128, 192
+    g = torch.Generator().manual_seed(51)
+    im1 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
+    im2 = (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=3)
+    eng.set_input(im1, im2)
+    eng.forward_net()
+    for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):      # flows of realistic magnitude
+        eng.act['flow%d' % lvl].copy_((torch.randn(2 * B, H // d, W // d, 2, generator=g) * (1.5 / (lvl - 1))).to(dev))
+    res = {}
+    for fused in (True, False):
+        eng.fused_pyramid = fused
+        loss = eng.forward_loss(with_grad=True).item()
+        res[fused] = (loss, [eng.grad['flow%d' % l].clone() for l in (2, 3, 4, 5, 6)])
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)

@@ -24,6 +24,7 @@ import math
 import os
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -314,6 +315,8 @@ class FlowNetEngine:
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
         self.defer_l2 = False      # True: forward_loss leaves the L2 term to adam_step (train_step / bench)
+        self.fused_pyramid = os.environ.get('UNFLOW_FUSED_PYRAMID', '1') != '0'   # default loss terms: 4 launches for all levels
+        self._pyr_cache = None
         # optional second HIP stream for filter gradients (see _Stage._bwd), off by default: both variants measured
         # slower inside the captured graph on MI355X — 'all' 397 vs 405 pairs/s, 'small' (only the latency-bound flow
         # heads / 2->2 deconvs) 438.6 vs 445.2
@@ -501,6 +504,12 @@ class FlowNetEngine:
         need_fbwarp = bool(wt('fb')) or occl == 1
         need_fwarp = bool(wt('sym')) or occl == 2
         need_mask_terms = need_fbwarp or need_fwarp or bool(wt('occ')) or not use_border
+        # the default terms (config.ini [train]: ternary + second-order, border mask): the whole pyramid in four launches
+        if (not need_mask_terms and wt('ternary') and wt('smooth_2nd')
+                and not any(wt(k) for k in ('smooth_1st', 'photo', 'grad')) and self.fused_pyramid):
+            check(lib.unflow_loss_pyramid_default(self._pyramid_levels(levels, wt), len(levels), N, B, ptr(self.loss_acc),
+                                                  int(bool(with_grad)), st), "loss_pyramid")
+            levels = []
         for i, lv in enumerate(levels):
             h, w = lv['h'], lv['w']
             fs = FLOW_SCALE / (2 ** i)
@@ -586,6 +595,32 @@ class FlowNetEngine:
         if not self.defer_l2:
             check(lib.unflow_l2_loss(ptr(self.P), cl(self.n_weights), cf(L2_SCALE), ptr(self.loss_acc), st), "l2_loss")
         return self.loss_acc
+
+    def _pyramid_levels(self, levels, wt):
+        """ctypes array of unflow_pyr_level for unflow_loss_pyramid_default (rebuilt when the mask pointers change)."""
+        import ctypes
+
+        class Level(ctypes.Structure):
+            _fields_ = [(k, ctypes.c_void_p) for k in ('im', 'flow', 'gray1', 'gray2w', 'mask', 'dist', 'd_flow')] + \
+                       [(k, ctypes.c_int) for k in ('H', 'W', 'n_mask', 'max_distance')] + \
+                       [(k, ctypes.c_float) for k in ('flow_scale', 'ternary_scale', 'smooth_scale')]
+        key = tuple(lv['mask'].data_ptr() for lv in levels) + (wt('ternary'), wt('smooth_2nd'))
+        if self._pyr_cache is None or self._pyr_cache[0] != key:
+            arr = (Level * len(levels))()
+            for i, lv in enumerate(levels):
+                n1 = self.B * lv['h'] * lv['w']
+                lw = LAYER_WEIGHTS[i]
+                a = arr[i]
+                a.im, a.flow, a.gray1, a.gray2w = lv['im'].data_ptr(), lv['flow'].data_ptr(), lv['gray1'].data_ptr(), \
+                    lv['gray2w'].data_ptr()
+                a.mask, a.dist, a.d_flow = lv['mask'].data_ptr(), lv['dist'].data_ptr(), lv['gflow'].data_ptr()
+                a.H, a.W, a.n_mask, a.max_distance = lv['h'], lv['w'], lv['n_mask'], LAYER_PATCH_DISTANCES[i]
+                a.flow_scale = FLOW_SCALE / (2 ** i)
+                f32 = np.float32    # the same fp32 quotient the per-level entry points form from (weight, normaliser)
+                a.ternary_scale = float(f32(lw * wt('ternary')) / f32(n1))            # normaliser B*H*W*1 (losses.py:311-312)
+                a.smooth_scale = float(f32(lw * wt('smooth_2nd')) / f32(n1 * 4))      # B*H*W*4 per flow channel
+            self._pyr_cache = (key, arr)
+        return self._pyr_cache[1]
 
     def _level_extra(self, lv):
         """Buffers only the non-default loss terms need (allocated on first use, before any graph capture)."""

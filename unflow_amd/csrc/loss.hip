@@ -72,10 +72,11 @@ __global__ void warp_gray_fwd_kernel(const float* __restrict__ im, int ld, const
 }
 
 // gray(im1) and gray(image_warp(im2, flow)) of a pyramid level in ONE launch (the two planes the census loss compares).
-__global__ void gray_pair_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow, float fscale,
-                                 float* __restrict__ gray1, float* __restrict__ gray2w, int shift, int N, int H, int W) {
+__device__ __forceinline__ void gray_pair_body(const float* __restrict__ im, int ld, const float* __restrict__ flow,
+                                               float fscale, float* __restrict__ gray1, float* __restrict__ gray2w,
+                                               int shift, int N, int H, int W, unsigned vb, unsigned vg) {
   const unsigned npx = (unsigned)N * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+  for (unsigned i = vb * blockDim.x + threadIdx.x; i < npx; i += vg * blockDim.x) {
     const Pix pp = decode_pix(i, W, H);
     const int px = pp.x, py = pp.y, n = pp.n;
     const long sb = (long)((n + shift) % N) * H * W;
@@ -90,6 +91,10 @@ __global__ void gray_pair_kernel(const float* __restrict__ im, int ld, const flo
     for (int k = 0; k < 3; k++) c[k] = ((t.wa * pa[k] + t.wb * pb[k]) + t.wc * pc[k]) + t.wd * pd[k];
     gray2w[i] = gray255(c[0], c[1], c[2]);
   }
+}
+__global__ void gray_pair_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow, float fscale,
+                                 float* __restrict__ gray1, float* __restrict__ gray2w, int shift, int N, int H, int W) {
+  gray_pair_body(im, ld, flow, fscale, gray1, gray2w, shift, N, H, W, blockIdx.x, gridDim.x);
 }
 
 // flow gradient of gray(image_warp(im, flow)) at one pixel, given d(loss)/d(gray) there (shared by warp_gray_bwd_kernel
@@ -182,10 +187,10 @@ __device__ __forceinline__ void load_tile(float* __restrict__ lds, const float* 
   }
 }
 
-__global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                          const float* __restrict__ mask, int n_mask,
-                                                          float* __restrict__ wgt_out, float* __restrict__ loss_acc,
-                                                          float scale, int D, int N, int H, int W) {
+__device__ __forceinline__ void ternary_fwd_body(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                 const float* __restrict__ mask, int n_mask,
+                                                 float* __restrict__ wgt_out, float* __restrict__ loss_acc, float scale,
+                                                 int D, int N, int H, int W, unsigned vb, unsigned vg) {
   __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW];
   __shared__ float red[4];
   const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restric
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   float local = 0.f;
   // grid-stride over tiles: one loss atomic per BLOCK, not per tile (49k same-address atomics at 768x1024x16)
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = (int)vb; tile < ntiles; tile += (int)vg) {
     const int n = tile / (tiles_x * tiles_y), tr = tile - n * tiles_x * tiles_y;
     const int x0 = (tr % tiles_x) * CT_W, y0 = (tr / tiles_x) * CT_H;
     __syncthreads();   // previous tile fully consumed
@@ -226,17 +231,25 @@ __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restric
   const float t = block_sum(local, red);
   if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
 }
+__global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          const float* __restrict__ mask, int n_mask,
+                                                          float* __restrict__ wgt_out, float* __restrict__ loss_acc,
+                                                          float scale, int D, int N, int H, int W) {
+  ternary_fwd_body(g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, blockIdx.x, gridDim.x);
+}
 
 // Gather form: d/dG2(q) = sum_e f(q, q+e) * (Wt(q+e) + Wt(q)), see DESIGN.md (census backward).
 // With `im` non-null the pixel's d(loss)/d(gray2w) goes straight into the flow gradient (warp_gray_bwd_pixel) instead of
 // (or in addition to) the dg2 plane: one launch and one [N,H,W] round trip less per pyramid level.
-__global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                          const float* __restrict__ wgt, float* __restrict__ dg2, int D,
-                                                          int N, int H, int W, const float* __restrict__ im, int ld,
-                                                          const float* __restrict__ flow, float fscale,
-                                                          float* __restrict__ dflow, int acc, int shift) {
+__device__ __forceinline__ void ternary_bwd_body(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                 const float* __restrict__ wgt, float* __restrict__ dg2, int D, int N,
+                                                 int H, int W, const float* __restrict__ im, int ld,
+                                                 const float* __restrict__ flow, float fscale, float* __restrict__ dflow,
+                                                 int acc, int shift, unsigned tile) {
   __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW], tw[CT_LH * CT_LW];
-  const int n = blockIdx.z, x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+  const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
+  const int n = (int)tile / (tiles_x * tiles_y), tr = (int)tile - n * tiles_x * tiles_y;
+  const int x0 = (tr % tiles_x) * CT_W, y0 = (tr / tiles_x) * CT_H;
   load_tile(t1, g1 + (long)n * H * W, x0, y0, D, H, W);
   load_tile(t2, g2 + (long)n * H * W, x0, y0, D, H, W);
   load_tile(tw, wgt + (long)n * H * W, x0, y0, D, H, W);   // zero outside the image == "no such centre pixel"
@@ -264,6 +277,13 @@ __global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restric
   if (dg2) dg2[i] = grad;
   if (im) warp_gray_bwd_pixel(grad, im, ld, flow, fscale, dflow, acc, shift, N, H, W, i, x, y, n);
 }
+__global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          const float* __restrict__ wgt, float* __restrict__ dg2, int D,
+                                                          int N, int H, int W, const float* __restrict__ im, int ld,
+                                                          const float* __restrict__ flow, float fscale,
+                                                          float* __restrict__ dflow, int acc, int shift) {
+  ternary_bwd_body(g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, blockIdx.x);
+}
 
 UNFLOW_API int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
                                   float* dist_out, float* loss_acc, float weight, float normalizer, int max_distance,
@@ -284,7 +304,7 @@ UNFLOW_API int unflow_ternary_bwd(const float* gray1, const float* gray2w, const
   if (N <= 0 || H <= 0 || W <= 0 || max_distance < 0) return UNFLOW_ERR_SHAPE;
   if (max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;
   (void)mask; (void)n_mask; (void)weight; (void)normalizer;   // already folded into `dist` (= dL/d dist) by the forward pass
-  dim3 grid(cdiv(W, CT_W), cdiv(H, CT_H), N);
+  const int grid = cdiv(W, CT_W) * cdiv(H, CT_H) * N;
   ternary_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(gray1, gray2w, dist, d_gray2w, max_distance, N, H, W, nullptr, 0,
                                                           nullptr, 0.f, nullptr, 0, 0);
   return launch_status();
@@ -296,7 +316,7 @@ UNFLOW_API int unflow_ternary_warp_bwd(const float* gray1, const float* gray2w, 
   if (!gray1 || !gray2w || !dist || !im || !flow || !d_flow) return UNFLOW_ERR_NULL;
   if (N <= 0 || H <= 0 || W <= 0 || max_distance < 0 || ld_im < 3) return UNFLOW_ERR_SHAPE;
   if (max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;
-  dim3 grid(cdiv(W, CT_W), cdiv(H, CT_H), N);
+  const int grid = cdiv(W, CT_W) * cdiv(H, CT_H) * N;
   ternary_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(gray1, gray2w, dist, nullptr, max_distance, N, H, W, im, ld_im,
                                                           flow, flow_scale, d_flow, accumulate, pair_shift);
   return launch_status();
@@ -312,14 +332,14 @@ __device__ __forceinline__ float charb_grad(float x) {
   return CHARB_ALPHA * fast_pow(x * x + CHARB_EPS * CHARB_EPS, CHARB_ALPHA - 1.f) * 2.f * x;
 }
 
-__global__ __launch_bounds__(256) void second_order_kernel(const float* __restrict__ flow, float fs,
-                                                           float* __restrict__ loss_acc, float* __restrict__ dflow,
-                                                           int acc, float scale, int N, int H, int W) {
+__device__ __forceinline__ void second_order_body(const float* __restrict__ flow, float fs, float* __restrict__ loss_acc,
+                                                  float* __restrict__ dflow, int acc, float scale, int N, int H, int W,
+                                                  unsigned vb, unsigned vg) {
   __shared__ float red[4];
   const long npx = (long)N * H * W;
   const int ady[4] = {0, 1, 1, 1}, adx[4] = {1, 0, 1, -1};
   float local = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
+  for (long i = vb * (long)blockDim.x + threadIdx.x; i < npx; i += (long)vg * blockDim.x) {
     const int x = (int)(i % W), y = (int)((i / W) % H);
     const long n = i / ((long)W * H);
     const float2* f = reinterpret_cast<const float2*>(flow) + n * H * W;
@@ -364,6 +384,85 @@ __global__ __launch_bounds__(256) void second_order_kernel(const float* __restri
   }
   const float t = block_sum(local, red);
   if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
+}
+__global__ __launch_bounds__(256) void second_order_kernel(const float* __restrict__ flow, float fs,
+                                                           float* __restrict__ loss_acc, float* __restrict__ dflow,
+                                                           int acc, float scale, int N, int H, int W) {
+  second_order_body(flow, fs, loss_acc, dflow, acc, scale, N, H, W, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------ the default loss pyramid in four launches
+// compute_losses with the default terms (ternary + second-order, border mask; config.ini [train]) over all pyramid
+// levels: each of the four kernel types runs ONCE for all levels — a block finds its level from a prefix table and runs
+// that level's body.  At 16k..48 pixels per sample the per-level launches were pure latency (~5 us each, 20 per step).
+struct PyrLevelDev {
+  const float* im; const float* flow; float* gray1; float* gray2w; const float* mask; float* dist; float* dflow;
+  int H, W, n_mask, D;
+  float fs, scale_tern, scale_smooth;
+  int b_so, b_gp, b_tf, b_tb;      // first block of this level in each of the four launches
+};
+struct PyrArgs {
+  PyrLevelDev lv[UNFLOW_MAX_PYR_LEVELS + 1];   // [n] holds the end offsets
+  int n, N, shift;
+  float* loss_acc;
+};
+#define PYR_FIND_LEVEL(FIELD)                                                        \
+  int l = 0;                                                                         \
+  while (l + 1 < a.n && (int)blockIdx.x >= a.lv[l + 1].FIELD) l++;                   \
+  const PyrLevelDev& L = a.lv[l];                                                    \
+  const unsigned vb = blockIdx.x - L.FIELD, vg = a.lv[l + 1].FIELD - L.FIELD;
+
+__global__ __launch_bounds__(256) void pyr_second_order_kernel(const PyrArgs a) {
+  PYR_FIND_LEVEL(b_so)
+  second_order_body(L.flow, L.fs, a.loss_acc, L.dflow, 0, L.scale_smooth, a.N, L.H, L.W, vb, vg);
+}
+__global__ __launch_bounds__(256) void pyr_gray_pair_kernel(const PyrArgs a) {
+  PYR_FIND_LEVEL(b_gp)
+  gray_pair_body(L.im, 3, L.flow, L.fs, L.gray1, L.gray2w, a.shift, a.N, L.H, L.W, vb, vg);
+}
+__global__ __launch_bounds__(256) void pyr_ternary_fwd_kernel(const PyrArgs a) {
+  PYR_FIND_LEVEL(b_tf)
+  ternary_fwd_body(L.gray1, L.gray2w, L.mask, L.n_mask, L.dist, a.loss_acc, L.scale_tern, L.D, a.N, L.H, L.W, vb, vg);
+}
+__global__ __launch_bounds__(256) void pyr_ternary_bwd_kernel(const PyrArgs a) {
+  PYR_FIND_LEVEL(b_tb)
+  (void)vg;
+  ternary_bwd_body(L.gray1, L.gray2w, L.dist, nullptr, L.D, a.N, L.H, L.W, L.im, 3, L.flow, L.fs, L.dflow, 1, a.shift, vb);
+}
+
+UNFLOW_API int unflow_loss_pyramid_default(const unflow_pyr_level* levels, int n_levels, int N, int pair_shift,
+                                           float* loss_acc, int with_grad, unflow_stream_t stream) {
+  if (!levels || !loss_acc) return UNFLOW_ERR_NULL;
+  if (n_levels <= 0 || n_levels > UNFLOW_MAX_PYR_LEVELS || N <= 0) return UNFLOW_ERR_SHAPE;
+  PyrArgs a{};
+  a.n = n_levels; a.N = N; a.shift = pair_shift; a.loss_acc = loss_acc;
+  int so = 0, gp = 0, tf = 0, tb = 0;
+  for (int l = 0; l < n_levels; l++) {
+    const unflow_pyr_level& s = levels[l];
+    if (!s.im || !s.flow || !s.gray1 || !s.gray2w || !s.mask || !s.dist || (with_grad && !s.d_flow)) return UNFLOW_ERR_NULL;
+    if (s.H <= 0 || s.W <= 0 || s.n_mask <= 0 || s.max_distance < 0) return UNFLOW_ERR_SHAPE;
+    if (s.max_distance > CT_MAXD) return UNFLOW_ERR_UNSUPPORTED;
+    PyrLevelDev& d = a.lv[l];
+    d.im = s.im; d.flow = s.flow; d.gray1 = s.gray1; d.gray2w = s.gray2w; d.mask = s.mask; d.dist = s.dist;
+    d.dflow = with_grad ? s.d_flow : nullptr;
+    d.H = s.H; d.W = s.W; d.n_mask = s.n_mask; d.D = s.max_distance;
+    d.fs = s.flow_scale; d.scale_tern = s.ternary_scale; d.scale_smooth = s.smooth_scale;
+    d.b_so = so; d.b_gp = gp; d.b_tf = tf; d.b_tb = tb;
+    const long npx = (long)N * s.H * s.W;
+    const long ntiles = (long)cdiv(s.W, CT_W) * cdiv(s.H, CT_H) * N;
+    so += stream_grid(npx);
+    gp += stream_grid(npx);
+    tf += (int)min(ntiles, (long)2048);
+    tb += (int)ntiles;
+  }
+  PyrLevelDev& e = a.lv[n_levels];
+  e.b_so = so; e.b_gp = gp; e.b_tf = tf; e.b_tb = tb;
+  hipStream_t st = as_stream(stream);
+  pyr_second_order_kernel<<<so, 256, 0, st>>>(a);
+  pyr_gray_pair_kernel<<<gp, 256, 0, st>>>(a);
+  pyr_ternary_fwd_kernel<<<tf, 256, 0, st>>>(a);
+  if (with_grad) pyr_ternary_bwd_kernel<<<tb, 256, 0, st>>>(a);
+  return launch_status();
 }
 
 UNFLOW_API int unflow_second_order_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow,
