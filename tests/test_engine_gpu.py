@@ -225,8 +225,8 @@ def test_flownet_s_and_stacks_vs_oracle(spec, dev):
             assert got[k].abs().max().item() == 0.0 and gref.abs().max().item() < 1e-12, k   # frozen stage
         else:
             # single net: fp32-vs-fp64 noise only; stacks: the refinement input (warp by the previous net's fp32 flow,
-            # |.|, leaky kinks) amplifies that noise ~10x per stage
-            tol = 3e-4 * 10 ** (len(spec) - 1) if len(spec) < 3 else 1e-2
+            # |.|, leaky kinks) amplifies that noise (observed 2e-3 .. 7e-3 depending on the rounding realisation)
+            tol = 3e-4 if len(spec) == 1 else 1e-2
             if got[k].numel() <= 4:      # 2-element bias gradients after three stages of noise amplification
                 tol *= 5
             assert _rel(got[k], gref) < tol, (k, _rel(got[k], gref))

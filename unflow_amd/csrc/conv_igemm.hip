@@ -21,6 +21,7 @@
 // caller workspace and a fixed-order reduce applies the epilogue (deterministic, no float atomics).
 #include <stdlib.h>
 #include <cstdint>
+#include <cstring>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -77,6 +78,32 @@ __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// ---- fp32-equivalent products on the bf16 matrix cores (MATH == 1) -------------------------------------------------------
+// x = hi + mid + lo with three bf16 values (3 x 8 significand bits = the 24 of fp32, same exponent range); a*b is summed
+// from the six terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 (fp32 accumulation); the
+// dropped terms are <= 2^-23 |a||b|.  Measured (tools/microbench/bf16x3_accuracy.hip, K = 4608): rms error 2.5e-8 of
+// sum|a||b| against 2.8e-8 for v_mfma_f32_32x32x2_f32 — the same accuracy class, at 1/16 of the matrix-core time per
+// product term.  The split happens once per element while the tile is staged into LDS (v_cvt_pk_bf16_f32, gfx950).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDH = BK + 8;   // bf16 row pitch of one plane: 80 bytes (16-byte aligned rows, conflict-free b128 reads)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// four consecutive k of one row -> three planes, 8 bytes each
+__device__ __forceinline__ void split_store(unsigned short* __restrict__ dst, int plane_stride, const float4 v) {
+  const unsigned h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+  const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+  const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+  const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xffff0000u);
+  const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xffff0000u);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(dst + plane_stride) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(dst + 2 * plane_stride) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+}
+
 // LDS operand layout: [row][LDK] with LDK = 36 floats (16-byte aligned rows, conflict-free for the
 // 128-bit reads and writes used below).  K order inside a tile is permuted: wave half lh (lanes 32*lh..)
 // supplies k = 16*lh + s at MFMA step s, so one ds_read_b128 feeds 4 consecutive steps.  Both operands
@@ -87,12 +114,13 @@ __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int
 // there: an in-order wave then always has an MFMA within a few instructions, instead of a ~300
 // instruction load prologue during which its SIMD's matrix pipe idles (and co-resident waves lock-step).
 // All predication is by address select + value select — no divergent branches in the loop.
-template <int BM, int BN, int WM, int WN, bool B_NK>
+template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
   constexpr int A_ELEMS = BM * LDK;
+  constexpr int A_PLANE = BM * LDH, B_PLANE = BN * LDH;   // MATH == 1: bf16 planes [3][rows][LDH]
   constexpr int AR = BM / 32;                 // A rows per thread (quad column kq fixed)
   constexpr int BR_NK = BN / 32;              // B rows per thread, K-contiguous weights
   constexpr int KG = 256 / BN;                // KN weights: thread = (n, k-group); k-quads kq = kg + KG*i
@@ -102,7 +130,9 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + A_ELEMS;
-  int* pix = reinterpret_cast<int*>(smem + A_ELEMS + BN * LDK);
+  unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bh = Ah + 3 * A_PLANE;
+  int* pix = MATH ? reinterpret_cast<int*>(Bh + 3 * B_PLANE) : reinterpret_cast<int*>(smem + A_ELEMS + BN * LDK);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -233,6 +263,18 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   static_assert(AR + NB + 2 <= 16, "pieces must fit the 16 steps");
 
   auto store_tile = [&]() {
+    if constexpr (MATH == 1) {
+#pragma unroll
+      for (int i = 0; i < AR; i++) split_store(Ah + ((tid >> 3) + 32 * i) * LDH + kq * 4, A_PLANE, ra[i]);
+      if constexpr (B_NK) {
+#pragma unroll
+        for (int i = 0; i < BR_NK; i++) split_store(Bh + ((tid >> 3) + 32 * i) * LDH + kq * 4, B_PLANE, rb[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < BQ_KN; i++) split_store(Bh + (tid % BN) * LDH + 4 * ((tid / BN) + KG * i), B_PLANE, rb[i]);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AR; i++)
       *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * i) * LDK + kq * 4) = ra[i];
@@ -263,8 +305,39 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   __syncthreads();
   const float* a_rd = As + (wm * WM + l31) * LDK + 16 * lh;
   const float* b_rd = Bs + (wn * WN + l31) * LDK + 16 * lh;
+  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH + 8 * lh;
+  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH + 8 * lh;
   for (int kt = kt0; kt < kt1; kt++) {
     live = (kt + 1 < kt1) && !(p.dbg & 1);
+    if constexpr (MATH == 1) {
+      // two K16 slabs per tile; lane (row l31, half lh) holds k = 16*slab + 8*lh .. +7 of its row for both operands
+#pragma unroll
+      for (int slab = 0; slab < 2; slab++) {
+        bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+            av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 16 * slab);
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 16 * slab);
+        }
+        constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ta[t]][i], bv[tb[t]][j], acc[i][j], 0, 0, 0);
+          piece(slab * 6 + t, kt + 1);          // 12 of the 16 load pieces sit between the term groups ...
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int st = 12; st < 16; st++) piece(st, kt + 1);   // ... the rest (if any) right after
+    } else {
 #pragma unroll
     for (int j4 = 0; j4 < 4; j4++) {
       float4 av[TM], bv[TN];
@@ -282,6 +355,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
         piece(j4 * 4 + e, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
     if (!(p.dbg & 2)) __syncthreads();  // every wave is done reading this tile
     if (!(p.dbg & 4)) store_tile();     // (last iteration: zeros, never read)
@@ -1422,6 +1496,12 @@ inline int fill_one_round(long blocks, int slots, int max_split) {
   return ns < 1 ? 1 : ns;
 }
 
+// UNFLOW_CONV_MATH=bf16x3: the 128-row gather tiles compute on the bf16 matrix cores (3-way split, fp32-equivalent)
+inline bool conv_math_bf16x3() {
+  static const bool on = getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "bf16x3");
+  return on;
+}
+
 inline GatherPlan plan_gather(const GatherParams& p) {
   GatherPlan pl;
   const long M = (long)p.B * p.Hg * p.Wg;
@@ -1442,7 +1522,8 @@ inline GatherPlan plan_gather(const GatherParams& p) {
   static const int tall = getenv("UNFLOW_GATHER_TALL") ? atoi(getenv("UNFLOW_GATHER_TALL")) : 0;   // tuning knob
   if (pl.cfg == 1 && tall && M * p.ncls >= 256L * 768) pl.cfg = 3;
   const int bm = pl.cfg == 2 ? 64 : pl.cfg == 3 ? 256 : 128, bn = pl.cfg == 0 ? 128 : 64;
-  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : pl.cfg == 3 ? 3 : 6);
+  const bool b3 = conv_math_bf16x3();   // 60 KB / 45 KB of LDS per block instead of 37 / 28
+  const int slots = 256 * (pl.cfg == 0 ? (b3 ? 2 : 3) : pl.cfg == 1 ? (b3 ? 3 : 4) : pl.cfg == 3 ? 3 : 6);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
   return pl;
@@ -1531,18 +1612,19 @@ inline int reduce_partials(const float* partial, float* scratch, float* out, siz
   return launch_status();
 }
 
-template <int BM, int BN, int WM, int WN, bool B_NK>
+template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0>
 int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
-  const size_t smem = (size_t)(BM + BN) * LDK * sizeof(float) + BM * sizeof(int);
+  const size_t smem = (MATH ? (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short) : (size_t)(BM + BN) * LDK * sizeof(float)) +
+                      BM * sizeof(int);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
-  igemm_gather_kernel<BM, BN, WM, WN, B_NK><<<grid, 256, smem, st>>>(p);
+  igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH><<<grid, 256, smem, st>>>(p);
   return launch_status();
 }
 
@@ -1562,8 +1644,10 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   }
   int code;
   switch (pl.cfg) {
-    case 0: code = launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st); break;
-    case 1: code = launch_gather_cfg<128, 64, 64, 32, B_NK>(p, st); break;
+    case 0: code = conv_math_bf16x3() ? launch_gather_cfg<128, 128, 64, 64, B_NK, 1>(p, st)
+                                      : launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st); break;
+    case 1: code = conv_math_bf16x3() ? launch_gather_cfg<128, 64, 64, 32, B_NK, 1>(p, st)
+                                      : launch_gather_cfg<128, 64, 64, 32, B_NK>(p, st); break;
     case 3: code = launch_gather_cfg<256, 64, 64, 64, B_NK>(p, st); break;
     default: code = launch_gather_cfg<64, 64, 32, 32, B_NK>(p, st); break;
   }
