@@ -27,6 +27,8 @@ os.environ.setdefault("MKL_NUM_THREADS", str(CPU_THREADS))
 
 FWD_BWD_GFLOP_PER_PAIR = 204.9      # algorithmic 2*MAC, FlowNetC 384x512 bidirectional
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
+BF16X3_TERMS = 6                    # product terms of the fp32-equivalent 3-way bf16 split (csrc/conv_igemm.hip)
 
 
 def conv_family_gflop(eng):
@@ -63,6 +65,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the UNFLOW_CONV_MATH=fp32 re-measurement (a sub-process)")
     args = ap.parse_args()
 
     import torch
@@ -168,12 +171,19 @@ def main():
                                % (args.flownet, " + RCCL grad all-reduce" if world > 1 else "", B, H, W,
                                   3 if args.flownet != "C" else (2 if world > 1 else 1)),
                    "global_batch": world * B, "height": H, "width": W, "parallelism": "dp%d" % world,
-                   "hipgraph": graphs is not None, "final_loss": round(loss, 4)},
+                   "hipgraph": graphs is not None, "final_loss": round(loss, 4),
+                   "conv_math": ("conv fwd/dgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on the "
+                                 "bf16 MFMA — same error as the fp32 MFMA (tools/microbench/bf16x3_accuracy.hip); filter "
+                                 "gradients: fp32 MFMA") if os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
+                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"},
         "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W, args.flownet) == (384, 512, "C") else None,
     }
 
     if rank == 0 and world == 1 and not args.no_roofline and args.flownet == 'C':
         out["roofline"] = measure_roofline(eng, args)
+    if (rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C'
+            and os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"):
+        out["value_fp32_mfma_only"] = measure_alt_fp32(args)      # same step with every conv kernel on the fp32 MFMA
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.flownet == 'C':
         out["cpu_baseline"] = measure_cpu_baseline(H, W)
         if out["cpu_baseline"]["value"]:
@@ -245,12 +255,38 @@ def measure_roofline(eng, args):
         ms = e0.elapsed_time(e1) / reps
     torch.cuda.current_stream().wait_stream(side)
     achieved = gflop / ms            # GFLOP / ms == TFLOP/s
-    return {"bound": "mfma", "kernel": "igemm_gather_kernel + igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM) incl. "
-                                       "their split-K reduces and the Cout=2 flow-head kernels: %d layer launches/step" % launches,
-            "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+    # Peak of the class = its FLOPs / the time its kernels need at their own matrix-core peaks: the gather kernels (conv
+    # fwd / dgrad, 2/3 of the FLOPs) run the fp32-equivalent 3-way bf16 split = bf16 peak / 6 product terms, the
+    # filter-gradient kernel (1/3) runs v_mfma_f32_32x32x2_f32.  With UNFLOW_CONV_MATH=fp32 everything is on the latter.
+    bf16x3 = os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
+    g_peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if bf16x3 else FP32_MFMA_PEAK_TFLOPS
+    peak = 1.0 / ((2.0 / 3.0) / g_peak + (1.0 / 3.0) / FP32_MFMA_PEAK_TFLOPS)
+    return {"bound": "mfma", "kernel": "igemm_gather_kernel (%s) + igemm_wgrad_kernel (v_mfma_f32_32x32x2_f32) incl. their "
+                                       "split-K reduces and the Cout=2 flow-head kernels: %d layer launches/step"
+                                       % ("fp32-equivalent 3xbf16 split, 6 terms on v_mfma_f32_32x32x16_bf16" if bf16x3
+                                          else "v_mfma_f32_32x32x2_f32", launches),
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "peak_note": "FLOP-weighted: 2/3 of the class at %.1f (gather kernels), 1/3 at %.1f TFLOP/s (filter gradients)"
+                         % (g_peak, FP32_MFMA_PEAK_TFLOPS),
             **(_pmc_traffic() if (eng.B, eng.H, eng.W, eng.spec) == (4, 384, 512, 'C') else {"traffic": None}),
             "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
+
+
+def measure_alt_fp32(args):
+    """image-pairs/s of the same step with UNFLOW_CONV_MATH=fp32 (the library reads the knob once per process, so this
+    is a sub-process of this script)."""
+    import subprocess
+    env = dict(os.environ, UNFLOW_CONV_MATH="fp32")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch",
+           str(args.batch), "--height", str(args.height), "--width", str(args.width), "--no-cpu-baseline", "--no-roofline",
+           "--no-alt"] + (["--no-graph"] if args.no_graph else [])
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
+        return json.loads(line)["value"]
+    except Exception as e:
+        return "failed: %r" % (e,)
 
 
 def _pmc_traffic():

@@ -175,3 +175,19 @@ def test_conv_full_size_linearity(dev):
     layers.conv2d_fwd(x1[..., :240], w[:, :, :240].contiguous(), None, ya, 1, leaky=False)
     layers.conv2d_fwd(x1[..., 240:], w[:, :, 240:].contiguous(), None, yb, 1, leaky=False)
     assert rel_err(ya + yb, y1) < 1e-5
+
+
+def test_both_conv_math_modes(dev):
+    """The gather kernels default to the fp32-equivalent 3-way bf16 split on the bf16 matrix cores; UNFLOW_CONV_MATH=fp32
+    puts them on v_mfma_f32_32x32x2_f32.  The library reads the knob once per process, so the other mode runs this file
+    in a sub-process: every parity case must hold at the SAME tolerances in both modes."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("UNFLOW_CONV_MATH_SUBTEST"):
+        pytest.skip("already inside the sub-process")
+    other = "bf16x3" if os.environ.get("UNFLOW_CONV_MATH", "bf16x3") == "fp32" else "fp32"
+    env = dict(os.environ, UNFLOW_CONV_MATH=other, UNFLOW_CONV_MATH_SUBTEST="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

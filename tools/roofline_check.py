@@ -40,10 +40,10 @@ def main():
         if 'igemm' in k:
             mfma += t
         print("%-62s %5d %10.1f %10.1f" % (k[:62], per_step[k], avg.get(k, 0.0) / 1e3, t))
-    print("conv family: %.3f ms/step -> %.1f TFLOP/s (%.1f %% of 157.3) for %.1f algorithmic GFLOP"
-          % (total / 1e3, gflop / total * 1e3, gflop / total * 1e3 / 157.3 * 100, gflop))
-    print("implicit-GEMM kernels alone: %.3f ms/step -> %.1f TFLOP/s (%.1f %%)"
-          % (mfma / 1e3, gflop / mfma * 1e3, gflop / mfma * 1e3 / 157.3 * 100))
+    print("conv family: %.3f ms/step -> %.1f TFLOP/s for %.1f algorithmic GFLOP (compare with roofline.achieved of the "
+          "bench line; %.1f %% of the 157.3 TFLOP/s fp32-MFMA peak)"
+          % (total / 1e3, gflop / total * 1e3, gflop, gflop / total * 1e3 / 157.3 * 100))
+    print("implicit-GEMM kernels alone: %.3f ms/step -> %.1f TFLOP/s" % (mfma / 1e3, gflop / mfma * 1e3))
 
 
 if __name__ == '__main__':

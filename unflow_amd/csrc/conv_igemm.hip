@@ -1496,9 +1496,10 @@ inline int fill_one_round(long blocks, int slots, int max_split) {
   return ns < 1 ? 1 : ns;
 }
 
-// UNFLOW_CONV_MATH=bf16x3: the 128-row gather tiles compute on the bf16 matrix cores (3-way split, fp32-equivalent)
+// The 128-row gather tiles (conv fwd / dgrad, deconv fwd / dgrad) compute on the bf16 matrix cores by default (3-way
+// split, six terms: fp32-equivalent, see split_store); UNFLOW_CONV_MATH=fp32 selects v_mfma_f32_32x32x2_f32 for them too.
 inline bool conv_math_bf16x3() {
-  static const bool on = getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "bf16x3");
+  static const bool on = !(getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32"));
   return on;
 }
 
