@@ -16,7 +16,8 @@ a, b = idx[-2], idx[-1]
 fwd = [('conv1',7.40),('conv2',40.27),('conv3',40.27),('conv_redir',0.40),('conv3_1',53.57),('conv4',14.50),('conv4_1',28.99),('conv5',7.25),('conv5_1',7.25),('conv6',3.62),('conv6_1',7.25),('deconv5',6.44),('deconv4',12.91),('deconv3',19.38),('deconv2',19.43)]
 bwd = [('deconv2 wgrad',19.43),('deconv2 dgrad',19.43),('deconv3 wgrad',19.38),('deconv3 dgrad',19.38),('deconv4 wgrad',12.91),('deconv4 dgrad',12.91),('deconv5 wgrad',6.44),('deconv5 dgrad',6.44),
        ('conv6_1 wgrad',7.25),('conv6_1 dgrad',7.25),('conv6 wgrad',3.62),('conv6 dgrad',3.62),('conv5_1 wgrad',7.25),('conv5_1 dgrad',7.25),('conv5 wgrad',7.25),('conv5 dgrad',7.25),
-       ('conv4_1 wgrad',28.99),('conv4_1 dgrad',28.99),('conv4 wgrad',14.5),('conv4 dgrad',14.5),('conv3_1 wgrad',53.57),('conv3_1 dgrad',53.57),('conv_redir wgrad',0.4),('conv_redir dgrad',0.4),
+       ('conv4_1 wgrad',28.99),('conv4_1 dgrad',28.99),('conv4 wgrad',14.5),('conv4 dgrad',14.5),('conv3_1 wgrad',53.57),('conv3_1 dgrad',53.57),('conv_redir wgrad',0.4),   # its dgrad runs in pointwise32_dgrad_kernel, not an igemm launch
+       
        ('conv3 wgrad',40.27),('conv3 dgrad',40.27),('conv2 wgrad',40.27),('conv2 dgrad',40.27),('conv1 wgrad',7.4)]
 seq = fwd + bwd
 k = 0
