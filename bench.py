@@ -172,9 +172,9 @@ def main():
                                   3 if args.flownet != "C" else (2 if world > 1 else 1)),
                    "global_batch": world * B, "height": H, "width": W, "parallelism": "dp%d" % world,
                    "hipgraph": graphs is not None, "final_loss": round(loss, 4),
-                   "conv_math": ("conv fwd/dgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on the "
-                                 "bf16 MFMA — same error as the fp32 MFMA (tools/microbench/bf16x3_accuracy.hip); filter "
-                                 "gradients: fp32 MFMA") if os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
+                   "conv_math": ("conv fwd/dgrad/wgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on "
+                                 "the bf16 MFMA — same error as the fp32 MFMA (tools/microbench/bf16x3_accuracy.hip)")
+                   if os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
                    else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"},
         "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W, args.flownet) == (384, 512, "C") else None,
     }
@@ -255,20 +255,23 @@ def measure_roofline(eng, args):
         ms = e0.elapsed_time(e1) / reps
     torch.cuda.current_stream().wait_stream(side)
     achieved = gflop / ms            # GFLOP / ms == TFLOP/s
-    # Peak of the class = its FLOPs / the time its kernels need at their own matrix-core peaks: the gather kernels (conv
-    # fwd / dgrad, 2/3 of the FLOPs) run the fp32-equivalent 3-way bf16 split = bf16 peak / 6 product terms, the
-    # filter-gradient kernel (1/3) runs v_mfma_f32_32x32x2_f32.  With UNFLOW_CONV_MATH=fp32 everything is on the latter.
+    # Peak of the class = its FLOPs / the time its kernels need at their own matrix-core peaks.  Default: gather kernels
+    # (conv fwd / dgrad, 2/3 of the FLOPs) and filter-gradient kernels (1/3) both run the fp32-equivalent 3-way bf16 split =
+    # bf16 peak / 6 product terms; UNFLOW_WGRAD_MATH=fp32 / UNFLOW_CONV_MATH=fp32 put the latter / both on
+    # v_mfma_f32_32x32x2_f32.
     bf16x3 = os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
+    wg_b3 = bf16x3 and os.environ.get("UNFLOW_WGRAD_MATH", "bf16x3") != "fp32"
     g_peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if bf16x3 else FP32_MFMA_PEAK_TFLOPS
-    peak = 1.0 / ((2.0 / 3.0) / g_peak + (1.0 / 3.0) / FP32_MFMA_PEAK_TFLOPS)
-    return {"bound": "mfma", "kernel": "igemm_gather_kernel (%s) + igemm_wgrad_kernel (v_mfma_f32_32x32x2_f32) incl. their "
-                                       "split-K reduces and the Cout=2 flow-head kernels: %d layer launches/step"
-                                       % ("fp32-equivalent 3xbf16 split, 6 terms on v_mfma_f32_32x32x16_bf16" if bf16x3
-                                          else "v_mfma_f32_32x32x2_f32", launches),
+    w_peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if wg_b3 else FP32_MFMA_PEAK_TFLOPS
+    peak = 1.0 / ((2.0 / 3.0) / g_peak + (1.0 / 3.0) / w_peak)
+    b3name, f32name = "fp32-equivalent 3xbf16 split, 6 terms on v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32"
+    return {"bound": "mfma", "kernel": "igemm_gather_kernel (%s) + igemm_wgrad kernel (%s) incl. their split-K reduces and "
+                                       "the Cout=2 flow-head kernels: %d layer launches/step"
+                                       % (b3name if bf16x3 else f32name, b3name if wg_b3 else f32name, launches),
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "peak_note": "FLOP-weighted: 2/3 of the class at %.1f (gather kernels), 1/3 at %.1f TFLOP/s (filter gradients)"
-                         % (g_peak, FP32_MFMA_PEAK_TFLOPS),
+            "peak_note": "FLOP-weighted: 2/3 of the class at %.1f (gather kernels), 1/3 at %.1f TFLOP/s (filter gradients); "
+                         "bf16x3 peak = 2500 / 6 product terms" % (g_peak, w_peak),
             **(_pmc_traffic() if (eng.B, eng.H, eng.W, eng.spec) == (4, 384, 512, 'C') else {"traffic": None}),
             "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
 

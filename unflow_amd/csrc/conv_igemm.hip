@@ -590,6 +590,154 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// Filter gradient with the fp32-equivalent 3-way bf16 split (see split_store).  The MFMA wants 8 consecutive k (= sites)
+// of one row per lane, but both operands are site-major in HBM, so here a LANE IS A ROW: lane m loads its channel of 4
+// consecutive sites as four dword loads — each instruction still covers 64 consecutive channels of one site, 256
+// contiguous bytes — splits the float4 of 4 consecutive k and stores it like the gather kernel does.  The site
+// decode is wave-uniform (scalar); the per-lane part of the gathered address is a constant of the thread.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  constexpr int A_PLANE = BM * LDH, B_PLANE = BN * LDH;
+  constexpr int ASETS = 256 / BM, BSETS = 256 / BN;   // thread sets per operand; a wave lies inside one set (BM, BN >= 64)
+  constexpr int AG = 8 / ASETS, BG = 8 / BSETS;       // groups of 4 consecutive sites per thread (BK / 4 = 8 groups)
+  constexpr int NLA = 4 * AG, NL = 4 * AG + 4 * BG;   // dword loads per thread and K tile
+  static_assert(BM >= 64 && BN >= 64 && NL <= 36, "load schedule");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bh = Ah + 3 * A_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int S = p.B * p.Hg * p.Wg;
+  const int KT = (S + BK - 1) / BK;
+  const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
+  const int kt0 = blockIdx.z * kt_per, kt1 = min(KT, kt0 + kt_per);
+
+  const __amdgpu_buffer_rsrc_t src_rs =
+      make_rsrc(p.src, ((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds * 4 + (size_t)p.Ca * 4);
+  const __amdgpu_buffer_rsrc_t dst_rs = make_rsrc(p.dst, ((size_t)S - 1) * (size_t)p.ldd * 4 + (size_t)p.Cb * 4);
+
+  // gathered operand: this lane's row m = (tap, a)
+  const int arow = tid % BM;
+  const int aset = __builtin_amdgcn_readfirstlane(tid / BM);
+  const int mm = m0 + arow;
+  const bool m_ok = mm < Mp;
+  const unsigned tap = fast_div((unsigned)mm, p.ca_magic);
+  const int a_ch = mm - (int)tap * p.Ca;
+  const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
+  const int dy = p.dy0 + ky, dx = p.dx0 + kx;
+  const int lds4 = p.lds * 4;
+  const int a_lane_off = (dy * p.Ws + dx) * lds4 + a_ch * 4;      // may be negative; added to the site's base offset
+  // dense operand: this lane's column n
+  const int brow = tid % BN;
+  const int bset = __builtin_amdgcn_readfirstlane(tid / BN);
+  const int nb = n0 + brow;
+  const bool b_ok = nb < p.Cb;
+  const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
+
+  float ra[AG][4], rb[BG][4];
+  auto load_one = [&](int l, int kt) {
+    if (l < NLA) {
+      const int gi = l >> 2, j = l & 3;
+      const unsigned sidx = (unsigned)(kt * BK + 4 * (aset + ASETS * gi) + j);      // wave-uniform
+      const unsigned q = fast_div(sidx, magW);
+      const int xg = (int)(sidx - q * (unsigned)p.Wg);
+      const unsigned bb = fast_div(q, magH);
+      const int yg = (int)(q - bb * (unsigned)p.Hg);
+      const int yb = yg * p.sm, xb = xg * p.sm;
+      const int base = (((int)bb * p.Hs + yb) * p.Ws + xb) * lds4;                  // uniform
+      const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
+      ra[gi][j] = buf_ld1(src_rs, ok ? base + a_lane_off : OOB_MARK, 0);
+    } else {
+      const int lb = l - NLA;
+      const int gi = lb >> 2, j = lb & 3;
+      const int sidx = kt * BK + 4 * (bset + BSETS * gi) + j;                       // wave-uniform
+      const bool ok = b_ok && sidx < S;
+      rb[gi][j] = buf_ld1(dst_rs, ok ? (sidx * p.ldd + nb) * 4 : OOB_MARK, 0);
+    }
+  };
+  // 12 MFMA term groups per K tile: up to three loads after each
+  auto piece = [&](int step, int kt) {
+#pragma unroll
+    for (int l = 3 * step; l < 3 * step + 3; l++)
+      if (l < NL) load_one(l, kt);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int gi = 0; gi < AG; gi++)
+      split_store(Ah + arow * LDH + 4 * (aset + ASETS * gi), A_PLANE, make_float4(ra[gi][0], ra[gi][1], ra[gi][2], ra[gi][3]));
+#pragma unroll
+    for (int gi = 0; gi < BG; gi++)
+      split_store(Bh + brow * LDH + 4 * (bset + BSETS * gi), B_PLANE, make_float4(rb[gi][0], rb[gi][1], rb[gi][2], rb[gi][3]));
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int st = 0; st < 12; st++) piece(st, kt0);
+  store_tile();
+  __syncthreads();
+  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH + 8 * lh;
+  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH + 8 * lh;
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;   // past the last tile: every load is out of range (zeros)
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++) {
+      bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+          av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 16 * slab);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 16 * slab);
+      }
+      constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ta[t]][i], bv[tb[t]][j], acc[i][j], 0, 0, 0);
+        piece(slab * 6 + t, ktn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+  }
+
+  float* o = p.nsplit > 1 ? p.partial + (size_t)blockIdx.z * Mp * p.Cb : p.out;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= Mp) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n < p.Cb) o[(size_t)m * p.Cb + n] = acc[i][j][r];
+      }
+    }
+}
+
 // out[g][e] = sum_{k < fan} partial[g*fan + k][e]  (fixed order; g < ceil(S/fan)).  With S <= fan this is the
 // final sum.  Applied repeatedly it is a deterministic tree reduction whose serial depth is <= fan.
 __global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n, int S,
@@ -1503,6 +1651,11 @@ inline bool conv_math_bf16x3() {
   return on;
 }
 
+inline bool wgrad_math_bf16x3() {   // UNFLOW_WGRAD_MATH=fp32 keeps the filter gradients on v_mfma_f32_32x32x2_f32
+  static const bool on = conv_math_bf16x3() && !(getenv("UNFLOW_WGRAD_MATH") && !strcmp(getenv("UNFLOW_WGRAD_MATH"), "fp32"));
+  return on;
+}
+
 inline GatherPlan plan_gather(const GatherParams& p) {
   GatherPlan pl;
   const long M = (long)p.B * p.Hg * p.Wg;
@@ -1551,7 +1704,8 @@ inline int plan_wgrad(const WgradParams& p) {
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
   const int max_by_k = min(256, KT / 4 > 0 ? KT / 4 : 1);
-  const int slots = 256 * (cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // single-stage LDS 32 KB / 122 regs: 4 per CU
+  const bool b3 = wgrad_math_bf16x3() && cfg != 2;                // bf16x3: 61 / 46 KB of LDS per block
+  const int slots = 256 * (b3 ? (cfg == 1 ? 3 : 2) : cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // fp32: single-stage LDS 32 KB / 122 regs: 4 per CU
   return fill_one_round(blocks, slots, max_by_k);
 }
 
@@ -1666,6 +1820,21 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN>
+int launch_wgrad_b3_cfg(const WgradParams& p, hipStream_t st) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const size_t smem = (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_b3_kernel<BM, BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
+  igemm_wgrad_b3_kernel<BM, BN, WM, WN><<<grid, 256, smem, st>>>(p);
+  return launch_status();
+}
+
+template <int BM, int BN, int WM, int WN>
 int launch_wgrad_cfg(const WgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const size_t smem = (size_t)(BK * BM + BK * BN) * sizeof(float);
@@ -1693,7 +1862,9 @@ int run_wgrad(WgradParams& p, void* ws, size_t ws_bytes, size_t* used, hipStream
   p.partial = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
   *used = wgrad_partial_bytes(p, ns);
   const int cfg = wgrad_cfg(p);
-  const int code = cfg == 1 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st)
+  const bool b3 = wgrad_math_bf16x3() && cfg != 2;
+  const int code = b3 ? (cfg == 1 ? launch_wgrad_b3_cfg<128, 64, 64, 32>(p, st) : launch_wgrad_b3_cfg<128, 128, 64, 64>(p, st))
+                 : cfg == 1 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st)
                  : cfg == 2 ? launch_wgrad_cfg<256, 128, 128, 64>(p, st)
                             : launch_wgrad_cfg<128, 128, 64, 64>(p, st);
   if (code != UNFLOW_OK) return code;
