@@ -1641,7 +1641,19 @@ inline int fill_one_round(long blocks, int slots, int max_split) {
   if (blocks >= slots) return 1;
   int ns = (int)(slots / blocks);
   if (ns > max_split) ns = max_split;
-  return ns < 1 ? 1 : ns;
+  if (ns < 1) ns = 1;
+  // With only 2 resident 128x128 blocks per CU (bf16x3 tiles) one round can be badly filled (288 blocks on 512 slots):
+  // then a split that runs 2-3 well-filled rounds wins.  Take it only for a clear gain, and the fewest splits that get it.
+  auto eff = [&](int n) { const long b = blocks * n; return (double)b / (double)(((b + slots - 1) / slots) * slots); };
+  const double e1 = eff(ns);
+  if (e1 < 0.8) {
+    int best = ns;
+    double be = e1;
+    for (int n = ns + 1; n <= max_split && blocks * n <= 3L * slots; n++)
+      if (eff(n) > be + 0.02) { best = n; be = eff(n); }
+    if (be >= e1 + 0.15) ns = best;
+  }
+  return ns;
 }
 
 // The 128-row gather tiles (conv fwd / dgrad, deconv fwd / dgrad) compute on the bf16 matrix cores by default (3-way
