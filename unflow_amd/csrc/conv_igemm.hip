@@ -85,7 +85,12 @@ __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int
 // sum|a||b| against 2.8e-8 for v_mfma_f32_32x32x2_f32 — the same accuracy class, at 1/16 of the matrix-core time per
 // product term.  The split happens once per element while the tile is staged into LDS (v_cvt_pk_bf16_f32, gfx950).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDH = BK + 8;   // bf16 row pitch of one plane: 80 bytes (16-byte aligned rows, conflict-free b128 reads)
+constexpr int LDH = BK;       // bf16 row pitch of one plane: 64 bytes, no padding (49 KB per 128x128 block -> 3 blocks per CU)
+// ... made conflict-free by an XOR swizzle of the 16-byte granule index with bits 2..3 of the row: the 16 lanes a
+// ds_read_b128 serves per cycle (rows r .. r+15, same logical granule) then touch 16 different granule slots of 256 bytes.
+__device__ __forceinline__ int swz_off(int row, int kquad) {   // offset (in bf16 elements) of k = 4*kquad of `row`
+  return row * LDH + 8 * ((kquad >> 1) ^ ((row >> 2) & 3)) + 4 * (kquad & 1);
+}
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   unsigned r;
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -265,13 +270,13 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   auto store_tile = [&]() {
     if constexpr (MATH == 1) {
 #pragma unroll
-      for (int i = 0; i < AR; i++) split_store(Ah + ((tid >> 3) + 32 * i) * LDH + kq * 4, A_PLANE, ra[i]);
+      for (int i = 0; i < AR; i++) split_store(Ah + swz_off((tid >> 3) + 32 * i, kq), A_PLANE, ra[i]);
       if constexpr (B_NK) {
 #pragma unroll
-        for (int i = 0; i < BR_NK; i++) split_store(Bh + ((tid >> 3) + 32 * i) * LDH + kq * 4, B_PLANE, rb[i]);
+        for (int i = 0; i < BR_NK; i++) split_store(Bh + swz_off((tid >> 3) + 32 * i, kq), B_PLANE, rb[i]);
       } else {
 #pragma unroll
-        for (int i = 0; i < BQ_KN; i++) split_store(Bh + (tid % BN) * LDH + 4 * ((tid / BN) + KG * i), B_PLANE, rb[i]);
+        for (int i = 0; i < BQ_KN; i++) split_store(Bh + swz_off(tid % BN, (tid / BN) + KG * i), B_PLANE, rb[i]);
       }
       return;
     }
@@ -305,8 +310,9 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   __syncthreads();
   const float* a_rd = As + (wm * WM + l31) * LDK + 16 * lh;
   const float* b_rd = Bs + (wn * WN + l31) * LDK + 16 * lh;
-  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH + 8 * lh;
-  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH + 8 * lh;
+  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH;
+  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
+  const int gsw = lh ^ ((l31 >> 2) & 3);     // swizzled granule of K16 slab 0 (slab 1: ^ 2); tile bases are multiples of 32
   for (int kt = kt0; kt < kt1; kt++) {
     live = (kt + 1 < kt1) && !(p.dbg & 1);
     if constexpr (MATH == 1) {
@@ -318,10 +324,10 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
         for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
           for (int i = 0; i < TM; i++)
-            av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 16 * slab);
+            av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 8 * (gsw ^ (2 * slab)));
 #pragma unroll
           for (int j = 0; j < TN; j++)
-            bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 16 * slab);
+            bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
         }
         constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
 #pragma unroll
@@ -671,10 +677,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p
   auto store_tile = [&]() {
 #pragma unroll
     for (int gi = 0; gi < AG; gi++)
-      split_store(Ah + arow * LDH + 4 * (aset + ASETS * gi), A_PLANE, make_float4(ra[gi][0], ra[gi][1], ra[gi][2], ra[gi][3]));
+      split_store(Ah + swz_off(arow, aset + ASETS * gi), A_PLANE, make_float4(ra[gi][0], ra[gi][1], ra[gi][2], ra[gi][3]));
 #pragma unroll
     for (int gi = 0; gi < BG; gi++)
-      split_store(Bh + brow * LDH + 4 * (bset + BSETS * gi), B_PLANE, make_float4(rb[gi][0], rb[gi][1], rb[gi][2], rb[gi][3]));
+      split_store(Bh + swz_off(brow, bset + BSETS * gi), B_PLANE, make_float4(rb[gi][0], rb[gi][1], rb[gi][2], rb[gi][3]));
   };
 
   f32x16 acc[TM][TN];
@@ -690,8 +696,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p
   for (int st = 0; st < 12; st++) piece(st, kt0);
   store_tile();
   __syncthreads();
-  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH + 8 * lh;
-  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH + 8 * lh;
+  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH;
+  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
+  const int gsw = lh ^ ((l31 >> 2) & 3);
   for (int kt = kt0; kt < kt1; kt++) {
     const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;   // past the last tile: every load is out of range (zeros)
 #pragma unroll
@@ -701,10 +708,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p
       for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
-          av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 16 * slab);
+          av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 8 * (gsw ^ (2 * slab)));
 #pragma unroll
         for (int j = 0; j < TN; j++)
-          bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 16 * slab);
+          bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
       }
       constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
 #pragma unroll
@@ -1688,8 +1695,8 @@ inline GatherPlan plan_gather(const GatherParams& p) {
   static const int tall = getenv("UNFLOW_GATHER_TALL") ? atoi(getenv("UNFLOW_GATHER_TALL")) : 0;   // tuning knob
   if (pl.cfg == 1 && tall && M * p.ncls >= 256L * 768) pl.cfg = 3;
   const int bm = pl.cfg == 2 ? 64 : pl.cfg == 3 ? 256 : 128, bn = pl.cfg == 0 ? 128 : 64;
-  const bool b3 = conv_math_bf16x3();   // 60 KB / 45 KB of LDS per block instead of 37 / 28
-  const int slots = 256 * (pl.cfg == 0 ? (b3 ? 2 : 3) : pl.cfg == 1 ? (b3 ? 3 : 4) : pl.cfg == 3 ? 3 : 6);
+  // bf16x3 tiles: 49 KB / 37 KB of LDS per block (swizzled, unpadded planes): the same residency as the fp32 tiles
+  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : pl.cfg == 3 ? 3 : 6);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
   return pl;
@@ -1716,8 +1723,8 @@ inline int plan_wgrad(const WgradParams& p) {
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
   const int max_by_k = min(256, KT / 4 > 0 ? KT / 4 : 1);
-  const bool b3 = wgrad_math_bf16x3() && cfg != 2;                // bf16x3: 61 / 46 KB of LDS per block
-  const int slots = 256 * (b3 ? (cfg == 1 ? 3 : 2) : cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // fp32: single-stage LDS 32 KB / 122 regs: 4 per CU
+  const bool b3 = wgrad_math_bf16x3() && cfg != 2;                // bf16x3: 49 / 37 KB of LDS per block
+  const int slots = 256 * (b3 ? (cfg == 1 ? 4 : 3) : cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // fp32: single-stage LDS 32 KB / 122 regs: 4 per CU
   return fill_one_round(blocks, slots, max_by_k);
 }
 
