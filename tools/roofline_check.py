@@ -10,7 +10,7 @@ import csv
 import sys
 from collections import defaultdict
 
-FAMILY = ('igemm_gather_kernel', 'igemm_wgrad_kernel', 'splitk_reduce_epilogue', 'sum_partials', 'head3_', 'skinny_conv',
+FAMILY = ('igemm_gather_kernel', 'igemm_wgrad', 'splitk_reduce_epilogue', 'sum_partials', 'head3_', 'skinny_conv',
           'tiny_deconv')
 
 
