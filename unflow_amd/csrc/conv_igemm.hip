@@ -119,7 +119,7 @@ __device__ __forceinline__ void split_store(unsigned short* __restrict__ dst, in
 // there: an in-order wave then always has an MFMA within a few instructions, instead of a ~300
 // instruction load prologue during which its SIMD's matrix pipe idles (and co-resident waves lock-step).
 // All predication is by address select + value select — no divergent branches in the loop.
-template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0>
+template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0, int PF = 1>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
 
   float4 ra[AR];
   float4 rb[NB];
+  float4 ra2[PF == 2 ? AR : 1], rb2[PF == 2 ? NB : 1];   // PF == 2: second register set (tile t+2 in flight while t+1 waits)
   // state of the tile being loaded (set by piece 0)
   int dy, dx, a_tile, w_tile;
 
@@ -231,15 +232,15 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
       w_tile = kvalid ? widx * p.N * p.Cs * 4 + cofs : OOB_MARK;
     }
   };
-  auto piece_a = [&](int i) {
+  auto piece_a = [&](int i, float4* RA) {
     const int y = a_y[i] + dy, x = a_x[i] + dx;
     const bool inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
     const int voff = inb ? a_lin[i] * lds4 + a_tile : OOB_MARK;
-    ra[i] = buf_ld4(src_rs, voff, 0);
+    RA[i] = buf_ld4(src_rs, voff, 0);
   };
-  auto piece_b = [&](int i, int kt_next) {
+  auto piece_b = [&](int i, int kt_next, float4* RB) {
     if constexpr (B_NK) {
-      rb[i] = buf_ld4(w_rs, b_row[i] + w_tile, 0);
+      RB[i] = buf_ld4(w_rs, b_row[i] + w_tile, 0);
     } else {
       // W[kk][n] (conv fwd, deconv dgrad: the class walks all taps in weight order, so the flattened K
       // index is the weight row).  Lane = n (coalesced 256 B per wave and k); the row offset is a scalar
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) v[j] = buf_ld1(w_rs, kn_voff, min(kk + j, Ktot - 1) * p.N * 4);
-      rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+      RB[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
   };
   auto piece_end = [&]() {
@@ -259,25 +260,29 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
     q_tap += wrap ? 1 : 0;
   };
   // piece schedule over the 16 MFMA steps of a tile: 0: begin, 1..AR: A rows, then B, then end
-  auto piece = [&](int step, int kt_next) {
+  auto piece_set = [&](int step, int kt_next, float4* RA, float4* RB) {
     if (step == 0) piece_begin();
-    if (step >= 1 && step <= AR) piece_a(step - 1);
-    if (step > AR && step <= AR + NB) piece_b(step - AR - 1, kt_next);
+    if (step >= 1 && step <= AR) piece_a(step - 1, RA);
+    if (step > AR && step <= AR + NB) piece_b(step - AR - 1, kt_next, RB);
     if (step == AR + NB + 1) piece_end();
   };
+  auto piece = [&](int step, int kt_next) { piece_set(step, kt_next, ra, rb); };
   static_assert(AR + NB + 2 <= 16, "pieces must fit the 16 steps");
 
+  auto store_set = [&](const float4* RA, const float4* RB) {     // MATH == 1
+#pragma unroll
+    for (int i = 0; i < AR; i++) split_store(Ah + swz_off((tid >> 3) + 32 * i, kq), A_PLANE, RA[i]);
+    if constexpr (B_NK) {
+#pragma unroll
+      for (int i = 0; i < BR_NK; i++) split_store(Bh + swz_off((tid >> 3) + 32 * i, kq), B_PLANE, RB[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BQ_KN; i++) split_store(Bh + swz_off(tid % BN, (tid / BN) + KG * i), B_PLANE, RB[i]);
+    }
+  };
   auto store_tile = [&]() {
     if constexpr (MATH == 1) {
-#pragma unroll
-      for (int i = 0; i < AR; i++) split_store(Ah + swz_off((tid >> 3) + 32 * i, kq), A_PLANE, ra[i]);
-      if constexpr (B_NK) {
-#pragma unroll
-        for (int i = 0; i < BR_NK; i++) split_store(Bh + swz_off((tid >> 3) + 32 * i, kq), B_PLANE, rb[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < BQ_KN; i++) split_store(Bh + swz_off(tid % BN, (tid / BN) + KG * i), B_PLANE, rb[i]);
-      }
+      store_set(ra, rb);
       return;
     }
 #pragma unroll
@@ -313,36 +318,60 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH;
   const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
   const int gsw = lh ^ ((l31 >> 2) & 3);     // swizzled granule of K16 slab 0 (slab 1: ^ 2); tile bases are multiples of 32
+  // MATH == 1: the 12 term groups of the tile in LDS, with the load pieces of tile `kload` (into RA/RB) between them.
+  // Two K16 slabs per tile; lane (row l31, half lh) holds k = 16*slab + 8*lh .. +7 of its row for both operands.
+  auto mfma_phase = [&](int kload, float4* RA, float4* RB) {
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++) {
+      bf16x8 av[3][TM], bv[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+          av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 8 * (gsw ^ (2 * slab)));
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
+      }
+      constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ta[t]][i], bv[tb[t]][j], acc[i][j], 0, 0, 0);
+        piece_set(slab * 6 + t, kload, RA, RB);          // 12 of the 16 load pieces sit between the term groups ...
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int st = 12; st < 16; st++) piece_set(st, kload, RA, RB);   // ... the rest (if any) right after
+  };
+  if constexpr (MATH == 1 && PF == 2) {
+    // distance-2 prefetch: while tile kt is multiplied, tile kt+1 is already in flight in the other register set and
+    // tile kt+2 is requested — a bf16x3 tile takes only ~0.6 us of matrix-core time, less than an L2/HBM round trip
+    live = kt0 + 1 < kt1;
+#pragma unroll
+    for (int st = 0; st < 16; st++) piece_set(st, kt0 + 1, ra2, rb2);
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      live = kt + 2 < kt1;
+      mfma_phase(kt + 2, ra, rb);
+      __syncthreads();
+      store_set(ra2, rb2);          // tile kt+1
+      __syncthreads();
+      if (kt + 1 >= kt1) break;
+      live = kt + 3 < kt1;
+      mfma_phase(kt + 3, ra2, rb2);
+      __syncthreads();
+      store_set(ra, rb);            // tile kt+2
+      __syncthreads();
+    }
+  } else
   for (int kt = kt0; kt < kt1; kt++) {
     live = (kt + 1 < kt1) && !(p.dbg & 1);
     if constexpr (MATH == 1) {
-      // two K16 slabs per tile; lane (row l31, half lh) holds k = 16*slab + 8*lh .. +7 of its row for both operands
-#pragma unroll
-      for (int slab = 0; slab < 2; slab++) {
-        bf16x8 av[3][TM], bv[3][TN];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-#pragma unroll
-          for (int i = 0; i < TM; i++)
-            av[pl][i] = *reinterpret_cast<const bf16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-            bv[pl][j] = *reinterpret_cast<const bf16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-        }
-        constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
-#pragma unroll
-        for (int t = 0; t < 6; t++) {
-#pragma unroll
-          for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ta[t]][i], bv[tb[t]][j], acc[i][j], 0, 0, 0);
-          piece(slab * 6 + t, kt + 1);          // 12 of the 16 load pieces sit between the term groups ...
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int st = 12; st < 16; st++) piece(st, kt + 1);   // ... the rest (if any) right after
+      mfma_phase(kt + 1, ra, rb);
     } else {
 #pragma unroll
     for (int j4 = 0; j4 < 4; j4++) {
@@ -1670,6 +1699,11 @@ inline bool conv_math_bf16x3() {
   return on;
 }
 
+inline bool gather_pf2() {   // UNFLOW_GATHER_PF2=1: distance-2 prefetch in the 128x128 bf16x3 gather kernel (tuning knob)
+  static const bool on = getenv("UNFLOW_GATHER_PF2") && atoi(getenv("UNFLOW_GATHER_PF2")) != 0;
+  return on;
+}
+
 inline bool wgrad_math_bf16x3() {   // UNFLOW_WGRAD_MATH=fp32 keeps the filter gradients on v_mfma_f32_32x32x2_f32
   static const bool on = conv_math_bf16x3() && !(getenv("UNFLOW_WGRAD_MATH") && !strcmp(getenv("UNFLOW_WGRAD_MATH"), "fp32"));
   return on;
@@ -1786,19 +1820,19 @@ inline int reduce_partials(const float* partial, float* scratch, float* out, siz
   return launch_status();
 }
 
-template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0>
+template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0, int PF = 1>
 int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
   const size_t smem = (MATH ? (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short) : (size_t)(BM + BN) * LDK * sizeof(float)) +
                       BM * sizeof(int);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
-  igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH><<<grid, 256, smem, st>>>(p);
+  igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF><<<grid, 256, smem, st>>>(p);
   return launch_status();
 }
 
@@ -1818,8 +1852,9 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   }
   int code;
   switch (pl.cfg) {
-    case 0: code = conv_math_bf16x3() ? launch_gather_cfg<128, 128, 64, 64, B_NK, 1>(p, st)
-                                      : launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st); break;
+    case 0: code = !conv_math_bf16x3() ? launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st)
+                 : gather_pf2()        ? launch_gather_cfg<128, 128, 64, 64, B_NK, 1, 2>(p, st)
+                                       : launch_gather_cfg<128, 128, 64, 64, B_NK, 1>(p, st); break;
     case 1: code = conv_math_bf16x3() ? launch_gather_cfg<128, 64, 64, 32, B_NK, 1>(p, st)
                                       : launch_gather_cfg<128, 64, 64, 32, B_NK>(p, st); break;
     case 3: code = launch_gather_cfg<256, 64, 64, 64, B_NK>(p, st); break;
