@@ -262,6 +262,8 @@ typedef struct unflow_pyr_level {
   int H, W, n_mask, max_distance;
   float flow_scale, ternary_scale, smooth_scale;
 } unflow_pyr_level;
+/* sizeof(unflow_pyr_level) as compiled into the library (bindings check their struct layout against it) */
+int unflow_sizeof_pyr_level(void);
 int unflow_loss_pyramid_default(const unflow_pyr_level* levels, int n_levels, int N, int pair_shift, float* loss_acc,
                                 int with_grad, unflow_stream_t stream);
 

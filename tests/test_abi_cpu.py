@@ -79,3 +79,10 @@ def test_product_path_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|liboracle|ops_ref|model_ref", s, re.M):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_pyr_level_struct_layout_matches_the_library():
+    import ctypes
+    from unflow_amd import _lib
+    assert ctypes.sizeof(_lib.PyrLevel) == _lib.lib().unflow_sizeof_pyr_level()
+    assert _lib.PyrLevel.H.offset == 7 * ctypes.sizeof(ctypes.c_void_p)

@@ -69,3 +69,10 @@ def csz(x):
 def stream():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PyrLevel(ctypes.Structure):
+    """unflow_pyr_level of include/unflow_hip.h (argument of unflow_loss_pyramid_default)."""
+    _fields_ = [(k, ctypes.c_void_p) for k in ('im', 'flow', 'gray1', 'gray2w', 'mask', 'dist', 'd_flow')] + \
+               [(k, ctypes.c_int) for k in ('H', 'W', 'n_mask', 'max_distance')] + \
+               [(k, ctypes.c_float) for k in ('flow_scale', 'ternary_scale', 'smooth_scale')]

@@ -598,12 +598,7 @@ class FlowNetEngine:
 
     def _pyramid_levels(self, levels, wt):
         """ctypes array of unflow_pyr_level for unflow_loss_pyramid_default (rebuilt when the mask pointers change)."""
-        import ctypes
-
-        class Level(ctypes.Structure):
-            _fields_ = [(k, ctypes.c_void_p) for k in ('im', 'flow', 'gray1', 'gray2w', 'mask', 'dist', 'd_flow')] + \
-                       [(k, ctypes.c_int) for k in ('H', 'W', 'n_mask', 'max_distance')] + \
-                       [(k, ctypes.c_float) for k in ('flow_scale', 'ternary_scale', 'smooth_scale')]
+        Level = _lib.PyrLevel
         key = tuple(lv['mask'].data_ptr() for lv in levels) + (wt('ternary'), wt('smooth_2nd'))
         if self._pyr_cache is None or self._pyr_cache[0] != key:
             arr = (Level * len(levels))()

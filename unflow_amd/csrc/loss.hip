@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256) void pyr_ternary_bwd_kernel(const PyrArgs a) {
   ternary_bwd_body(L.gray1, L.gray2w, L.dist, nullptr, L.D, a.N, L.H, L.W, L.im, 3, L.flow, L.fs, L.dflow, 1, a.shift, vb);
 }
 
+UNFLOW_API int unflow_sizeof_pyr_level(void) { return (int)sizeof(unflow_pyr_level); }
+
 UNFLOW_API int unflow_loss_pyramid_default(const unflow_pyr_level* levels, int n_levels, int N, int pair_shift,
                                            float* loss_acc, int with_grad, unflow_stream_t stream) {
   if (!levels || !loss_acc) return UNFLOW_ERR_NULL;
