@@ -1718,7 +1718,8 @@ inline GatherPlan plan_gather(const GatherParams& p) {
   int maxtaps = 0;
   for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
   const int KT = (maxtaps * p.Cs + BK - 1) / BK;
-  const int max_by_k = min(16, KT / 8 > 0 ? KT / 8 : 1);  // keep >= 8 K-tiles per split
+  static const int min_kt = getenv("UNFLOW_GATHER_MIN_KT") ? max(1, atoi(getenv("UNFLOW_GATHER_MIN_KT"))) : 8;   // tuning knob
+  const int max_by_k = min(16, KT / min_kt > 0 ? KT / min_kt : 1);  // keep >= 8 K-tiles per split
   if (pl.cfg == 0) {
     const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
     if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
@@ -1756,7 +1757,8 @@ inline int plan_wgrad(const WgradParams& p) {
   const long blocks = (long)cdiv(Mp, bm) * cdiv(p.Cb, bn);
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
-  const int max_by_k = min(256, KT / 4 > 0 ? KT / 4 : 1);
+  static const int min_kt = getenv("UNFLOW_WGRAD_MIN_KT") ? max(1, atoi(getenv("UNFLOW_WGRAD_MIN_KT"))) : 8;     // tuning knob (8 vs 4: +0.8 %)
+  const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
   const bool b3 = wgrad_math_bf16x3() && cfg != 2;                // bf16x3: 49 / 37 KB of LDS per block
   const int slots = 256 * (b3 ? (cfg == 1 ? 4 : 3) : cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // fp32: single-stage LDS 32 KB / 122 regs: 4 per CU
   return fill_one_round(blocks, slots, max_by_k);
