@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libunflow_hip.so")
+LIB_PATH = os.environ.get("UNFLOW_LIB_PATH") or os.path.join(_HERE, "csrc", "libunflow_hip.so")   # override: A/B builds
 
 STATUS_TEXT = {
     -1: "null pointer argument",

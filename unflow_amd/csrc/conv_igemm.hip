@@ -85,6 +85,9 @@ __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int
 // sum|a||b| against 2.8e-8 for v_mfma_f32_32x32x2_f32 — the same accuracy class, at 1/16 of the matrix-core time per
 // product term.  The split happens once per element while the tile is staged into LDS (v_cvt_pk_bf16_f32, gfx950).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef UNFLOW_EARLY_LOADS
+#define UNFLOW_EARLY_LOADS 1
+#endif
 constexpr int LDH = BK;       // bf16 row pitch of one plane: 64 bytes, no padding (49 KB per 128x128 block -> 3 blocks per CU)
 // ... made conflict-free by an XOR swizzle of the 16-byte granule index with bits 2..3 of the row: the 16 lanes a
 // ds_read_b128 serves per cycle (rows r .. r+15, same logical granule) then touch 16 different granule slots of 256 bytes.
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   const int gsw = lh ^ ((l31 >> 2) & 3);     // swizzled granule of K16 slab 0 (slab 1: ^ 2); tile bases are multiples of 32
   // MATH == 1: the 12 term groups of the tile in LDS, with the load pieces of tile `kload` (into RA/RB) between them.
   // Two K16 slabs per tile; lane (row l31, half lh) holds k = 16*slab + 8*lh .. +7 of its row for both operands.
+  constexpr bool EARLY_LOADS = UNFLOW_EARLY_LOADS;
   auto mfma_phase = [&](int kload, float4* RA, float4* RB) {
 #pragma unroll
     for (int slab = 0; slab < 2; slab++) {
@@ -341,12 +345,21 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
 #pragma unroll
           for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ta[t]][i], bv[tb[t]][j], acc[i][j], 0, 0, 0);
-        piece_set(slab * 6 + t, kload, RA, RB);          // 12 of the 16 load pieces sit between the term groups ...
+        // two load pieces after each of the first eight term groups: a bf16x3 tile is ~0.6 us of matrix-core time, so the
+        // requests go out early in the phase and have the rest of it (plus the other resident waves) to come back
+        if (EARLY_LOADS) {
+          piece_set(2 * (slab * 6 + t), kload, RA, RB);
+          piece_set(2 * (slab * 6 + t) + 1, kload, RA, RB);
+        } else {
+          piece_set(slab * 6 + t, kload, RA, RB);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (!EARLY_LOADS) {
 #pragma unroll
-    for (int st = 12; st < 16; st++) piece_set(st, kload, RA, RB);   // ... the rest (if any) right after
+      for (int st = 12; st < 16; st++) piece_set(st, kload, RA, RB);
+    }
   };
   if constexpr (MATH == 1 && PF == 2) {
     // distance-2 prefetch: while tile kt is multiplied, tile kt+1 is already in flight in the other register set and
@@ -697,10 +710,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p
       rb[gi][j] = buf_ld1(dst_rs, ok ? (sidx * p.ldd + nb) * 4 : OOB_MARK, 0);
     }
   };
-  // 12 MFMA term groups per K tile: up to three loads after each
+  // 12 MFMA term groups per K tile: the loads go out after the first ones (six per group when UNFLOW_EARLY_LOADS)
+  constexpr int LPG = UNFLOW_EARLY_LOADS ? 6 : 3;
   auto piece = [&](int step, int kt) {
 #pragma unroll
-    for (int l = 3 * step; l < 3 * step + 3; l++)
+    for (int l = LPG * step; l < LPG * step + LPG; l++)
       if (l < NL) load_one(l, kt);
   };
   auto store_tile = [&]() {
