@@ -9,7 +9,8 @@ restatement; the custom ops go through oracle/ops_ref.c.
 
 PARITY UNPINNED for everything whose arithmetic lives in (absent) TensorFlow:
 conv / conv_transpose SAME geometry, resize_bilinear, rgb_to_grayscale, pow,
-Adam.  They follow TF1's documented semantics and are
+Adam — and for the augmentation (core/augment.py, core/spatial_transformer.py:
+tf.linspace, tf.matmul, tf.pow), which the reference does not test at all.  They follow TF1's documented semantics and are
 cross-checked fp32-vs-fp64 in tests; the reference's own tests only pin
 image_warp values, the 1st-order stencil/masks, create_outgoing_mask and
 gradient_loss~0 (tests/golden/ref_kats.json).
