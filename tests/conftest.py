@@ -32,3 +32,15 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_sessionstart(session):
+    """The oracle is torch-CPU + OpenMP: cap its threads (a 256-thread run of these small problems on the GPU host is far
+    slower than 32 threads)."""
+    n = min(os.cpu_count() or 1, 32)
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    try:
+        import torch
+        torch.set_num_threads(n)
+    except Exception:
+        pass

@@ -1,11 +1,10 @@
 """-m gpu: size-independent properties at BASELINE.json's full sizes (configs[1]: B=4, 384x512; warps at the
-768x1024 of configs[3]), where the CPU oracle is too slow to be the checker.
+768x1024 of configs[3]).  The value-level comparison with the oracle at these shapes is test_parity_fullsize_gpu.py.
 
   * ops: integer-flow backward_warp is an exact shift (bit-exact), forward_warp of zero flow has the analytic
     interior value, downsample preserves constants and means, correlation of x with itself at zero displacement
     is mean_c(x^2), correlation(a, b) and correlation(b, a) are mirror images of each other;
-  * step: gradients are bit-reproducible run to run (no float atomics on the parameter-gradient path), the
-    analytic gradient matches a central finite difference of the loss along a random direction, and the gradient of
+  * step: gradients are bit-reproducible run to run (no float atomics on the parameter-gradient path) and the gradient of
     a batch equals the mean of the gradients of its two halves (the data-parallel identity of SURVEY 8e at full size).
 """
 import numpy as np
@@ -82,7 +81,10 @@ def _images(B, H, W, seed):
     return im1, im2
 
 
-def test_step_reproducible_and_finite_difference_full(dev):
+def test_step_reproducible_full(dev):
+    """B = 4, 384x512 (the benchmarked shape): parameter gradients are bit-identical run to run (no float atomics on that
+    path); the loss scalar is a float-atomic sum of block partials.  The VALUES at this shape are checked against the fp64
+    oracle in test_parity_fullsize_gpu.py (the 5 % finite-difference check that used to live here is gone)."""
     from unflow_amd.core.engine import FlowNetCEngine
     B, H, W = 4, 384, 512
     eng = FlowNetCEngine(B, H, W, device=dev, seed=11)
@@ -91,32 +93,9 @@ def test_step_reproducible_and_finite_difference_full(dev):
     l0 = eng.fwd_bwd(im1, im2).item()
     g0 = eng.G.clone()
     l1 = eng.fwd_bwd(im1, im2).item()
-    assert torch.equal(eng.G, g0)                      # parameter gradients: bit-identical run to run
-    assert abs(l1 - l0) <= 5e-6 * abs(l0)              # the loss scalar is a float-atomic sum of block partials
+    assert torch.equal(eng.G, g0)
+    assert abs(l1 - l0) <= 5e-6 * abs(l0)
     assert torch.isfinite(g0).all()
-    # directional derivative of the DATA loss (the engine's G excludes the L2 term, which adam_step adds)
-    gen = torch.Generator().manual_seed(13)
-    d = torch.randn(eng.n_params, generator=gen).to(dev)
-    d[eng.n_weights:] = 0                               # move weights only (biases start at zero -> kinks)
-    d *= eng.P.abs().mean() / d.abs().mean()           # same scale as the weights
-    P0 = eng.P.clone()
-    l2 = lambda: 0.0004 * 0.5 * (eng.P[:eng.n_weights].double() ** 2).sum().item()
-    # the fp32 loss scalar (~7e2, atomically accumulated: ~5e-7 relative run-to-run noise) limits the step from below:
-    # eps = 5e-3 and three evaluations per side keep that noise under 1 % of the difference quotient
-    eps = 5e-3
-    vals = []
-    for sgn in (+1, -1):
-        eng.P.copy_(P0 + sgn * eps * d)
-        eng.set_input(im1, im2)
-        acc = 0.0
-        for _ in range(3):
-            eng.forward_net()
-            acc += eng.forward_loss(with_grad=False).item() - l2()
-        vals.append(acc / 3)
-    eng.P.copy_(P0)
-    fd = (vals[0] - vals[1]) / (2 * eps)
-    an = (g0.double() * d.double()).sum().item()
-    assert abs(fd - an) <= 0.05 * abs(an) + 2e-2, (fd, an)
 
 
 def test_batch_halves_average_to_full_batch_gradient(dev):

@@ -1,0 +1,211 @@
+"""HIP path vs the oracle AT THE BENCHMARKED SHAPES (BASELINE.json configs[1] and configs[3]).
+
+The step runs through the same launch path bench.py times (split-K plans and tile configs of the real shapes, fused
+4-launch loss pyramid, two captured hipGraphs) and is compared with the fp64 shadow of the oracle
+(oracle/model_ref.py; torch-CPU autograd) on the same seeded inputs:
+
+  * FlowNetC 384x512, B = 1 and B = 2: loss (rel 1e-4), final flows (EPE 1e-3 px, the north-star bar), EVERY parameter
+    gradient (2e-4 of its max AND 1e-3 mean-relative);
+  * FlowNetC 384x512, B = 4 (the benchmark batch): loss and flows (the B = 4 gradient is tied to the B = 2 one by
+    test_fullsize_gpu.py::test_batch_halves_average_to_full_batch_gradient);
+  * FlowNetCSS 768x1024, B = 1: end-to-end flows and loss vs the fp32 oracle, and the trained (last) network's flows,
+    loss and gradients vs the fp64 oracle fed the engine's own stage-2 flow (isolates the stage from the amplification
+    of fp32 noise through the two frozen stages in front of it);
+  * the 441-channel correlation at the step's shape (8 directed samples of 256x48x64, written into the concat slice).
+
+reference: src/e2eflow/core/unsupervised.py:27-164, core/flownet.py:14-81, ops/correlation_op.cu.cc:51-248."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from parity_util import check_grads, graph_step, images, max_rel, oracle_step
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_flownetc_step_384x512_vs_fp64_oracle(B, dev):
+    from unflow_amd.core.engine import FlowNetCEngine, flow_error_avg
+    H, W = 384, 512
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
+    tf_params = eng.init_params(seed=100 + B)
+    im1, im2 = images(B, H, W, 200 + B)
+    loss = graph_step(eng, im1.to(dev), im2.to(dev))
+    fw, bw = eng.final_flows()
+    got = eng.export_tf_grads()
+    loss_ref, ffw, fbw, grads = oracle_step(tf_params, im1, im2, dtype=torch.float64)
+    assert abs(loss - loss_ref) <= 1e-4 * abs(loss_ref), (loss, loss_ref)
+    for a, r in ((fw, ffw), (bw, fbw)):
+        r = r.float().to(dev)
+        assert (a - r).abs().max().item() < 1e-3
+        assert flow_error_avg(a, r).item() < 1e-3           # north-star bar: EPE within 1e-3 px of the reference path
+    worst = check_grads(got, grads, tf_params, max_tol=2e-4, mean_tol=1e-3)
+    print("B=%d 384x512: loss rel %.2e, gradients worst max-rel %.2e, worst mean-rel %.2e"
+          % (B, abs(loss - loss_ref) / abs(loss_ref), worst[0], worst[1]))
+
+
+def test_flownetc_b4_384x512_loss_and_flows_vs_oracle(dev):
+    """The benchmark batch.  Forward-only oracle in fp64 (the loss is a 6.3 M-term reduction: the fp32 oracle itself carries
+    ~1e-6); the weights and images are the ones bench.py uses (seed 0 / generator 1234)."""
+    from unflow_amd.core.engine import FlowNetCEngine, flow_error_avg
+    B, H, W = 4, 384, 512
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
+    tf_params = eng.init_params(seed=0)
+    g = torch.Generator().manual_seed(1234)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.rand(B, H, W, 3, generator=g) * 255
+    loss = graph_step(eng, im1.to(dev), im2.to(dev))
+    fw, bw = eng.final_flows()
+    loss_ref, ffw, fbw, _ = oracle_step(tf_params, im1, im2, dtype=torch.float64, backward=False)
+    assert abs(loss - loss_ref) <= 1e-4 * abs(loss_ref), (loss, loss_ref)
+    assert flow_error_avg(fw, ffw.float().to(dev)).item() < 1e-3
+    assert flow_error_avg(bw, fbw.float().to(dev)).item() < 1e-3
+    assert (fw - ffw.float().to(dev)).abs().max().item() < 1e-3
+    print("B=4 384x512 (bench inputs): loss %.4f oracle %.4f rel %.2e" % (loss, loss_ref, abs(loss - loss_ref) / abs(loss_ref)))
+
+
+def test_flownet_css_768x1024_vs_oracle(dev):
+    """BASELINE configs[3]: C -> S -> S at 768x1024 (B = 1 keeps the CPU oracle within minutes)."""
+    from unflow_amd.core.engine import FlowNetEngine, flow_error_avg, FLOW_SCALE
+    from oracle import model_ref as M
+    B, H, W = 1, 768, 1024
+    spec = 'CSS'
+    params = dict(flownet=spec, pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0)
+    eng = FlowNetEngine(B, H, W, params=params, device=dev, seed=None)
+    tf_params = M.init_params_spec(spec, seed=31)
+    eng.load_tf_params(tf_params)
+    im1, im2 = images(B, H, W, 32)
+    loss = graph_step(eng, im1.to(dev), im2.to(dev))
+    fw, bw = eng.final_flows()
+    got = eng.export_tf_grads()
+    reg = 0.0004 * 0.5 * sum((v.double() ** 2).sum().item() for k, v in tf_params.items() if k.endswith('/weights'))
+
+    # (1) end to end, fp32 oracle (an fp64 pass over three networks at this size takes many minutes on the host): the two
+    # frozen stages amplify fp32 summation-order noise through the next stage's warp, hence the wider bounds
+    loss32, ffw, fbw, _ = oracle_step(tf_params, im1, im2, params, dtype=torch.float32, backward=False)
+    e_loss = abs(loss - loss32) / abs(loss32)
+    e_fw = flow_error_avg(fw, ffw.to(dev)).item()
+    e_bw = flow_error_avg(bw, fbw.to(dev)).item()
+    print("CSS 768x1024 end-to-end vs fp32 oracle: loss rel %.2e, EPE fw %.2e bw %.2e" % (e_loss, e_fw, e_bw))
+    assert e_loss <= 2e-4 and e_fw < 2e-3 and e_bw < 2e-3
+
+    # (2) the trained network alone, fp64, fed the ENGINE's stage-2 flows: loss, flows and every gradient, tight bounds
+    scope = 'stack_2_flownet/'
+    P64 = {k: v.clone().double().requires_grad_() for k, v in tf_params.items() if k.startswith(scope)}
+    prev = eng.stages[1].act['flow2'].detach().cpu().double()
+    mean = torch.tensor(M.CHANNEL_MEAN, dtype=torch.float64) / 255.0
+    a, b = im1.double() / 255.0 - mean, im2.double() / 255.0 - mean
+
+    def stage(x, y, flow):      # flownet.py:46-57 with stop_gradient
+        flow = M.resize_bilinear_tf1(flow, H, W) * 4 * M.FLOW_SCALE
+        warp = M.image_warp(y, flow)
+        inputs = torch.cat([x, y, flow, warp, torch.abs(warp - x)], 3)
+        return M.flownet_s(P64, inputs, pre=scope + 'flownet_s/')
+    flows_fw, flows_bw = stage(a, b, prev[:B]), stage(b, a, prev[B:])
+    comb, _ = M.pyramid_loss_from_flows(im1.double(), im2.double(), flows_fw, flows_bw, params)
+    comb.backward()
+    assert abs((loss - reg) - comb.item()) <= 1e-4 * abs(comb.item()), (loss - reg, comb.item())
+    f2 = eng.stages[2].act['flow2']
+    ref2 = torch.cat([flows_fw[0], flows_bw[0]], 0).detach()
+    # flow2 in network units; the final flow is 20x this (resize is a convex combination): 5e-5 <-> 1e-3 px
+    assert (f2.cpu().double() - ref2).abs().max().item() * FLOW_SCALE * 4 < 1e-3
+    grads = {k: v.grad for k, v in P64.items()}
+    worst = check_grads(got, grads, tf_params, max_tol=2e-4, mean_tol=1e-3)
+    print("CSS last stage vs fp64 oracle: loss rel %.2e, gradients worst max-rel %.2e mean-rel %.2e"
+          % (abs((loss - reg) - comb.item()) / abs(comb.item()), worst[0], worst[1]))
+    for k, v in got.items():      # frozen stages: no data gradient at all
+        if not k.startswith(scope):
+            assert v.abs().max().item() == 0.0, k
+
+
+def test_correlation_step_shape_b4_vs_oracle(dev, oracle_lib):
+    """The correlation exactly as the B = 4 step issues it (engine.py forward / _backward_shallow): 8 directed samples of
+    256 x 48 x 64 from ONE shared feature tensor, sample n paired with (n + 4) % 8, output written into channels 32..473
+    of the 476-wide concat buffer; backward fused over both roles of every sample."""
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, ptr, stream
+    B, N, C, h, w = 4, 8, 256, 48, 64
+    rs = np.random.RandomState(77)
+    feat = rs.randn(N, h, w, C).astype(np.float32)
+    f = torch.from_numpy(feat).to(dev)
+    cat = torch.zeros(N, h, w, 476, device=dev)
+    lib = _lib.lib()
+    check(lib.unflow_correlation_nhwc_fwd(ptr(f), ptr(f), C, B, ptr(cat[..., 32:473]), 476, N, C, h, w, 1, 20, 20, 1, 2,
+                                          stream()), "correlation")
+    a_nchw = np.ascontiguousarray(feat.transpose(0, 3, 1, 2))
+    b_nchw = np.ascontiguousarray(np.roll(a_nchw, -B, axis=0))        # partner of sample n is (n + B) % N
+    attrs = dict(pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
+    ref = oracle_lib.correlation(a_nchw, b_nchw, **attrs)             # [N,441,h,w]
+    got = cat[..., 32:473].permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert cat[..., :32].abs().max().item() == 0 and cat[..., 473:].abs().max().item() == 0   # neighbours untouched
+    go = rs.randn(*ref.shape).astype(np.float32)
+    gcat = torch.zeros(N, h, w, 476, device=dev)
+    gcat[..., 32:473] = torch.from_numpy(go).to(dev).permute(0, 2, 3, 1)
+    gfeat = torch.full((N, h, w, C), 7.0, device=dev)                  # must be overwritten, not accumulated into
+    check(lib.unflow_correlation_nhwc_bwd(ptr(gcat[..., 32:473]), 476, ptr(f), ptr(f), C, B, ptr(gfeat), ptr(None), C, 1,
+                                          N, C, h, w, 1, 20, 20, 1, 2, stream()), "correlation_grad")
+    g0, g1 = oracle_lib.correlation_grad(go, a_nchw, b_nchw, **attrs)
+    want = g0 + np.roll(g1, B, axis=0)                                 # g1[n] is the gradient of sample (n + B) % N
+    gotg = gfeat.permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(gotg - want).max() <= 2e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp32"])
+def test_conv_wide_dynamic_range_elementwise(mode, dev):
+    """Accuracy class of the fp32-equivalent 3-way bf16 split, in pytest: a 3x3 conv whose inputs
+    span 4 decades per channel group, K = 9*256 = 2304, checked ELEMENT-WISE against fp64 — every output against
+    sum|x||w| of its own receptive field, the natural scale of a dot product's rounding error — in both math modes
+    (the mode is a per-process library knob, so each runs in a sub-process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UNFLOW_CONV_MATH=mode, UNFLOW_DYNRANGE_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__),
+                        "-k", "dynrange_child"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_dynrange_child(dev):
+    if os.environ.get("UNFLOW_DYNRANGE_CHILD") != "1":
+        pytest.skip("runs as a sub-process of test_conv_wide_dynamic_range_elementwise")
+    from unflow_amd.core import layers as L
+    B, H, W, Cin, Cout, k = 2, 48, 64, 256, 128, 3      # 6144 sites: the 128x128 bf16x3 tiles of the real layers
+    g = torch.Generator().manual_seed(5)
+    scale = (10.0 ** (torch.arange(Cin) % 5 - 2).float()).view(1, 1, 1, Cin)        # 1e-2 .. 1e2 across channels
+    x = torch.randn(B, H, W, Cin, generator=g) * scale
+    wgt = torch.randn(k, k, Cin, Cout, generator=g) / scale.view(1, 1, Cin, 1) * (10.0 ** (torch.arange(Cout) % 3).float())
+    xd, wd = x.to(dev), wgt.to(dev).contiguous()
+    y = torch.zeros(B, H, W, Cout, device=dev)
+    L.conv2d_fwd(xd, wd, None, y, 1, False)
+    x64, w64 = x.double().permute(0, 3, 1, 2), wgt.double().permute(3, 2, 0, 1)
+    ref = torch.nn.functional.conv2d(x64, w64, padding=1).permute(0, 2, 3, 1)
+    mag = torch.nn.functional.conv2d(x64.abs(), w64.abs(), padding=1).permute(0, 2, 3, 1)   # sum |x||w| per output
+    err = ((y.cpu().double() - ref).abs() / mag).max().item()
+    # fp32 accumulation over K = 2304: ~K^0.5 * 2^-24 typical, a few e-7 worst case (the fp32 MFMA measures the same)
+    assert err < 1e-6, err
+    # data gradient and filter gradient through the same check
+    dz = torch.randn(B, H, W, Cout, generator=g) * (10.0 ** (torch.arange(Cout) % 4 - 2).float())
+    dzd = dz.to(dev)
+    dx = torch.zeros(B, H, W, Cin, device=dev)
+    L.conv2d_bwd_data(dzd, wd, dx, 1)
+    dz64 = dz.double().permute(0, 3, 1, 2)
+    rdx = torch.nn.functional.conv_transpose2d(dz64, w64, padding=1).permute(0, 2, 3, 1)
+    mdx = torch.nn.functional.conv_transpose2d(dz64.abs(), w64.abs(), padding=1).permute(0, 2, 3, 1)
+    e2 = ((dx.cpu().double() - rdx).abs() / mdx).max().item()
+    assert e2 < 1e-6, e2
+    dw = torch.zeros(k, k, Cin, Cout, device=dev)
+    L.conv2d_bwd_filter(xd, dzd, dw, None, 1)
+    xp = torch.nn.functional.pad(x64, (1, 1, 1, 1))
+    rdw = torch.zeros(k, k, Cin, Cout, dtype=torch.float64)
+    mdw = torch.zeros_like(rdw)
+    for ky in range(k):
+        for kx in range(k):
+            patch = xp[:, :, ky:ky + H, kx:kx + W]
+            rdw[ky, kx] = torch.einsum('bchw,bohw->co', patch, dz64)
+            mdw[ky, kx] = torch.einsum('bchw,bohw->co', patch.abs(), dz64.abs())
+    e3 = ((dw.cpu().double() - rdw).abs() / mdw).max().item()
+    assert e3 < 1e-6, e3
+    print("mode %s: element-wise error / sum|a||b|: fwd %.2e dgrad %.2e wgrad %.2e"
+          % (os.environ.get("UNFLOW_CONV_MATH"), err, e2, e3))
