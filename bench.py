@@ -32,6 +32,17 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 (v_mfma_f3
 BF16X3_TERMS = 6                    # product terms of the fp32-equivalent 3-way bf16 split (csrc/conv_igemm.hip)
 
 
+CONV_MATH_TEXT = {
+    "bf16x3": "conv fwd/dgrad/wgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on the bf16 MFMA, "
+              "operands pre-split into planes by their producers (csrc/conv_planes.hip) — same error class as the fp32 MFMA",
+    "bf16x3_inline": "conv fwd/dgrad/wgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on the bf16 "
+                     "MFMA, split while staging fp32 operands (csrc/conv_igemm.hip)",
+    "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
+    "f16": "fp16 activations and weights into v_mfma_f32_32x32x16_f16, fp32 accumulate (NOT fp32-equivalent: BASELINE "
+           "configs[4]; tolerance vs the fp32 oracle stated in tests/test_f16_gpu.py)",
+}
+
+
 def conv_family_gflop(eng):
     """Algorithmic GFLOP (2*MAC, true channel counts) of all conv/deconv fwd + dgrad + wgrad launches of one step."""
     N = eng.N
@@ -68,10 +79,15 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the UNFLOW_CONV_MATH=fp32 re-measurement (a sub-process)")
     ap.add_argument("--no-parity", action="store_true", help="skip the step-1 loss/flow comparison with the CPU oracle")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f32 (default): fp32-equivalent arithmetic (UNFLOW_CONV_MATH picks the kernels); f16: fp16 activations "
+                         "and weights into the fp16 MFMA with fp32 accumulation (BASELINE configs[4], use --batch 8)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="after the K timed steps, keep stepping this long and report it as sustained_value (0 = skip)")
     args = ap.parse_args()
 
+    if args.dtype == "f16":
+        os.environ["UNFLOW_CONV_MATH"] = "f16"
     import torch
     import torch.distributed as dist
     from unflow_amd.core.engine import FlowNetCEngine
@@ -193,17 +209,14 @@ def main():
     out = {
         "metric": "image-pairs/s (fwd+bwd) FlowNet%s %dx%d" % (args.flownet, H, W), "value": round(pairs_per_s, 3), "unit": "image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "FlowNet%s unsupervised step: bidirectional fwd + census/2nd-order loss pyramid + bwd + "
                                "L2/Adam%s, %d pairs/GPU, %dx%d, 441-ch correlation (BASELINE configs[%d])"
                                % (args.flownet, " + RCCL grad all-reduce" if world > 1 else "", B, H, W,
                                   3 if args.flownet != "C" else (2 if world > 1 else 1)),
                    "global_batch": world * B, "height": H, "width": W, "parallelism": "dp%d" % world,
                    "hipgraph": graphs is not None, "final_loss": round(loss, 4),
-                   "conv_math": ("conv fwd/dgrad/wgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on "
-                                 "the bf16 MFMA — same error as the fp32 MFMA (tools/microbench/bf16x3_accuracy.hip)")
-                   if os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
-                   else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"},
+                   "conv_math": CONV_MATH_TEXT[eng.math]},
         "model_tflops_per_gpu": round(FWD_BWD_GFLOP_PER_PAIR * B / ms, 2) if (H, W, args.flownet) == (384, 512, "C") else None,
         "sustained_value": None if sustained is None else sustained["value"],
         "sustained": sustained,
@@ -216,8 +229,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_roofline and args.flownet == 'C':
         out["roofline"] = measure_roofline(eng, args)
-    if (rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C'
-            and os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"):
+    if rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C' and eng.math in ("bf16x3", "bf16x3_inline"):
         out["value_fp32_mfma_only"] = measure_alt_fp32(args)      # same step with every conv kernel on the fp32 MFMA
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.flownet == 'C':
         out["cpu_baseline"] = measure_cpu_baseline(H, W)
@@ -247,8 +259,7 @@ def measure_roofline(eng, args):
     import torch
     from unflow_amd.core import layers as L
     gflop, _ = conv_family_gflop(eng)
-    names = ["conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_filter", "conv2d_transpose_fwd",
-             "conv2d_transpose_bwd_data", "conv2d_transpose_bwd_filter"]
+    names = ["conv_fwd", "conv_bwd_data", "conv_bwd_filter", "deconv_fwd", "deconv_bwd_data", "deconv_bwd_filter"]
     orig = {n: getattr(L, n) for n in names}
     calls = []
 
@@ -294,15 +305,21 @@ def measure_roofline(eng, args):
     # (conv fwd / dgrad, 2/3 of the FLOPs) and filter-gradient kernels (1/3) both run the fp32-equivalent 3-way bf16 split =
     # bf16 peak / 6 product terms; UNFLOW_WGRAD_MATH=fp32 / UNFLOW_CONV_MATH=fp32 put the latter / both on
     # v_mfma_f32_32x32x2_f32.
-    bf16x3 = os.environ.get("UNFLOW_CONV_MATH", "bf16x3") != "fp32"
-    wg_b3 = bf16x3 and os.environ.get("UNFLOW_WGRAD_MATH", "bf16x3") != "fp32"
-    g_peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if bf16x3 else FP32_MFMA_PEAK_TFLOPS
-    w_peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if wg_b3 else FP32_MFMA_PEAK_TFLOPS
+    f16 = eng.math == "f16"
+    bf16x3 = eng.math in ("bf16x3", "bf16x3_inline")
+    wg_b3 = bf16x3 and (eng.math == "bf16x3" or os.environ.get("UNFLOW_WGRAD_MATH", "bf16x3") != "fp32")
+    g_peak = BF16_MFMA_PEAK_TFLOPS if f16 else BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if bf16x3 else FP32_MFMA_PEAK_TFLOPS
+    w_peak = BF16_MFMA_PEAK_TFLOPS if f16 else BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if wg_b3 else FP32_MFMA_PEAK_TFLOPS
     peak = 1.0 / ((2.0 / 3.0) / g_peak + (1.0 / 3.0) / w_peak)
     b3name, f32name = "fp32-equivalent 3xbf16 split, 6 terms on v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32"
-    return {"bound": "mfma", "kernel": "igemm_gather_kernel (%s) + igemm_wgrad kernel (%s) incl. their split-K reduces and "
+    if f16:
+        b3name = "fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulate"
+    kname = {"bf16x3": "igemm_pl_gather_kernel / igemm_pl_wgrad_kernel (operand planes, csrc/conv_planes.hip)",
+             "f16": "igemm_pl_gather_kernel / igemm_pl_wgrad_kernel (fp16 planes, csrc/conv_planes.hip)"}.get(
+                 eng.math, "igemm_gather_kernel / igemm_wgrad kernel (csrc/conv_igemm.hip)")
+    return {"bound": "mfma", "kernel": "%s: gather (%s) + filter gradients (%s) incl. their split-K reduces and "
                                        "the Cout=2 flow-head kernels: %d layer launches/step"
-                                       % (b3name if bf16x3 else f32name, b3name if wg_b3 else f32name, launches),
+                                       % (kname, b3name if (bf16x3 or f16) else f32name, b3name if (wg_b3 or f16) else f32name, launches),
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "peak_note": "FLOP-weighted: 2/3 of the class at %.1f (gather kernels), 1/3 at %.1f TFLOP/s (filter gradients); "

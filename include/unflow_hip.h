@@ -326,6 +326,74 @@ int unflow_stack_input_bwd(const float* d_out, int ld_out, const float* net_in4,
                            float* d_prev_flow2, int pair_shift, int N, int H, int W, int h, int w, float flow_scale,
                            unflow_stream_t stream);
 
+/* ===================================================================== */
+/* 16-bit operand planes (csrc/conv_planes.hip)                            */
+/* The conv / conv_transpose layers above can take their operands from,     */
+/* and write their results to, "operand planes": the tensor once more as    */
+/* n_planes arrays of 16-bit values with the tensor's [pixel][channel]      */
+/* layout (channel stride ld, a multiple of 4; plane p at base +            */
+/* p*plane_stride elements):                                                */
+/*   n_planes == 3: bf16 hi/mid/lo with x = hi + mid + lo exactly — the     */
+/*     products are summed from six bf16 MFMA terms with fp32 accumulation, */
+/*     fp32-class accuracy (the default training mode);                     */
+/*   n_planes == 1: fp16 (fp16 activations/weights in, fp32 accumulate).    */
+/* `base` points at channel 0 of the slice the fp32 pointer addresses.  A   */
+/* consumed slice of C channels is walked in groups of 8: channels          */
+/* C .. round_up_8(C)-1 of the plane rows must exist (ld >= that) and be 0. */
+/* Every *_pl entry point falls back to the fp32-operand kernel of the      */
+/* same op when the planes are NULL / unusable, and still writes the        */
+/* output planes (y_pl / dx_pl; may be NULL).                               */
+/* ===================================================================== */
+typedef struct unflow_planes {
+  void* base;
+  long plane_stride;
+  int ld;
+  int n_planes;
+} unflow_planes;
+
+/* fp32 [npix][ldx] (C channels) -> planes; channels C .. round_up_8(C)-1 are zero-filled. */
+int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, const unflow_planes* out, unflow_stream_t stream);
+
+/* Planes of weight tensors W[taps][R][Cc] (conv: HWIO, R = Cin, Cc = Cout; conv_transpose: R = Cout, Cc = Cin):
+ *   direct[i]     [p][tap][R][round_up_8(Cc)]  — operand of conv2d_bwd_data_pl and conv2d_transpose_fwd_pl
+ *   transposed[i] [p][tap][Cc][round_up_8(R)]  — operand of conv2d_fwd_pl and conv2d_transpose_bwd_data_pl
+ * (either may be NULL), plane stride = unflow_weight_planes_elems(...).  One launch for the whole table. */
+size_t unflow_weight_planes_elems(int taps, int R, int Cc, int transposed);
+int unflow_weight_planes_batched(int n, const float* const* w, const int* taps, const int* R, const int* Cc,
+                                 void* const* direct, void* const* transposed, int n_planes, unflow_stream_t stream);
+
+size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes);
+
+/* w_pl: the `transposed` planes of w (ld = round_up_8(Cin)). */
+int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* w, const unflow_planes* w_pl,
+                         const float* bias, float* y, int ldy, const unflow_planes* y_pl, int B, int H, int W, int Cin,
+                         int Cout, int k, int stride, int leaky, void* workspace, size_t workspace_bytes,
+                         unflow_stream_t stream);
+/* w_pl: the `direct` planes of w (ld = round_up_8(Cout)); dx_pl receives channels [pl_lo, pl_hi) of dx (the range whose
+ * values are final after this call, i.e. [act_lo, act_hi)). */
+int unflow_conv2d_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
+                              const unflow_planes* w_pl, float* dx, int lddx, const unflow_planes* dx_pl, int pl_lo,
+                              int pl_hi, int B, int H, int W, int Cin, int Cout, int k, int stride, int accumulate,
+                              const float* act_src, int ld_act, int act_lo, int act_hi, void* workspace,
+                              size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_bwd_filter_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* dz, int lddz,
+                                const unflow_planes* dz_pl, float* dw, int B, int H, int W, int Cin, int Cout, int k,
+                                int stride, void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+/* conv_transpose k4 s2: w [4,4,Cout,Cin]; fwd takes the `direct` planes (ld = round_up_8(Cin)), bwd_data the
+ * `transposed` ones (ld = round_up_8(Cout)). */
+int unflow_conv2d_transpose_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* w,
+                                   const unflow_planes* w_pl, const float* bias, float* y, int ldy,
+                                   const unflow_planes* y_pl, int B, int H, int W, int Cin, int Cout, int leaky,
+                                   void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_transpose_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
+                                        const unflow_planes* w_pl, float* dx, int lddx, const unflow_planes* dx_pl,
+                                        int pl_lo, int pl_hi, int B, int H, int W, int Cin, int Cout, int accumulate,
+                                        const float* act_src, int ld_act, int act_lo, int act_hi, void* workspace,
+                                        size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_transpose_bwd_filter_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* dz, int lddz,
+                                          const unflow_planes* dz_pl, float* dw, int B, int H, int W, int Cin, int Cout,
+                                          void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+
 /* tf.image.resize_bilinear (TF1 legacy, align_corners=False) * scale (unsupervised.py:103-104). */
 int unflow_resize_bilinear_tf1(const float* in, float* out, int B, int H, int W, int C, int out_h, int out_w,
                                float scale, unflow_stream_t stream);

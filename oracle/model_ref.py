@@ -111,36 +111,51 @@ def _vs_init(shape, fan_in, gen):
     return t
 
 
-def flownet_layer_specs(spec='C', in_channels=6):
-    """(name, kind, k, cin, cout, stride, act) in the reference's variable order."""
+def channel_mult(name):
+    """flownet.py:22-23: upper-case nets are full width, lower-case ones 3/8 width."""
+    return 1 if name in ('C', 'S') else 3 / 8
+
+
+def flownet_layer_specs(spec='C', in_channels=6, full_res=False):
+    """(name, kind, k, cin, cout, stride, act) in the reference's variable order; spec in 'C', 'S' (full width) or
+    'c', 's' (3/8 width, flownet.py:22-23); full_res adds the 'full_res/' variables of flownet.py:133-153."""
+    m = channel_mult(spec)
+    c = lambda x: int(x * m)                                                # noqa: E731
     L = []
-    if spec == 'C':
-        L += [('flownet_c_features/conv1', 'conv', 7, 3, 64, 2, True),
-              ('flownet_c_features/conv2', 'conv', 5, 64, 128, 2, True),
-              ('flownet_c_features/conv3', 'conv', 5, 128, 256, 2, True)]
+    if spec in ('C', 'c'):
+        L += [('flownet_c_features/conv1', 'conv', 7, 3, c(64), 2, True),
+              ('flownet_c_features/conv2', 'conv', 5, c(64), c(128), 2, True),
+              ('flownet_c_features/conv3', 'conv', 5, c(128), c(256), 2, True)]
         pre = 'flownet_c/'
-        L += [(pre + 'conv_redir', 'conv', 1, 256, 32, 1, True),
-              (pre + 'conv3_1', 'conv', 3, 473, 256, 1, True)]
-        skip2 = 128
+        L += [(pre + 'conv_redir', 'conv', 1, c(256), c(32), 1, True),
+              (pre + 'conv3_1', 'conv', 3, c(32) + 441, c(256), 1, True)]
     else:
         pre = 'flownet_s/'
-        L += [(pre + 'conv1', 'conv', 7, in_channels, 64, 2, True),
-              (pre + 'conv2', 'conv', 5, 64, 128, 2, True),
-              (pre + 'conv3', 'conv', 5, 128, 256, 2, True),
-              (pre + 'conv3_1', 'conv', 3, 256, 256, 1, True)]
-        skip2 = 128
-    L += [(pre + 'conv4', 'conv', 3, 256, 512, 2, True), (pre + 'conv4_1', 'conv', 3, 512, 512, 1, True),
-          (pre + 'conv5', 'conv', 3, 512, 512, 2, True), (pre + 'conv5_1', 'conv', 3, 512, 512, 1, True),
-          (pre + 'conv6', 'conv', 3, 512, 1024, 2, True), (pre + 'conv6_1', 'conv', 3, 1024, 1024, 1, True),
-          (pre + 'flow6', 'conv', 3, 1024, 2, 1, False),
-          (pre + 'deconv5', 'deconv', 4, 1024, 512, 2, True), (pre + 'flow6_up5', 'deconv', 4, 2, 2, 2, False),
-          (pre + 'flow5', 'conv', 3, 1026, 2, 1, False),
-          (pre + 'deconv4', 'deconv', 4, 1026, 256, 2, True), (pre + 'flow5_up4', 'deconv', 4, 2, 2, 2, False),
-          (pre + 'flow4', 'conv', 3, 770, 2, 1, False),
-          (pre + 'deconv3', 'deconv', 4, 770, 128, 2, True), (pre + 'flow4_up3', 'deconv', 4, 2, 2, 2, False),
-          (pre + 'flow3', 'conv', 3, 386, 2, 1, False),
-          (pre + 'deconv2', 'deconv', 4, 386, 64, 2, True), (pre + 'flow3_up2', 'deconv', 4, 2, 2, 2, False),
-          (pre + 'flow2', 'conv', 3, skip2 + 64 + 2, 2, 1, False)]
+        L += [(pre + 'conv1', 'conv', 7, in_channels, c(64), 2, True),
+              (pre + 'conv2', 'conv', 5, c(64), c(128), 2, True),
+              (pre + 'conv3', 'conv', 5, c(128), c(256), 2, True),
+              (pre + 'conv3_1', 'conv', 3, c(256), c(256), 1, True)]
+    cat5, cat4, cat3, cat2 = c(512) + c(512) + 2, c(512) + c(256) + 2, c(256) + c(128) + 2, c(128) + c(64) + 2
+    L += [(pre + 'conv4', 'conv', 3, c(256), c(512), 2, True), (pre + 'conv4_1', 'conv', 3, c(512), c(512), 1, True),
+          (pre + 'conv5', 'conv', 3, c(512), c(512), 2, True), (pre + 'conv5_1', 'conv', 3, c(512), c(512), 1, True),
+          (pre + 'conv6', 'conv', 3, c(512), c(1024), 2, True), (pre + 'conv6_1', 'conv', 3, c(1024), c(1024), 1, True),
+          (pre + 'flow6', 'conv', 3, c(1024), 2, 1, False),
+          (pre + 'deconv5', 'deconv', 4, c(1024), c(512), 2, True), (pre + 'flow6_up5', 'deconv', 4, 2, 2, 2, False),
+          (pre + 'flow5', 'conv', 3, cat5, 2, 1, False),
+          (pre + 'deconv4', 'deconv', 4, cat5, c(256), 2, True), (pre + 'flow5_up4', 'deconv', 4, 2, 2, 2, False),
+          (pre + 'flow4', 'conv', 3, cat4, 2, 1, False),
+          (pre + 'deconv3', 'deconv', 4, cat4, c(128), 2, True), (pre + 'flow4_up3', 'deconv', 4, 2, 2, 2, False),
+          (pre + 'flow3', 'conv', 3, cat3, 2, 1, False),
+          (pre + 'deconv2', 'deconv', 4, cat3, c(64), 2, True), (pre + 'flow3_up2', 'deconv', 4, 2, 2, 2, False),
+          (pre + 'flow2', 'conv', 3, cat2, 2, 1, False)]
+    if full_res:
+        fr = pre + 'full_res/'
+        cat1 = c(64) + c(32) + 2
+        cat0 = in_channels + c(16) + 2
+        L += [(fr + 'deconv1', 'deconv', 4, cat2, c(32), 2, True), (fr + 'flow2_up1', 'deconv', 4, 2, 2, 2, False),
+              (fr + 'flow1', 'conv', 3, cat1, 2, 1, False),
+              (fr + 'deconv0', 'deconv', 4, cat1, c(16), 2, True), (fr + 'flow1_up0', 'deconv', 4, 2, 2, 2, False),
+              (fr + 'flow0', 'conv', 3, cat0, 2, 1, False)]
     return L
 
 
@@ -167,8 +182,8 @@ def _dc(P, pre, name, x, act=True):
     return conv2d_transpose(x, P[pre + name + '/weights'], P[pre + name + '/biases'], act)
 
 
-def flownet_upconv(P, pre, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
-    """_flownet_upconv, flownet.py:89-131 (full_res off)."""
+def flownet_upconv(P, pre, conv6_1, conv5_1, conv4_1, conv3_1, conv2, conv1=None, inputs=None, full_res=False):
+    """_flownet_upconv, flownet.py:89-155."""
     flow6 = _cv(P, pre, 'flow6', conv6_1, act=False)
     deconv5 = _dc(P, pre, 'deconv5', conv6_1)
     flow6_up5 = _dc(P, pre, 'flow6_up5', flow6, act=False)
@@ -186,7 +201,19 @@ def flownet_upconv(P, pre, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
     flow3_up2 = _dc(P, pre, 'flow3_up2', flow3, act=False)
     concat2 = torch.cat([conv2, deconv2, flow3_up2], 1)
     flow2 = _cv(P, pre, 'flow2', concat2, act=False)
-    return [flow2, flow3, flow4, flow5, flow6]
+    flows = [flow2, flow3, flow4, flow5, flow6]
+    if full_res:                                                            # flownet.py:133-153
+        fr = pre + 'full_res/'
+        deconv1 = _dc(P, fr, 'deconv1', concat2)
+        flow2_up1 = _dc(P, fr, 'flow2_up1', flow2, act=False)
+        concat1 = torch.cat([conv1, deconv1, flow2_up1], 1)
+        flow1 = _cv(P, fr, 'flow1', concat1, act=False)
+        deconv0 = _dc(P, fr, 'deconv0', concat1)
+        flow1_up0 = _dc(P, fr, 'flow1_up0', flow1, act=False)
+        concat0 = torch.cat([inputs, deconv0, flow1_up0], 1)
+        flow0 = _cv(P, fr, 'flow0', concat0, act=False)
+        flows = [flow0, flow1] + flows
+    return flows
 
 
 def flownet_c_features(P, im_nhwc):
@@ -219,8 +246,8 @@ def flownet_c(P, conv3_a, conv3_b, conv2_a, return_internals=False):
     return flows
 
 
-def flownet_s(P, inputs_nhwc, pre='flownet_s/'):
-    """flownet.py:166-192 (full_res off)."""
+def flownet_s(P, inputs_nhwc, pre='flownet_s/', full_res=False):
+    """flownet.py:166-192 (the channel multiplier is implied by the shapes of P)."""
     x = inputs_nhwc.permute(0, 3, 1, 2)
     conv1 = _cv(P, pre, 'conv1', x, 2)
     conv2 = _cv(P, pre, 'conv2', conv1, 2)
@@ -232,21 +259,23 @@ def flownet_s(P, inputs_nhwc, pre='flownet_s/'):
     conv5_1 = _cv(P, pre, 'conv5_1', conv5, 1)
     conv6 = _cv(P, pre, 'conv6', conv5_1, 2)
     conv6_1 = _cv(P, pre, 'conv6_1', conv6, 1)
-    res = flownet_upconv(P, pre, conv6_1, conv5_1, conv4_1, conv3_1, conv2)
+    res = flownet_upconv(P, pre, conv6_1, conv5_1, conv4_1, conv3_1, conv2, conv1, x, full_res=full_res)
     return [t.permute(0, 2, 3, 1) for t in res]
 
 
-def flownet(P, im1, im2, flownet_spec='C', backward_flow=False, train_all=False):
-    """flownet.py:14-81 (full_resolution off).  'C', 'S' and stacked specs ('CS', 'CSS', 'SS' ...): every later net is
+def flownet(P, im1, im2, flownet_spec='C', backward_flow=False, train_all=False, full_resolution=False):
+    """flownet.py:14-81.  'C', 'S', 'c', 's' and stacked specs ('CS', 'CSS', 'SS' ...): every later net is
     a FlowNetS on [im1, im2, flow*20 upsampled, warp(im2, flow), |warp - im1|] of the previous net's finest flow,
     with stop_gradient on flow/warp/diff unless train_all (:46-57).  Variable scopes: first net 'flownet_c*/' or
     'flownet_s/', net i >= 1 'stack_<i>_flownet/flownet_s/' (:72-77)."""
     H, W = im1.shape[1:3]
     flows_fw, flows_bw = [], []
     for i, name in enumerate(flownet_spec):
-        assert name in ('C', 'S')
+        assert name in ('C', 'S', 'c', 's')
         scope = '' if i == 0 else 'stack_%d_flownet/' % i
-        if name == 'C':
+        full_res = full_resolution and i == len(flownet_spec) - 1           # flownet.py:24
+        if name in ('C', 'c'):
+            assert not full_res, "flownet_c passes neither conv1 nor inputs to _flownet_upconv (flownet.py:231-233)"
             assert i == 0, 'FlowNetS must be used for refinement networks'
             _, conv2_a, conv3_a = flownet_c_features(P, im1)
             _, conv2_b, conv3_b = flownet_c_features(P, im2)
@@ -264,7 +293,7 @@ def flownet(P, im1, im2, flownet_spec='C', backward_flow=False, train_all=False)
                     inputs = torch.cat([a, b, flow, warp, diff], 3)
                 else:
                     inputs = torch.cat([a, b], 3)
-                return flownet_s(P, inputs, pre=scope + 'flownet_s/')
+                return flownet_s(P, inputs, pre=scope + 'flownet_s/', full_res=full_res)
             stacked = len(flows_fw) > 0
             flows_fw.append(_s(im1, im2, flows_fw[-1][0] if stacked else None))
             if backward_flow:
@@ -274,13 +303,14 @@ def flownet(P, im1, im2, flownet_spec='C', backward_flow=False, train_all=False)
     return flows_fw
 
 
-def init_params_spec(flownet_spec='C', seed=0):
+def init_params_spec(flownet_spec='C', seed=0, full_res=False):
     """Variables of a (possibly stacked) spec with the reference's scope names."""
     gen = torch.Generator().manual_seed(seed)
     P = OrderedDict()
     for i, name in enumerate(flownet_spec):
         scope = '' if i == 0 else 'stack_%d_flownet/' % i
-        for lname, kind, k, cin, cout, stride, act in flownet_layer_specs(name, 14 if i > 0 else 6):
+        fr = full_res and i == len(flownet_spec) - 1
+        for lname, kind, k, cin, cout, stride, act in flownet_layer_specs(name, 14 if i > 0 else 6, fr):
             lname = scope + lname
             if kind == 'conv':
                 P[lname + '/weights'] = _vs_init((k, k, cin, cout), k * k * cin, gen)
@@ -553,7 +583,7 @@ def regularization_loss(P, scale=0.0004):
 
 
 def pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params, border_mask=None):
-    """unsupervised.py:85-147 (full_res off), given un-normalised images in [0,255] — or, with `border_mask` given
+    """unsupervised.py:85-147, given un-normalised images in [0,255] — or, with `border_mask` given
     (the augmented per-sample mask of unsupervised.py:39-49), the geometrically augmented images in [0,1]."""
     if border_mask is None:
         im1 = im1 / 255.0
@@ -561,8 +591,14 @@ def pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params, border_mask=No
         border_mask = create_border_mask(im1, 0.1)
     layer_weights = [12.7, 4.35, 3.9, 3.4, 1.1]
     layer_patch_distances = [3, 2, 2, 1, 1]
-    im1_s, im2_s, mask_s = downsample(im1, 4), downsample(im2, 4), downsample(border_mask, 4)
-    final_flow_scale = FLOW_SCALE
+    if params.get('full_res'):                                              # unsupervised.py:89-97
+        layer_weights = [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]
+        layer_patch_distances = [3, 3] + layer_patch_distances
+        im1_s, im2_s, mask_s = im1, im2, border_mask
+        final_flow_scale = FLOW_SCALE * 4
+    else:
+        im1_s, im2_s, mask_s = downsample(im1, 4), downsample(im2, 4), downsample(border_mask, 4)
+        final_flow_scale = FLOW_SCALE
     combined = 0.0
     terms = {k: 0.0 for k in LOSSES}
     need = {l for l in LOSSES if params.get(l + '_weight')}
@@ -676,13 +712,15 @@ def unsupervised_loss(P, im1, im2, params=None, return_flow=False, augment=None)
         im1, im2, border_mask, p1, p2 = augment_apply(im1, im2, augment)   # losses see the geo images (:63-65)
         a, b = p1 - mean, p2 - mean                                         # the network the photo ones (:67-68)
     flows_fw, flows_bw = flownet(P, a, b, flownet_spec=params.get('flownet', 'S'), backward_flow=True,
-                                 train_all=bool(params.get('train_all')))
+                                 train_all=bool(params.get('train_all')), full_resolution=bool(params.get('full_res')))
     flows_fw, flows_bw = flows_fw[-1], flows_bw[-1]
     combined, terms = pyramid_loss_from_flows(im1, im2, flows_fw, flows_bw, params, border_mask=border_mask)
     final_loss = combined + regularization_loss(P)
     if not return_flow:
         return final_loss
     H, W = im1.shape[1:3]
+    if params.get('full_res'):                                              # unsupervised.py:95-97
+        return final_loss, flows_fw[0] * FLOW_SCALE * 4, flows_bw[0] * FLOW_SCALE * 4, terms
     ffw = resize_bilinear_tf1(flows_fw[0], H, W) * FLOW_SCALE * 4
     fbw = resize_bilinear_tf1(flows_bw[0], H, W) * FLOW_SCALE * 4
     return final_loss, ffw, fbw, terms

@@ -112,16 +112,44 @@ def test_two_rank_sharded_step_equals_one_rank_full_batch(tmp_path):
 
 
 def test_engine_layer_table_matches_reference_variables():
-    """Host logic of the engine that needs no GPU: the layer list equals the oracle's variable list and the
-    channel padding is zero-extension at the END of Cin."""
+    """Host logic of the engine that needs no GPU: for every network kind (full / 3/8 width, first / refinement stage,
+    with / without the full_res decoder) the layer list equals the oracle's variable list, every input channel of the
+    reference has exactly one physical slot, and the backward plan applies each leaky-ReLU derivative exactly once."""
     from unflow_amd.core import engine
     from oracle import model_ref as M
-    layers = engine.flownet_c_layers()
-    spec = M.flownet_layer_specs('C')
-    assert [l.name for l in layers] == [s[0] for s in spec]
-    for l, s in zip(layers, spec):
-        assert (l.kind, l.k, l.cin, l.cout, l.stride, l.act) == s[1:]
-        assert l.cin_p >= l.cin and (l.cin_p % 4 == 0 or l.cin == 2)
+
+    class FakeEng:
+        pass
+    for kind, index, full_res in [('C', 0, False), ('c', 0, False), ('S', 0, False), ('S', 1, False), ('s', 0, False),
+                                  ('S', 0, True), ('S', 1, True), ('s', 1, True)]:
+        st = engine._Stage(FakeEng(), kind, index, full_res)
+        spec = M.flownet_layer_specs(kind, 14 if index else 6, full_res)
+        scope = '' if index == 0 else 'stack_%d_flownet/' % index
+        assert [l.name for l in st.layers] == [scope + s[0] for s in spec], (kind, index, full_res)
+        for l, sp in zip(st.layers, spec):
+            assert (l.kind, l.k, l.cin, l.cout, l.stride, l.act) == sp[1:], (l.name, sp)
+            assert l.cin_p >= l.cin and (l.cin_p % 4 == 0 or l.cin == 2)
+            slots = sorted((plo, plo + n) for plo, _, n in l.in_map)
+            assert sum(n for _, _, n in l.in_map) == l.cin and sorted(t for _, t, _ in l.in_map)[0] == 0
+            assert all(a[1] <= b[0] for a, b in zip(slots, slots[1:])) and slots[-1][1] <= l.cin_p
+        # every activated layer's output segment gets its derivative from exactly one data-gradient call
+        applied = {}
+        for op, first, lo, hi in st.bwd:
+            if hi > lo:
+                key = (op.src[0], op.src[1] + lo, op.src[1] + hi)
+                applied[key] = applied.get(key, 0) + 1
+        covered = set()
+        for (b, lo, hi), cnt in applied.items():
+            assert cnt == 1
+            covered.update((b, ch) for ch in range(lo, hi))
+        for op in st.ops:
+            if op.kind == 'layer' and op.l.act:
+                b, lo, hi = op.dst
+                consumers = [o for o in st.ops if o.src[0] == b]
+                if consumers:
+                    assert all((b, ch) in covered for ch in range(lo, hi)), (op.l.name, op.dst)
+    layers = engine._Stage(FakeEng(), 'C', 0).layers
     n_logical = sum(l.k * l.k * l.cin * l.cout + l.cout for l in layers)
     assert n_logical == 39175298
     assert engine.LAYER_WEIGHTS == [12.7, 4.35, 3.9, 3.4, 1.1] and engine.LAYER_PATCH_DISTANCES == [3, 2, 2, 1, 1]
+    assert engine.LAYER_WEIGHTS_FULL_RES == [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]

@@ -1,0 +1,232 @@
+"""-m gpu: the operand-plane kernels of csrc/conv_planes.hip through the C ABI (unflow_*_pl) vs fp64 torch-CPU:
+plane producers (exactness of the 3-way bf16 split, fp16 rounding, weight planes in both layouts), conv / conv_transpose
+fwd, dgrad (stride 1 and the 4 parity classes of stride 2), wgrad (the ds_read_b64_tr_b16 path), every tile config, the
+split-K reduce, odd channel counts with zero-padded plane tails, channel-slice views, the fused epilogues and the output
+planes they write.
+
+Tolerances: n_planes = 3 is fp32-equivalent (six exact bf16 products, fp32 accumulation): 2e-5 of the output scale like the
+fp32-MFMA kernels (tests/test_conv_gpu.py).  n_planes = 1 (fp16 operands, fp32 accumulate): operands carry 2^-11 relative
+rounding, a K-term dot product of zero-mean terms ~ 2^-11 * sqrt(2/K) * sum|a||b| / sqrt(K): stated bound 2e-3 of the
+output scale."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def bf16_bits_to_f64(t):
+    return (t.to(torch.int32) << 16).view(torch.float32).double()
+
+
+def planes_value(pl):
+    """fp64 value an int16 planes tensor [P, ...] encodes (3: hi + mid + lo bf16; 1: fp16)."""
+    if pl.shape[0] == 1:
+        return pl[0].view(torch.float16).double()
+    return bf16_bits_to_f64(pl[0]) + bf16_bits_to_f64(pl[1]) + bf16_bits_to_f64(pl[2])
+
+
+TOL = {3: 2e-5, 1: 2e-3}
+
+
+def make_pt(x, dev, P, extra=0, offset=0):
+    """PT of x (NHWC) living as a channel slice [offset, offset + C) of a wider zero buffer; planes filled by the
+    library (unflow_planes_from_f32)."""
+    from unflow_amd.core import layers as L
+    B, H, W, C = x.shape
+    buf = L.PT.alloc((B, H, W, offset + C + extra), dev, P)
+    buf.t[..., offset:offset + C] = x.to(dev)
+    pt = buf.sl(offset, offset + C) if (offset or extra) else buf
+    L.planes_from_f32(pt.t, pt.pl)
+    return pt
+
+
+def weight_planes(w, dev, P):
+    """(direct, transposed) planes of W[k,k,R,Cc] via the batched library call."""
+    import ctypes
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, stream
+    k, _, R, Cc = w.shape
+    r8 = lambda c: (c + 7) // 8 * 8                                         # noqa: E731
+    d = torch.zeros(P, k * k, R, r8(Cc), dtype=torch.int16, device=dev)
+    t = torch.zeros(P, k * k, Cc, r8(R), dtype=torch.int16, device=dev)
+    wd = w.to(dev).contiguous()
+    check(_lib.lib().unflow_weight_planes_batched(1, (ctypes.c_void_p * 1)(wd.data_ptr()), (ctypes.c_int * 1)(k * k),
+                                                  (ctypes.c_int * 1)(R), (ctypes.c_int * 1)(Cc),
+                                                  (ctypes.c_void_p * 1)(d.data_ptr()), (ctypes.c_void_p * 1)(t.data_ptr()), P,
+                                                  stream()), "weight_planes")
+    return wd, d, t
+
+
+@pytest.mark.parametrize("P", [3, 1])
+def test_plane_producers(P, dev):
+    from unflow_amd.core import layers as L
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 7, 13, generator=g) * (10.0 ** torch.randint(-6, 6, (2, 5, 7, 13), generator=g).float())
+    pt = make_pt(x, dev, P, extra=3, offset=4)
+    val = planes_value(pt.pl.cpu())
+    if P == 3:
+        assert torch.equal(val[..., :13], x.double())                      # hi + mid + lo == x EXACTLY
+    else:
+        assert torch.equal(val[..., :13].float(), x.half().float())        # round-to-nearest-even fp16
+    assert torch.all(val[..., 13:16] == 0)                                   # zero tail up to the next multiple of 8
+    # weights, both layouts
+    w = torch.randn(3, 3, 10, 12, generator=g)
+    wd, d, t = weight_planes(w, dev, P)
+    vd, vt = planes_value(d.cpu()), planes_value(t.cpu())                    # [9,10,16], [9,12,16]
+    ref = w.double().reshape(9, 10, 12)
+    if P == 1:
+        ref = ref.float().half().double()
+    assert torch.equal(vd[..., :12], ref) and torch.all(vd[..., 12:] == 0)
+    assert torch.equal(vt[..., :10], ref.transpose(1, 2)) and torch.all(vt[..., 10:] == 0)
+
+
+# (B, H, W, Cin, Cout, k, stride)
+CONV_CASES = [
+    (2, 24, 32, 4, 64, 7, 2),      # conv1: 4 -> 8 plane channels, one tap per K granule, 128x64 tile
+    (2, 16, 24, 64, 128, 5, 2),    # conv2
+    (2, 48, 64, 128, 128, 3, 1),   # 6144 sites: 128x128 tiles, no split
+    (1, 12, 16, 476, 256, 3, 1),   # conv3_1: 476 -> 480 plane channels (granules straddle taps? 60 per tap)
+    (1, 12, 16, 388, 64, 3, 1),    # odd granule count per tap (49): K tiles straddle taps
+    (2, 6, 8, 256, 512, 3, 2),     # conv4-like, asymmetric pad
+    (8, 6, 8, 512, 1024, 3, 2),    # conv6: split-K + reduce epilogue
+    (8, 6, 8, 1024, 1024, 3, 1),   # conv6_1: split-K
+    (2, 12, 16, 256, 32, 1, 1),    # conv_redir: 64x64 tile (fwd), pointwise kernel (dgrad)
+    (1, 10, 14, 40, 44, 3, 1),     # M and N tails
+    (2, 12, 16, 96, 12, 1, 1),     # 3/8-width conv_redir: Cout 12 (K tail granule of the dgrad reads zeros)
+]
+
+
+@pytest.mark.parametrize("P", [3, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_planes_vs_fp64(case, P, dev):
+    from unflow_amd.core import layers as L
+    B, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(k, k, Cin, Cout, generator=g) * (1.0 / np.sqrt(k * k * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    if P == 1:      # compare against the fp16-rounded operands' exact result?  No: against the true fp32 problem.
+        pass
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    pt_, pb = ((k - 1) // 2, k // 2) if stride == 1 else (None, None)
+    from oracle import model_ref as M
+    y_ref = M.conv2d(xr.permute(0, 3, 1, 2), wr, br, stride, act=True).permute(0, 2, 3, 1)
+    gy = torch.randn(y_ref.shape, generator=g).double()
+    dz_ref = gy * torch.where(y_ref.detach() > 0, 1.0, 0.1)
+    y_ref.backward(gy)
+
+    X = make_pt(x, dev, P, extra=8)
+    wd, w_dir, w_tr = weight_planes(w, dev, P)
+    Ho, Wo = L.out_hw(H, W, stride)
+    Y = L.PT.alloc((B, Ho, Wo, Cout + 8), dev, P)
+    Y.t.fill_(7.0)
+    Yv = Y.sl(0, Cout)
+    L.conv_fwd(X, wd, w_tr, b.to(dev), Yv, stride, True)
+    assert rel_err(Yv.t, y_ref) < TOL[P]
+    assert torch.all(Y.t[..., Cout:] == 7.0)                                # neighbours of the slice untouched
+    # the output planes are the split of the fp32 output, element for element
+    got_pl = planes_value(Y.pl.cpu())[..., :Cout]
+    if P == 3:
+        assert torch.equal(got_pl, Yv.t.cpu().double())
+    else:
+        assert torch.equal(got_pl.float(), Yv.t.cpu().half().float())
+
+    DZ = make_pt(dz_ref.float(), dev, P, extra=4)
+    Cp4 = (Cin + 3) // 4 * 4
+    DX = L.PT.alloc((B, H, W, Cp4), dev, P)
+    DX.t.fill_(3.0)
+    L.conv_bwd_data(DZ, wd, w_dir, DX, stride, accumulate=False)
+    assert rel_err(DX.t[..., :Cin], xr.grad) < TOL[P]
+    # accumulate + activation-derivative epilogue + planes only for the activated range
+    base = torch.randn(B, H, W, Cp4, generator=g).to(dev)
+    src = torch.randn(B, H, W, Cp4, generator=g).to(dev)
+    DX2 = L.PT.alloc((B, H, W, Cp4), dev, P)
+    DX2.t.copy_(base)
+    hi = Cp4 // 2 // 4 * 4
+    L.conv_bwd_data(DZ, wd, w_dir, DX2, stride, accumulate=True, act_src=src, act_lo=0, act_hi=hi)
+    expect = base + DX.t
+    slope = torch.where(src > 0, torch.ones_like(src), torch.full_like(src, 0.1))
+    expect[..., :hi] *= slope[..., :hi]
+    assert rel_err(DX2.t, expect) < TOL[P]
+    pl2 = planes_value(DX2.pl.cpu())
+    if P == 3:
+        assert torch.equal(pl2[..., :hi], DX2.t.cpu().double()[..., :hi])
+    assert torch.all(pl2[..., hi:] == 0)                                     # outside [act_lo, act_hi): planes untouched
+
+    dw = torch.full((k, k, Cin, Cout), 9.0, device=dev)
+    L.conv_bwd_filter(X, DZ, dw, stride)
+    assert rel_err(dw, wr.grad) < (3e-5 if P == 3 else TOL[P])
+
+
+# (B, H, W, Cin, Cout)   H,W = INPUT size; output is 2H x 2W
+DECONV_CASES = [
+    (8, 6, 8, 1024, 512),     # deconv5
+    (2, 12, 16, 1028, 256),   # deconv4: 1028 -> 1032 plane channels
+    (1, 24, 32, 772, 128),    # deconv3
+    (1, 24, 32, 388, 64),     # deconv2
+    (2, 12, 16, 76, 12),      # 3/8-width full_res deconv1: Cout 12
+]
+
+
+@pytest.mark.parametrize("P", [3, 1])
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_deconv_planes_vs_fp64(case, P, dev):
+    from unflow_amd.core import layers as L
+    from oracle import model_ref as M
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(4, 4, Cout, Cin, generator=g) * (1.0 / np.sqrt(4 * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    y_ref = M.conv2d_transpose(xr.permute(0, 3, 1, 2), wr, br, act=True).permute(0, 2, 3, 1)
+    gy = torch.randn(y_ref.shape, generator=g).double()
+    dz_ref = gy * torch.where(y_ref.detach() > 0, 1.0, 0.1)
+    y_ref.backward(gy)
+
+    X = make_pt(x, dev, P)
+    wd, w_dir, w_tr = weight_planes(w, dev, P)
+    Y = L.PT.alloc((B, 2 * H, 2 * W, Cout + 4), dev, P)
+    Yv = Y.sl(0, Cout)
+    L.deconv_fwd(X, wd, w_dir, b.to(dev), Yv, True)
+    assert rel_err(Yv.t, y_ref) < TOL[P]
+    if P == 3:
+        assert torch.equal(planes_value(Y.pl.cpu())[..., :Cout], Yv.t.cpu().double())
+    DZ = make_pt(dz_ref.float(), dev, P)
+    DX = L.PT.alloc((B, H, W, Cin), dev, P)
+    DX.t.fill_(5.0)
+    L.deconv_bwd_data(DZ, wd, w_tr, DX, accumulate=False)
+    assert rel_err(DX.t, xr.grad) < TOL[P]
+    DX2 = L.PT.alloc((B, H, W, Cin), dev, P)
+    DX2.t.fill_(1.0)
+    L.deconv_bwd_data(DZ, wd, w_tr, DX2, accumulate=True)
+    assert rel_err(DX2.t, DX.t + 1.0) < TOL[P]
+    dw = torch.full((4, 4, Cout, Cin), 9.0, device=dev)
+    L.deconv_bwd_filter(X, DZ, dw)
+    assert rel_err(dw, wr.grad) < (3e-5 if P == 3 else TOL[P])
+
+
+def test_planes_kernels_match_inline_split_bitwise_close(dev):
+    """The plane kernels and conv_igemm.hip's in-kernel split compute the SAME six bf16 product terms; only the fp32
+    accumulation order inside a K tile differs (term-major vs plane order) — results agree to fp32 rounding."""
+    from unflow_amd.core import layers as L
+    B, H, W, Cin, Cout, k = 2, 48, 64, 128, 128, 3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(k, k, Cin, Cout, generator=g) / np.sqrt(k * k * Cin)
+    X = make_pt(x, dev, 3)
+    wd, w_dir, w_tr = weight_planes(w, dev, 3)
+    y_pl = torch.zeros(B, H, W, Cout, device=dev)
+    L.conv_fwd(X, wd, w_tr, None, y_pl, 1, False)
+    y_in = torch.zeros(B, H, W, Cout, device=dev)
+    L.conv2d_fwd(X.t, wd, None, y_in, 1, False)
+    assert rel_err(y_pl, y_in) < 2e-6

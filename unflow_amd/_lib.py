@@ -41,6 +41,8 @@ def lib():
         _lib.unflow_status_string.restype = ctypes.c_char_p
         _lib.unflow_correlation_workspace_bytes.restype = ctypes.c_size_t
         _lib.unflow_conv_workspace_bytes.restype = ctypes.c_size_t
+        _lib.unflow_conv_pl_workspace_bytes.restype = ctypes.c_size_t
+        _lib.unflow_weight_planes_elems.restype = ctypes.c_size_t
     return _lib
 
 
@@ -66,9 +68,22 @@ def csz(x):
     return ctypes.c_size_t(int(x))
 
 
-def stream():
+def stream(device=None):
+    """The current HIP stream of `device` (default: the current device) — pass the tensors' device when it may differ."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Planes(ctypes.Structure):
+    """unflow_planes of include/unflow_hip.h: 16-bit operand planes of a tensor / channel slice."""
+    _fields_ = [('base', ctypes.c_void_p), ('plane_stride', ctypes.c_long), ('ld', ctypes.c_int), ('n_planes', ctypes.c_int)]
+
+
+def planes_of(pl):
+    """ctypes pointer to the unflow_planes of an int16 planes view [P, N, H, W, C] (or [P, ..., C] weights), or NULL."""
+    if pl is None:
+        return None
+    return ctypes.byref(Planes(pl.data_ptr(), pl.stride(0), pl.stride(-2), pl.shape[0]))
 
 
 class PyrLevel(ctypes.Structure):

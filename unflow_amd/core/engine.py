@@ -36,6 +36,8 @@ FLOW_SCALE = 5.0                                   # flownet.py:11
 CHANNEL_MEAN = [104.920005, 110.1753, 114.785955]  # core/input.py:45
 LAYER_WEIGHTS = [12.7, 4.35, 3.9, 3.4, 1.1]        # unsupervised.py:87
 LAYER_PATCH_DISTANCES = [3, 2, 2, 1, 1]            # unsupervised.py:88
+LAYER_WEIGHTS_FULL_RES = [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]     # unsupervised.py:90
+LAYER_PATCH_DISTANCES_FULL_RES = [3, 3] + LAYER_PATCH_DISTANCES     # unsupervised.py:91
 L2_SCALE = 0.0004                                  # flownet.py:176
 LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']  # unsupervised.py:15
 
@@ -46,248 +48,343 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
-class Layer:
-    __slots__ = ('name', 'kind', 'k', 'cin', 'cout', 'stride', 'act', 'cin_p', 'w', 'b', 'dw', 'db')
+def round8(c):
+    return (c + 7) // 8 * 8
 
-    def __init__(self, name, kind, k, cin, cout, stride, act):
+
+def conv_math_mode():
+    """How the conv / conv_transpose layers multiply (UNFLOW_CONV_MATH):
+       'bf16x3'  (default) operands pre-split into three bf16 planes by their producers, six bf16 MFMA terms, fp32
+                 accumulate — fp32-class accuracy (csrc/conv_planes.hip);
+       'bf16x3_inline'     the same products with the split done while staging fp32 operands (csrc/conv_igemm.hip);
+       'fp32'    v_mfma_f32_32x32x2_f32 everywhere (csrc/conv_igemm.hip);
+       'f16'     fp16 activations and weights in, fp32 accumulate (BASELINE configs[4]); NOT fp32-equivalent."""
+    m = os.environ.get('UNFLOW_CONV_MATH', 'bf16x3')
+    if m not in ('bf16x3', 'bf16x3_inline', 'fp32', 'f16'):
+        raise ValueError("UNFLOW_CONV_MATH must be bf16x3, bf16x3_inline, fp32 or f16")
+    return m
+
+
+class Layer:
+    """One conv / conv_transpose variable pair.  in_map: [(physical lo, tf lo, n)] — where the reference's input channels
+    live in the (padded, segment-aligned) physical input of the layer; cout_p >= cout is the physical output width
+    (pad columns keep zero weights / bias and receive exactly zero gradient)."""
+    __slots__ = ('name', 'kind', 'k', 'cin', 'cout', 'stride', 'act', 'cin_p', 'cout_p', 'in_map', 'w', 'b', 'dw', 'db',
+                 'wpl_d', 'wpl_t')
+
+    def __init__(self, name, kind, k, cin, cout, stride, act, in_map=None, cin_p=None):
         self.name, self.kind, self.k, self.cin, self.cout, self.stride, self.act = name, kind, k, cin, cout, stride, act
-        self.cin_p = cin if (kind == 'deconv' and cin == 2) else pad4(cin)
+        self.in_map = in_map or [(0, 0, cin)]
+        if cin_p is None:
+            cin_p = cin if (kind == 'deconv' and cin == 2) else pad4(max(lo + n for lo, _, n in self.in_map))
+        self.cin_p = cin_p
+        self.cout_p = cout if cout <= 2 else pad4(cout)
+        self.wpl_d = self.wpl_t = None
 
     def wshape(self):
         if self.kind == 'conv':
-            return (self.k, self.k, self.cin_p, self.cout)   # HWIO
-        return (self.k, self.k, self.cout, self.cin_p)       # conv2d_transpose: [k,k,out,in]
+            return (self.k, self.k, self.cin_p, self.cout_p)   # HWIO
+        return (self.k, self.k, self.cout_p, self.cin_p)       # conv2d_transpose: [k,k,out,in]
+
+    def tf_wshape(self):
+        return (self.k, self.k, self.cin, self.cout) if self.kind == 'conv' else (self.k, self.k, self.cout, self.cin)
+
+    def uses_planes(self):
+        return self.cout > 4 and self.cin_p >= 4
 
 
-def _decoder_layers(c, skip2=128):
-    """_flownet_upconv variables (flownet.py:89-131) under scope prefix c."""
-    return [
-        Layer(c + 'flow6', 'conv', 3, 1024, 2, 1, False),
-        Layer(c + 'deconv5', 'deconv', 4, 1024, 512, 2, True), Layer(c + 'flow6_up5', 'deconv', 4, 2, 2, 2, False),
-        Layer(c + 'flow5', 'conv', 3, 1026, 2, 1, False),
-        Layer(c + 'deconv4', 'deconv', 4, 1026, 256, 2, True), Layer(c + 'flow5_up4', 'deconv', 4, 2, 2, 2, False),
-        Layer(c + 'flow4', 'conv', 3, 770, 2, 1, False),
-        Layer(c + 'deconv3', 'deconv', 4, 770, 128, 2, True), Layer(c + 'flow4_up3', 'deconv', 4, 2, 2, 2, False),
-        Layer(c + 'flow3', 'conv', 3, 386, 2, 1, False),
-        Layer(c + 'deconv2', 'deconv', 4, 386, 64, 2, True), Layer(c + 'flow3_up2', 'deconv', 4, 2, 2, 2, False),
-        Layer(c + 'flow2', 'conv', 3, skip2 + 64 + 2, 2, 1, False),
-    ]
+def concat_layout(parts):
+    """Physical channel layout of a tf.concat: every part starts at a multiple of 4 (16-byte aligned fp32 slices, 8-byte
+    aligned plane slices).  parts: [(name, channels)] -> ({name: (lo, n)}, physical width)."""
+    off, d = 0, {}
+    for nm, n in parts:
+        off = pad4(off)
+        d[nm] = (off, n)
+        off += n
+    return d, pad4(off)
 
 
-def _contracting_layers(c):
-    return [
-        Layer(c + 'conv4', 'conv', 3, 256, 512, 2, True), Layer(c + 'conv4_1', 'conv', 3, 512, 512, 1, True),
-        Layer(c + 'conv5', 'conv', 3, 512, 512, 2, True), Layer(c + 'conv5_1', 'conv', 3, 512, 512, 1, True),
-        Layer(c + 'conv6', 'conv', 3, 512, 1024, 2, True), Layer(c + 'conv6_1', 'conv', 3, 1024, 1024, 1, True),
-    ]
+class _Op:
+    """One forward launch of a stage: a layer (src slice -> dst slice) or the correlation."""
+    __slots__ = ('kind', 'l', 'src', 'dst')
 
-
-def flownet_c_layers(scope=''):
-    """Variables of flownet_c_features + flownet_c in the reference's creation order (flownet.py:195-237,89-131)."""
-    f, c = scope + 'flownet_c_features/', scope + 'flownet_c/'
-    return [
-        Layer(f + 'conv1', 'conv', 7, 3, 64, 2, True), Layer(f + 'conv2', 'conv', 5, 64, 128, 2, True),
-        Layer(f + 'conv3', 'conv', 5, 128, 256, 2, True),
-        Layer(c + 'conv_redir', 'conv', 1, 256, 32, 1, True), Layer(c + 'conv3_1', 'conv', 3, 473, 256, 1, True),
-    ] + _contracting_layers(c) + _decoder_layers(c)
-
-
-def flownet_s_layers(scope='', in_channels=6):
-    """Variables of flownet_s (flownet.py:166-192): 6 input channels, or 14 for a refinement stage (:56-57)."""
-    c = scope + 'flownet_s/'
-    return [
-        Layer(c + 'conv1', 'conv', 7, in_channels, 64, 2, True), Layer(c + 'conv2', 'conv', 5, 64, 128, 2, True),
-        Layer(c + 'conv3', 'conv', 5, 128, 256, 2, True), Layer(c + 'conv3_1', 'conv', 3, 256, 256, 1, True),
-    ] + _contracting_layers(c) + _decoder_layers(c)
+    def __init__(self, kind, l, src, dst):
+        self.kind, self.l, self.src, self.dst = kind, l, src, dst
 
 
 class _Stage:
-    """One network of the (possibly stacked) spec: its layers, activations, gradients and launch lists."""
+    """One network of the (possibly stacked) spec: layer table, buffers, forward launch list and the backward list derived
+    from it.  kind: 'C' / 'S' (full width) or 'c' / 's' (3/8 width, flownet.py:22-23); full_res adds deconv1/0 and
+    flow1/0 (flownet.py:133-153; FlowNetS only: flownet_c never passes conv1 / inputs, flownet.py:231-233)."""
 
-    def __init__(self, eng, kind, index):
-        self.eng, self.kind, self.index = eng, kind, index
-        scope = '' if index == 0 else 'stack_%d_flownet/' % index   # flownet.py:72-77
-        self.in_ch = 3 if kind == 'C' else (6 if index == 0 else 14)
-        self.layers = flownet_c_layers(scope) if kind == 'C' else flownet_s_layers(scope, self.in_ch)
-        self.by_name = {l.name.split('/')[-1]: l for l in self.layers}
+    def __init__(self, eng, kind, index, full_res=False):
+        self.eng, self.kind, self.index, self.full_res = eng, kind, index, full_res
+        self.is_c = kind in 'Cc'
+        m = 1.0 if kind in 'CS' else 3.0 / 8.0
+        c = lambda x: int(x * m)                                            # noqa: E731
+        self.c = c
+        scope = '' if index == 0 else 'stack_%d_flownet/' % index           # flownet.py:72-77
+        self.in_ch = 3 if self.is_c else (6 if index == 0 else 14)
         self.trainable = True
+        if full_res and self.is_c:
+            raise ValueError("full_res needs a FlowNetS as the last network: flownet_c passes neither conv1 nor the inputs "
+                             "to the refinement decoder (flownet.py:231-233)")
+        # ---- buffers: name -> (spatial divisor, {segment: (lo, n)}, physical width)
+        B = self.bufs = OrderedDict()
 
+        def buf(name, div, parts):
+            lay, width = concat_layout(parts)
+            B[name] = (div, lay, 2 if name.startswith('flow') else width)   # flow outputs: exactly [.., 2]
+        if full_res:
+            buf('cat0', 1, [('in', self.in_ch), ('deconv0', c(16)), ('up', 2)])
+            buf('cat1', 2, [('conv1', c(64)), ('deconv1', c(32)), ('up', 2)])
+        else:
+            if not self.is_c:
+                buf('x0s', 1, [('in', self.in_ch)])
+            buf('c1', 2, [('conv1', c(64))])
+        buf('cat2', 4, [('conv2', c(128)), ('deconv2', c(64)), ('up', 2)])
+        buf('c3', 8, [('conv3', c(256))])
+        if self.is_c:
+            buf('catc', 8, [('conv_redir', c(32)), ('corr', 441)])
+        buf('cat3', 8, [('conv3_1', c(256)), ('deconv3', c(128)), ('up', 2)])
+        buf('c4', 16, [('conv4', c(512))])
+        buf('cat4', 16, [('conv4_1', c(512)), ('deconv4', c(256)), ('up', 2)])
+        buf('c5', 32, [('conv5', c(512))])
+        buf('cat5', 32, [('conv5_1', c(512)), ('deconv5', c(512)), ('up', 2)])
+        buf('c6', 64, [('conv6', c(1024))])
+        buf('c6_1', 64, [('conv6_1', c(1024))])
+        self.flow_levels = ([0, 1] if full_res else []) + [2, 3, 4, 5, 6]
+        for lvl in self.flow_levels:
+            buf('flow%d' % lvl, 2 ** lvl, [('flow', 2)])
+        self.b1 = 'cat1' if full_res else 'c1'
+        self.bin = None if self.is_c else ('cat0' if full_res else 'x0s')   # stage input buffer (FlowNetC reads eng.x0)
+        # ---- layers + forward ops (the reference's variable creation order)
+        self.layers, self.ops = [], []
+        f = scope + ('flownet_c_features/' if self.is_c else 'flownet_s/')
+        d = scope + ('flownet_c/' if self.is_c else 'flownet_s/')
+
+        def seg(bname, sname):
+            lo, n = B[bname][1][sname]
+            return (bname, lo, lo + n)
+
+        def whole(bname):
+            return (bname, 0, B[bname][2])
+
+        def layer(pre, name, kind, k, src, dst, cout, stride=1, act=True):
+            sb, slo, shi = src
+            if sb == 'x0':
+                in_map, cin, cin_p = [(0, 0, 3)], 3, 4
+            else:
+                lay = B[sb][1]
+                segs = sorted((lo, n) for lo, n in lay.values() if lo >= slo and lo + n <= shi)
+                in_map, t = [], 0
+                for lo, n in segs:
+                    in_map.append((lo - slo, t, n))
+                    t += n
+                cin, cin_p = t, pad4(shi - slo)
+                if kind == 'deconv' and cin == 2:
+                    cin_p = 2
+            l = Layer(pre + name, kind, k, cin, cout, stride, act, in_map, cin_p)
+            self.layers.append(l)
+            self.ops.append(_Op('layer', l, src, dst))
+            return l
+
+        x_in = ('x0', 0, 4) if self.is_c else (self.bin, 0, pad4(self.in_ch))
+        layer(f, 'conv1', 'conv', 7, x_in, seg(self.b1, 'conv1'), c(64), 2)
+        layer(f, 'conv2', 'conv', 5, seg(self.b1, 'conv1'), seg('cat2', 'conv2'), c(128), 2)
+        layer(f, 'conv3', 'conv', 5, seg('cat2', 'conv2'), seg('c3', 'conv3'), c(256), 2)
+        if self.is_c:
+            # (conv_redir before the correlation: the backward list is the reverse, and the correlation's gradient kernel
+            # writes d c3 while conv_redir's data gradient accumulates into it and applies conv3's leaky derivative)
+            layer(d, 'conv_redir', 'conv', 1, seg('c3', 'conv3'), seg('catc', 'conv_redir'), c(32), 1)
+            self.ops.append(_Op('corr', None, seg('c3', 'conv3'), seg('catc', 'corr')))
+            layer(d, 'conv3_1', 'conv', 3, whole('catc'), seg('cat3', 'conv3_1'), c(256), 1)
+        else:
+            layer(d, 'conv3_1', 'conv', 3, seg('c3', 'conv3'), seg('cat3', 'conv3_1'), c(256), 1)
+        layer(d, 'conv4', 'conv', 3, seg('cat3', 'conv3_1'), seg('c4', 'conv4'), c(512), 2)
+        layer(d, 'conv4_1', 'conv', 3, seg('c4', 'conv4'), seg('cat4', 'conv4_1'), c(512), 1)
+        layer(d, 'conv5', 'conv', 3, seg('cat4', 'conv4_1'), seg('c5', 'conv5'), c(512), 2)
+        layer(d, 'conv5_1', 'conv', 3, seg('c5', 'conv5'), seg('cat5', 'conv5_1'), c(512), 1)
+        layer(d, 'conv6', 'conv', 3, seg('cat5', 'conv5_1'), seg('c6', 'conv6'), c(1024), 2)
+        layer(d, 'conv6_1', 'conv', 3, seg('c6', 'conv6'), seg('c6_1', 'conv6_1'), c(1024), 1)
+        # refinement decoder (_flownet_upconv, flownet.py:89-153)
+        prev = 'c6_1'
+        for lvl, cat, dch in ((6, 'cat5', c(512)), (5, 'cat4', c(256)), (4, 'cat3', c(128)), (3, 'cat2', c(64))):
+            up = lvl - 1
+            layer(d, 'flow%d' % lvl, 'conv', 3, whole(prev), seg('flow%d' % lvl, 'flow'), 2, 1, False)
+            layer(d, 'deconv%d' % up, 'deconv', 4, whole(prev), seg(cat, 'deconv%d' % up), dch, 2, True)
+            layer(d, 'flow%d_up%d' % (lvl, up), 'deconv', 4, seg('flow%d' % lvl, 'flow'), seg(cat, 'up'), 2, 2, False)
+            prev = cat
+        layer(d, 'flow2', 'conv', 3, whole('cat2'), seg('flow2', 'flow'), 2, 1, False)
+        if full_res:
+            fr = d + 'full_res/'
+            layer(fr, 'deconv1', 'deconv', 4, whole('cat2'), seg('cat1', 'deconv1'), c(32), 2, True)
+            layer(fr, 'flow2_up1', 'deconv', 4, seg('flow2', 'flow'), seg('cat1', 'up'), 2, 2, False)
+            layer(fr, 'flow1', 'conv', 3, whole('cat1'), seg('flow1', 'flow'), 2, 1, False)
+            layer(fr, 'deconv0', 'deconv', 4, whole('cat1'), seg('cat0', 'deconv0'), c(16), 2, True)
+            layer(fr, 'flow1_up0', 'deconv', 4, seg('flow1', 'flow'), seg('cat0', 'up'), 2, 2, False)
+            layer(fr, 'flow0', 'conv', 3, whole('cat0'), seg('flow0', 'flow'), 2, 1, False)
+        self.by_name = {l.name.split('/')[-1]: l for l in self.layers}
+        self._plan_backward()
+
+    # -------------------------------------------------------------- backward plan
+    def _plan_backward(self):
+        """Reverse of the forward list.  For every (consumer, input buffer) decide: accumulate or overwrite (the first data
+        gradient written into a buffer covers all of it), and the channel range whose leaky-ReLU derivative this call
+        applies — the segments of activated producers for which this consumer is the LAST one to add its share
+        (flownet.py:84-86: the epilogue multiplies the finished sum)."""
+        producers = {}                                      # (buf, lo, hi) -> producing layer
+        for op in self.ops:
+            if op.kind == 'layer':
+                producers[op.dst] = op.l
+        rev = list(reversed(self.ops))
+        # consumers of every buffer in backward processing order
+        order = {}
+        for i, op in enumerate(rev):
+            if op.src[0] != 'x0':
+                order.setdefault(op.src[0], []).append((i, op))
+        self.bwd = []
+        for i, op in enumerate(rev):
+            sb, slo, shi = op.src
+            act_lo = act_hi = 0
+            first = False
+            if sb != 'x0':
+                cons = order[sb]
+                first = cons[0][0] == i
+                if first:
+                    assert slo == 0 and shi == self.bufs[sb][2], "first data gradient into %s must cover it" % sb
+                rng = []
+                for (pb, plo, phi), pl in producers.items():
+                    if pb != sb or not pl.act or plo < slo or phi > shi:
+                        continue
+                    last = max(j for j, o in cons if o.src[1] <= plo and o.src[2] >= phi)
+                    if last == i:
+                        rng.append((plo - slo, phi - slo))
+                if rng:
+                    rng.sort()
+                    for (a0, a1), (b0, b1) in zip(rng, rng[1:]):
+                        assert a1 == b0, "activation ranges of one data gradient must be contiguous"
+                    act_lo, act_hi = rng[0][0], rng[-1][1]
+            self.bwd.append((op, first, act_lo, act_hi))
+        names = [op.l.name.split('/')[-1] if op.kind == 'layer' else 'corr' for op, _, _, _ in self.bwd]
+        self.split_at = names.index('conv4') + 1            # part 0 = [0, split_at): decoder + conv6_1 .. conv4
+
+    # -------------------------------------------------------------- buffers
     def alloc(self):
         e = self.eng
         N, H, W, dev = e.N, e.H, e.W, e.dev
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        a = self.act = {}
-        if self.kind == 'S':
-            a['x0s'] = z(N, H, W, pad4(self.in_ch))
-        a['c1'] = z(N, H // 2, W // 2, 64)
-        a['cat2'] = z(N, H // 4, W // 4, 196)
-        a['c3'] = z(N, H // 8, W // 8, 256)
-        if self.kind == 'C':
-            a['catc'] = z(N, H // 8, W // 8, 476)
-        a['cat3'] = z(N, H // 8, W // 8, 388)
-        a['c4'] = z(N, H // 16, W // 16, 512)
-        a['cat4'] = z(N, H // 16, W // 16, 772)
-        a['c5'] = z(N, H // 32, W // 32, 512)
-        a['cat5'] = z(N, H // 32, W // 32, 1028)
-        a['c6'] = z(N, H // 64, W // 64, 1024)
-        a['c6_1'] = z(N, H // 64, W // 64, 1024)
-        for lvl, d in zip((2, 3, 4, 5, 6), (4, 8, 16, 32, 64)):
-            a['flow%d' % lvl] = z(N, H // d, W // d, 2)
-        self.grad = {k: torch.zeros_like(v) for k, v in a.items() if k != 'x0s'} if self.trainable else {}
-        if self.kind == 'S' and self.index > 0 and e.train_all:
-            self.grad['x0s'] = torch.zeros_like(a['x0s'])      # d loss / d stage input -> the previous network
+        npl = e.n_planes
+        self.A, self.Gd = {}, {}
+        for name, (div, lay, width) in self.bufs.items():
+            is_flow = name.startswith('flow')
+            self.A[name] = L.PT.alloc((N, H // div, W // div, width), dev, 0 if is_flow else npl)
+        # d loss / d stage input -> the previous network (train_all only; otherwise behind stop_gradient, flownet.py:51-54)
+        self.need_in_grad = (not self.is_c) and self.index > 0 and e.train_all
+        if self.need_in_grad and self.full_res:
+            raise NotImplementedError("train_all through a full_res refinement stage")
+        if self.trainable:
+            for name, (div, lay, width) in self.bufs.items():
+                if name == 'x0s' and not self.need_in_grad:
+                    continue
+                is_flow = name.startswith('flow')
+                self.Gd[name] = L.PT.alloc((N, H // div, W // div, width), dev, 0 if is_flow else npl)
+        self.act = {k: v.t for k, v in self.A.items()}
+        self.grad = {k: v.t for k, v in self.Gd.items()}
+        if self.full_res:      # the stage input is the first segment of concat0
+            self.act['x0s'] = self.act['cat0'][..., :pad4(self.in_ch)]
 
-    def _sl(self, name, lo, hi):
-        return self.act[name][..., lo:hi]
-
-    def _gsl(self, name, lo, hi):
-        return self.grad[name][..., lo:hi]
-
-    def _conv(self, lname, x, y):
-        l = self.by_name[lname]
-        if l.kind == 'conv':
-            L.conv2d_fwd(x, l.w, l.b, y, l.stride, l.act)
-        else:
-            L.conv2d_transpose_fwd(x, l.w, l.b, y, l.act)
+    def pt(self, spec, grad=False):
+        """PT view of (buffer, lo, hi); 'x0' is the engine's network input."""
+        b, lo, hi = spec
+        if b == 'x0':
+            return self.eng.X0
+        src = (self.Gd if grad else self.A)[b]
+        return src if (lo == 0 and hi == src.t.shape[-1]) else src.sl(lo, hi)
 
     # -------------------------------------------------------------- forward
     def forward(self, prev_flow2=None):
-        e, a, s = self.eng, self.act, self._sl
+        e = self.eng
         B, N = e.B, e.N
-        if self.kind == 'C':
-            self._conv('conv1', e.x0, a['c1'])
-            self._conv('conv2', a['c1'], s('cat2', 0, 128))
-            self._conv('conv3', s('cat2', 0, 128), a['c3'])
-            h8, w8 = e.H // 8, e.W // 8
-            corr_out = s('catc', 32, 473)
-            check(_lib.lib().unflow_correlation_nhwc_fwd(ptr(a['c3']), ptr(a['c3']), 256, B, ptr(corr_out), 476, N, 256,
-                                                         h8, w8, 1, 20, 20, 1, 2, stream()), "correlation")
-            self._conv('conv_redir', a['c3'], s('catc', 0, 32))
-            self._conv('conv3_1', a['catc'], s('cat3', 0, 256))
-        else:
-            x0s = a['x0s']
+        if not self.is_c:
+            x0s = self.act['x0s']
             pf = prev_flow2
-            check(_lib.lib().unflow_stack_input(ptr(e.x0), ptr(pf), ptr(x0s), x0s.shape[3], B, N, e.H, e.W,
+            check(_lib.lib().unflow_stack_input(ptr(e.x0), ptr(pf), ptr(x0s), x0s.stride(2), B, N, e.H, e.W,
                                                 0 if pf is None else pf.shape[1], 0 if pf is None else pf.shape[2],
-                                                cf(4 * FLOW_SCALE), stream()), "stack_input")
-            self._conv('conv1', x0s, a['c1'])
-            self._conv('conv2', a['c1'], s('cat2', 0, 128))
-            self._conv('conv3', s('cat2', 0, 128), a['c3'])
-            self._conv('conv3_1', a['c3'], s('cat3', 0, 256))
-        self._conv('conv4', s('cat3', 0, 256), a['c4'])
-        self._conv('conv4_1', a['c4'], s('cat4', 0, 512))
-        self._conv('conv5', s('cat4', 0, 512), a['c5'])
-        self._conv('conv5_1', a['c5'], s('cat5', 0, 512))
-        self._conv('conv6', s('cat5', 0, 512), a['c6'])
-        self._conv('conv6_1', a['c6'], a['c6_1'])
-        # refinement decoder (_flownet_upconv, flownet.py:89-131)
-        self._conv('flow6', a['c6_1'], a['flow6'])
-        self._conv('deconv5', a['c6_1'], s('cat5', 512, 1024))
-        self._conv('flow6_up5', a['flow6'], s('cat5', 1024, 1026))
-        self._conv('flow5', a['cat5'], a['flow5'])
-        self._conv('deconv4', a['cat5'], s('cat4', 512, 768))
-        self._conv('flow5_up4', a['flow5'], s('cat4', 768, 770))
-        self._conv('flow4', a['cat4'], a['flow4'])
-        self._conv('deconv3', a['cat4'], s('cat3', 256, 384))
-        self._conv('flow4_up3', a['flow4'], s('cat3', 384, 386))
-        self._conv('flow3', a['cat3'], a['flow3'])
-        self._conv('deconv2', a['cat3'], s('cat2', 128, 192))
-        self._conv('flow3_up2', a['flow3'], s('cat2', 192, 194))
-        self._conv('flow2', a['cat2'], a['flow2'])
+                                                cf(4 * FLOW_SCALE), e.stream()), "stack_input")
+            inp = self.A[self.bin]
+            if inp.pl is not None:
+                w_in = pad4(self.in_ch)
+                L.planes_from_f32(x0s, inp.pl[..., :round8(w_in)], C=w_in)
+        for op in self.ops:
+            if op.kind == 'corr':
+                c3, out = self.pt(op.src), self.pt(op.dst)
+                C = op.src[2] - op.src[1]
+                h8, w8 = e.H // 8, e.W // 8
+                check(_lib.lib().unflow_correlation_nhwc_fwd(ptr(c3.t), ptr(c3.t), c3.t.stride(2), B, ptr(out.t),
+                                                             out.t.stride(2), N, C, h8, w8, 1, 20, 20, 1, 2, e.stream()),
+                      "correlation")
+                if out.pl is not None:       # operand planes of the cost volume for conv3_1 (pad channels zeroed)
+                    L.planes_from_f32(out.t, out.pl)
+                continue
+            l = op.l
+            x, y = self.pt(op.src), self.pt(op.dst)
+            if l.cout_p != l.cout:
+                y = L.PT(y.t.as_strided(y.t.shape[:3] + (l.cout_p,), y.t.stride(), y.t.storage_offset()),
+                         None if y.pl is None else y.pl)
+            if l.kind == 'conv':
+                L.conv_fwd(x, l.w, l.wpl_t, l.b, y, l.stride, l.act)
+            else:
+                L.deconv_fwd(x, l.w, l.wpl_d, l.b, y, l.act)
 
     # -------------------------------------------------------------- backward
-    def _bwd(self, lname, x, dz, dx=None, accumulate=False, act_src=None, act_lo=0, act_hi=0):
-        """Filter gradient of layer `lname` from dz (d pre-activation), then (optionally) the data gradient."""
-        l = self.by_name[lname]
-        e = self.eng
-        if e._bias_plan is None:
-            e._bias_jobs.append((dz, l))         # bias gradients: one batched column-sum launch at the end
-        # The filter gradient only needs dz (final at this point) and the stored activation: it runs on the side
-        # stream, concurrently with the data-gradient chain on the main stream (its tail waves and the latency-bound
-        # flow-head kernels fill the CUs the other kernel leaves idle).  Own split-K scratch (slot 3).
-        # ('small': only the latency-bound layers, the Cout = 2 flow heads and the 2->2 deconvs)
-        side = e.side if (e.side_all or l.cout <= 4) else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), L.ws_slot(3):
-                self._wgrad(l, x, dz)
-        else:
-            self._wgrad(l, x, dz)
-        if dx is not None:
-            if l.kind == 'conv':
-                L.conv2d_bwd_data(dz, l.w, dx, l.stride, accumulate, act_src, act_lo, act_hi)
-            else:
-                L.conv2d_transpose_bwd_data(dz, l.w, dx, accumulate, act_src, act_lo, act_hi)
-
-    @staticmethod
-    def _wgrad(l, x, dz):
-        if l.kind == 'conv':
-            L.conv2d_bwd_filter(x, dz, l.dw, None, l.stride)
-        else:
-            L.conv2d_transpose_bwd_filter(x, dz, l.dw, None)
-
     def backward(self, part=None):
         """part None: everything; 0: decoder + conv6_1..conv4 (94 % of the parameters — their gradients are final
         afterwards, so their all-reduce can start); 1: conv3_1 .. conv1."""
-        if part in (None, 0):
-            self._backward_deep()
-        if part in (None, 1):
-            self._backward_shallow()
-        if self.eng.side is not None:     # join: every filter gradient of this part is final after this point
-            torch.cuda.current_stream().wait_stream(self.eng.side)
-
-    def _backward_deep(self):
-        e, a, g, s, gs = self.eng, self.act, self.grad, self._sl, self._gsl
-        # level 2 (flow2 head reads concat2 = [conv2 | deconv2 | flow3_up2])
-        self._bwd('flow2', a['cat2'], g['flow2'], g['cat2'], False, a['cat2'], 128, 192)
-        self._bwd('flow3_up2', a['flow3'], gs('cat2', 192, 194), g['flow3'], True)
-        self._bwd('flow3', a['cat3'], g['flow3'], g['cat3'], False)
-        self._bwd('deconv2', a['cat3'], gs('cat2', 128, 192), g['cat3'], True, a['cat3'], 256, 384)
-        self._bwd('flow4_up3', a['flow4'], gs('cat3', 384, 386), g['flow4'], True)
-        self._bwd('flow4', a['cat4'], g['flow4'], g['cat4'], False)
-        self._bwd('deconv3', a['cat4'], gs('cat3', 256, 384), g['cat4'], True, a['cat4'], 512, 768)
-        self._bwd('flow5_up4', a['flow5'], gs('cat4', 768, 770), g['flow5'], True)
-        self._bwd('flow5', a['cat5'], g['flow5'], g['cat5'], False)
-        self._bwd('deconv4', a['cat5'], gs('cat4', 512, 768), g['cat5'], True, a['cat5'], 512, 1024)
-        self._bwd('flow6_up5', a['flow6'], gs('cat5', 1024, 1026), g['flow6'], True)
-        self._bwd('flow6', a['c6_1'], g['flow6'], g['c6_1'], False)
-        self._bwd('deconv5', a['c6_1'], gs('cat5', 512, 1024), g['c6_1'], True, a['c6_1'], 0, 1024)
-        # contracting part
-        self._bwd('conv6_1', a['c6'], g['c6_1'], g['c6'], False, a['c6'], 0, 1024)
-        self._bwd('conv6', s('cat5', 0, 512), g['c6'], gs('cat5', 0, 512), True, s('cat5', 0, 512), 0, 512)
-        self._bwd('conv5_1', a['c5'], gs('cat5', 0, 512), g['c5'], False, a['c5'], 0, 512)
-        self._bwd('conv5', s('cat4', 0, 512), g['c5'], gs('cat4', 0, 512), True, s('cat4', 0, 512), 0, 512)
-        self._bwd('conv4_1', a['c4'], gs('cat4', 0, 512), g['c4'], False, a['c4'], 0, 512)
-        self._bwd('conv4', s('cat3', 0, 256), g['c4'], gs('cat3', 0, 256), True, s('cat3', 0, 256), 0, 256)
-
-    def _backward_shallow(self):
-        e, a, g, s, gs = self.eng, self.act, self.grad, self._sl, self._gsl
+        e = self.eng
+        lo, hi = {None: (0, len(self.bwd)), 0: (0, self.split_at), 1: (self.split_at, len(self.bwd))}[part]
         B, N = e.B, e.N
-        if self.kind == 'C':
-            self._bwd('conv3_1', a['catc'], gs('cat3', 0, 256), g['catc'], False, a['catc'], 0, 32)
-            # correlation: gradient wrt the shared feature tensor (both roles of every sample), then conv_redir adds
-            h8, w8 = e.H // 8, e.W // 8
-            check(_lib.lib().unflow_correlation_nhwc_bwd(ptr(gs('catc', 32, 473)), 476, ptr(a['c3']), ptr(a['c3']), 256,
-                                                         B, ptr(g['c3']), ptr(None), 256, 1, N, 256, h8, w8, 1, 20, 20,
-                                                         1, 2, stream()), "correlation_grad")
-            self._bwd('conv_redir', a['c3'], gs('catc', 0, 32), g['c3'], True, a['c3'], 0, 256)
-            x_in = e.x0
-        else:
-            self._bwd('conv3_1', a['c3'], gs('cat3', 0, 256), g['c3'], False, a['c3'], 0, 256)
-            x_in = a['x0s']
-        self._bwd('conv3', s('cat2', 0, 128), g['c3'], gs('cat2', 0, 128), True, s('cat2', 0, 128), 0, 128)
-        self._bwd('conv2', a['c1'], gs('cat2', 0, 128), g['c1'], False, a['c1'], 0, 64)
-        # inputs are data (or behind stop_gradient, flownet.py:51-54) unless train_all reaches a refinement stage
-        self._bwd('conv1', x_in, g['c1'], g.get('x0s'))
+        for op, first, act_lo, act_hi in self.bwd[lo:hi]:
+            if op.kind == 'corr':
+                c3, g3, gout = self.pt(op.src), self.pt(op.src, True), self.pt(op.dst, True)
+                C = op.src[2] - op.src[1]
+                h8, w8 = e.H // 8, e.W // 8
+                assert first
+                check(_lib.lib().unflow_correlation_nhwc_bwd(ptr(gout.t), gout.t.stride(2), ptr(c3.t), ptr(c3.t),
+                                                             c3.t.stride(2), B, ptr(g3.t), ptr(None), g3.t.stride(2), 1, N,
+                                                             C, h8, w8, 1, 20, 20, 1, 2, e.stream()), "correlation_grad")
+                continue
+            l = op.l
+            x, dz = self.pt(op.src), self.pt(op.dst, True)
+            if l.cout_p != l.cout:
+                dz = L.PT(dz.t.as_strided(dz.t.shape[:3] + (l.cout_p,), dz.t.stride(), dz.t.storage_offset()), dz.pl)
+            if e._bias_plan is None:
+                e._bias_jobs.append((dz.t, l))       # bias gradients: one batched column-sum launch at the end
+            if l.kind == 'conv':
+                L.conv_bwd_filter(x, dz, l.dw, l.stride)
+            else:
+                L.deconv_bwd_filter(x, dz, l.dw)
+            sb = op.src[0]
+            if sb == 'x0' or sb not in self.Gd or (sb == self.bin and not self.need_in_grad):
+                continue                              # inputs are data (or behind stop_gradient, flownet.py:51-54)
+            dx = self.pt(op.src, True)
+            # the loss wrote d flowN first (flow buffers): everything after it accumulates
+            accumulate = (not first) or sb.startswith('flow')
+            act_src = self.pt(op.src) if act_hi > act_lo else None
+            if l.kind == 'conv':
+                L.conv_bwd_data(dz, l.w, l.wpl_d, dx, l.stride, accumulate, act_src, act_lo, act_hi)
+            else:
+                L.deconv_bwd_data(dz, l.w, l.wpl_t, dx, accumulate, act_src, act_lo, act_hi)
 
 
 class FlowNetEngine:
     """Bidirectional forward / loss / backward / Adam of a FlowNet spec on one GPU, fixed (B, H, W).
-    params['flownet']: 'C', 'S' or a stack 'CS', 'CSS', 'SS' ... (flownet.py:14-81).  In a stack only the last network
-    is trained unless params['train_all'] (flownet.py:51-54, train.py:29-37); frozen stages run forward only and —
-    exactly as in the reference, whose regulariser and optimizer span all variables — still receive the L2 gradient in
-    the Adam update.  With train_all the gradient also flows back through every inter-stage input (upsampled flow, warp,
-    |warp - first|) into the earlier networks."""
+    params['flownet']: a string over 'C', 'S' (full width) and 'c', 's' (3/8 width), a correlation net only first
+    (flownet.py:14-81), e.g. 'C', 'S', 'CS', 'CSS', 'css'.  In a stack only the last network is trained unless
+    params['train_all'] (flownet.py:51-54, train.py:29-37); frozen stages run forward only and — exactly as in the
+    reference, whose regulariser and optimizer span all variables — still receive the L2 gradient in the Adam update.
+    With train_all the gradient also flows back through every inter-stage input (upsampled flow, warp, |warp - first|)
+    into the earlier networks.  params['full_res'] adds the full-resolution decoder levels to the LAST network
+    (flownet.py:21,133-153; a FlowNetS) and the loss pyramid then has 7 levels (unsupervised.py:89-96)."""
 
     def __init__(self, batch, height, width, params=None, device=None, seed=0):
         assert height % 64 == 0 and width % 64 == 0, "FlowNet needs H, W divisible by 64"
@@ -295,41 +392,41 @@ class FlowNetEngine:
         if self.params.get('mask_occlusion', '') not in ('', 'fb', 'disocc'):   # unsupervised.py:125-126
             raise ValueError("mask_occlusion must be one of 'fb', 'disocc', ''")
         spec = self.params.get('flownet', 'C')
-        if not spec or any(ch not in 'CS' for ch in spec) or 'C' in spec[1:]:
-            raise ValueError("flownet spec must be 'C' or 'S' followed by 'S' refinement nets (full-size nets only)")
+        if not spec or any(ch not in 'CScs' for ch in spec) or any(ch in 'Cc' for ch in spec[1:]):
+            raise ValueError("flownet spec: 'C'/'c' or 'S'/'s' first, then 'S'/'s' refinement nets (flownet.py:20-28)")
         self.train_all = bool(self.params.get('train_all')) and len(spec) > 1     # train.py:29-37, flownet.py:51-54
-        if self.params.get('full_res'):
-            raise NotImplementedError("full_res decoder is not implemented")
+        self.full_res = bool(self.params.get('full_res'))
         self.spec = spec
         self.B, self.H, self.W = batch, height, width
         self.N = 2 * batch
-        self.dev = torch.device('cuda:0') if device is None else device
-        self.stages = [_Stage(self, k, i) for i, k in enumerate(spec)]
-        for st in self.stages[:-1]:
-            st.trainable = self.train_all
-        self.layers = [l for st in self.stages for l in st.layers]
-        self.by_name = self.stages[-1].by_name
-        self._alloc_params()
-        self._alloc_activations()
-        self._build_masks()
+        self.dev = torch.device('cuda:0') if device is None else torch.device(device)
+        self.math = conv_math_mode()
+        self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
+        with torch.cuda.device(self.dev):
+            self.stages = [_Stage(self, k, i, self.full_res and i == len(spec) - 1) for i, k in enumerate(spec)]
+            for st in self.stages[:-1]:
+                st.trainable = self.train_all
+            self.layers = [l for st in self.stages for l in st.layers]
+            self.by_name = self.stages[-1].by_name
+            self._alloc_params()
+            self._alloc_activations()
+            self._build_masks()
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
         self.defer_l2 = False      # True: forward_loss leaves the L2 term to adam_step (train_step / bench)
         self.fused_pyramid = os.environ.get('UNFLOW_FUSED_PYRAMID', '1') != '0'   # default loss terms: 4 launches for all levels
         self._pyr_cache = None
-        # optional second HIP stream for filter gradients (see _Stage._bwd), off by default: both variants measured
-        # slower inside the captured graph on MI355X — 'all' 397 vs 405 pairs/s, 'small' (only the latency-bound flow
-        # heads / 2->2 deconvs) 438.6 vs 445.2
-        mode = os.environ.get('UNFLOW_SIDE_STREAM', '0')      # '0' (default) | 'small' | '1' / 'all'
-        self.side = torch.cuda.Stream(self.dev) if mode != '0' else None
-        self.side_all = mode in ('1', 'all')
+        self._wplanes_version = None
         if seed is not None:
             self.init_params(seed)
+
+    def stream(self):
+        return stream(self.dev)
 
     # ------------------------------------------------------------------ parameters
     def _alloc_params(self):
         nw = sum(int(torch.Size(l.wshape()).numel()) for l in self.layers)
-        nb = sum(l.cout for l in self.layers)
+        nb = sum(l.cout_p for l in self.layers)
         self.n_weights, self.n_params = nw, nw + nb
         z = lambda: torch.zeros(self.n_params, dtype=torch.float32, device=self.dev)
         self.P, self.G, self.M, self.V = z(), z(), z(), z()
@@ -340,9 +437,51 @@ class FlowNetEngine:
             l.dw = self.G[off:off + n].view(l.wshape())
             off += n
         for l in self.layers:
-            l.b = self.P[off:off + l.cout]
-            l.db = self.G[off:off + l.cout]
-            off += l.cout
+            l.b = self.P[off:off + l.cout_p]
+            l.db = self.G[off:off + l.cout_p]
+            off += l.cout_p
+        # operand planes of the weights (csrc/conv_planes.hip): direct [P][tap][R][round8(Cc)], transposed
+        # [P][tap][Cc][round8(R)] of W[tap][R][Cc]; one flat int16 buffer, refreshed by one batched launch
+        self._wp_table = None
+        if self.n_planes:
+            P = self.n_planes
+            users = [l for l in self.layers if l.uses_planes()]
+            tot = 0
+            for l in users:
+                taps, R, Cc = l.k * l.k, l.wshape()[2], l.wshape()[3]
+                tot += P * (taps * R * round8(Cc) + taps * Cc * round8(R))
+            self.WP = torch.zeros(tot, dtype=torch.int16, device=self.dev)
+            off = 0
+            for l in users:
+                taps, R, Cc = l.k * l.k, l.wshape()[2], l.wshape()[3]
+                n = P * taps * R * round8(Cc)
+                l.wpl_d = self.WP[off:off + n].view(P, taps, R, round8(Cc))
+                off += n
+                n = P * taps * Cc * round8(R)
+                l.wpl_t = self.WP[off:off + n].view(P, taps, Cc, round8(R))
+                off += n
+            import ctypes
+            n = len(users)
+            self._wp_table = (n,
+                              (ctypes.c_void_p * n)(*[l.w.data_ptr() for l in users]),
+                              (ctypes.c_int * n)(*[l.k * l.k for l in users]),
+                              (ctypes.c_int * n)(*[l.wshape()[2] for l in users]),
+                              (ctypes.c_int * n)(*[l.wshape()[3] for l in users]),
+                              (ctypes.c_void_p * n)(*[l.wpl_d.data_ptr() for l in users]),
+                              (ctypes.c_void_p * n)(*[l.wpl_t.data_ptr() for l in users]))
+
+    def refresh_weight_planes(self, force=False):
+        """Re-split the parameters into their operand planes.  Needed whenever P changed: adam_step marks it; in-place
+        torch writes to P are seen through the tensor version counter; inside a stream capture it always runs (the
+        captured step is replayed after every optimizer update)."""
+        if self._wp_table is None:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not (force or capturing or self._wplanes_version != self.P._version):
+            return
+        n, w, taps, R, Cc, d, t = self._wp_table
+        check(_lib.lib().unflow_weight_planes_batched(n, w, taps, R, Cc, d, t, self.n_planes, self.stream()), "weight_planes")
+        self._wplanes_version = self.P._version
 
     def init_params(self, seed=0):
         """layers.variance_scaling_initializer() (flownet.py:177): truncated normal, stddev sqrt(1.3*2/fan_in);
@@ -350,7 +489,7 @@ class FlowNetEngine:
         from_tf = OrderedDict()
         gen = torch.Generator().manual_seed(seed)
         for l in self.layers:
-            shape = (l.k, l.k, l.cin, l.cout) if l.kind == 'conv' else (l.k, l.k, l.cout, l.cin)
+            shape = l.tf_wshape()
             fan_in = l.k * l.k * (l.cin if l.kind == 'conv' else l.cout)
             std = math.sqrt(1.3 * 2.0 / fan_in)
             t = torch.empty(shape, dtype=torch.float32)
@@ -361,22 +500,29 @@ class FlowNetEngine:
         return from_tf
 
     def load_tf_params(self, tf_params):
-        """tf_params: {'<scope>/<layer>/weights': HWIO (conv) or [k,k,out,in] (deconv), '.../biases'} on any device."""
+        """tf_params: {'<scope>/<layer>/weights': HWIO (conv) or [k,k,out,in] (deconv), '.../biases'} on any device,
+        keyed by the reference's variable names (what a TF checkpoint holds)."""
         self.P.zero_()
         for l in self.layers:
             w = tf_params[l.name + '/weights'].to(self.dev, torch.float32)
-            if l.kind == 'conv':
-                l.w[:, :, :l.cin, :] = w
-            else:
-                l.w[:, :, :, :l.cin] = w
-            l.b.copy_(tf_params[l.name + '/biases'].to(self.dev, torch.float32))
+            assert tuple(w.shape) == l.tf_wshape(), (l.name, tuple(w.shape), l.tf_wshape())
+            for plo, tlo, n in l.in_map:
+                if l.kind == 'conv':
+                    l.w[:, :, plo:plo + n, :l.cout] = w[:, :, tlo:tlo + n, :]
+                else:
+                    l.w[:, :, :l.cout, plo:plo + n] = w[:, :, :, tlo:tlo + n]
+            l.b[:l.cout].copy_(tf_params[l.name + '/biases'].to(self.dev, torch.float32))
+        self._wplanes_version = None
 
     def _export(self, wattr, battr):
         out = OrderedDict()
         for l in self.layers:
             w = getattr(l, wattr)
-            out[l.name + '/weights'] = (w[:, :, :l.cin, :] if l.kind == 'conv' else w[:, :, :, :l.cin]).detach().cpu().clone()
-            out[l.name + '/biases'] = getattr(l, battr).detach().cpu().clone()
+            parts = []
+            for plo, tlo, n in l.in_map:
+                parts.append(w[:, :, plo:plo + n, :l.cout] if l.kind == 'conv' else w[:, :, :l.cout, plo:plo + n])
+            out[l.name + '/weights'] = torch.cat(parts, 2 if l.kind == 'conv' else 3).detach().cpu().clone()
+            out[l.name + '/biases'] = getattr(l, battr)[:l.cout].detach().cpu().clone()
         return out
 
     def export_tf_params(self):
@@ -390,7 +536,10 @@ class FlowNetEngine:
     def _alloc_activations(self):
         N, H, W, dev = self.N, self.H, self.W, self.dev
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        self.x0 = z(N, H, W, 4)       # mean-subtracted network input (4th channel zero)
+        # mean-subtracted network input (4th channel zero) + its operand planes (8 channels: conv1 walks K in groups of 8)
+        self.X0 = L.PT(z(N, H, W, 4), torch.zeros(self.n_planes, N, H, W, 8, dtype=torch.int16, device=dev)
+                       if self.n_planes else None)
+        self.x0 = self.X0.t
         self.im01 = z(N, H, W, 3)     # images in [0,1] for the losses
         for st in self.stages:
             st.alloc()
@@ -398,12 +547,18 @@ class FlowNetEngine:
         # views used by the loss code, tests and tools: the trained (last) network
         self.act = dict(last.act, x0=self.x0, im01=self.im01)
         self.grad = last.grad
-        # loss-side pyramid
+        # loss-side pyramid: one level per flow output of the last network (unsupervised.py:85-104)
+        self.layer_weights = LAYER_WEIGHTS_FULL_RES if self.full_res else LAYER_WEIGHTS
+        self.patch_distances = LAYER_PATCH_DISTANCES_FULL_RES if self.full_res else LAYER_PATCH_DISTANCES
+        self.final_flow_scale = FLOW_SCALE * 4 if self.full_res else FLOW_SCALE
         self.lv = []
-        for i, d in enumerate((4, 8, 16, 32, 64)):
+        for i, lvl in enumerate(last.flow_levels):
+            d = 2 ** lvl
             h, w = H // d, W // d
-            self.lv.append(dict(h=h, w=w, im=z(N, h, w, 3), gray1=z(N, h, w), gray2w=z(N, h, w), dist=z(N, h, w),
-                                dgray=z(N, h, w), flow=last.act['flow%d' % (i + 2)], gflow=last.grad['flow%d' % (i + 2)]))
+            im = self.im01 if d == 1 else z(N, h, w, 3)
+            self.lv.append(dict(h=h, w=w, im=im, gray1=z(N, h, w), gray2w=z(N, h, w), dist=z(N, h, w), dgray=z(N, h, w),
+                                flow=last.act['flow%d' % lvl], gflow=last.grad['flow%d' % lvl],
+                                fs=self.final_flow_scale / (2 ** i), lw=self.layer_weights[i], pd=self.patch_distances[i]))
         self.loss_acc = z(1)
         self.raw = z(N, H, W, 3)
         self.final_flow = z(N, H, W, 2)
@@ -411,23 +566,27 @@ class FlowNetEngine:
         self.epe_out = z(2)
 
     def _build_masks(self):
-        """create_border_mask(im, 0.1) (losses.py:338-344) then downsample 4, 2, 2, 2, 2 (unsupervised.py:101,147)."""
+        """create_border_mask(im, 0.1) (losses.py:338-344) then downsample 4, 2, 2, 2, 2 (unsupervised.py:101,147); with
+        full_res the mask itself is level 0 (unsupervised.py:94).  Every level owns ONE [B,h,w] buffer for the whole life
+        of the engine (so a captured hipGraph never holds a stale mask pointer): without augmentation it holds B copies of
+        the static mask, with augmentation the per-sample warped masks."""
         from .. import ops
-        H, W = self.H, self.W
+        H, W, B = self.H, self.W, self.B
         sz = int(math.ceil(min(H, W) * 0.1))
         m = torch.zeros(1, H, W, 1, device=self.dev)
         m[:, sz:H - sz, sz:W - sz] = 1.0
         self.border0, self._aug, self._mask_aug = m, None, False
-        ones = torch.ones(1, H, W, 1, device=self.dev)
-        use_border = bool(self.params.get('border_mask'))
-        cur = ops.downsample(m, 4)
-        cur1 = ops.downsample(ones, 4)
+        cur = m if bool(self.params.get('border_mask')) else torch.ones(1, H, W, 1, device=self.dev)
         for i, lv in enumerate(self.lv):
-            lv['mask'] = (cur if use_border else cur1).reshape(1, lv['h'], lv['w']).contiguous()
-            lv['mask_static'], lv['n_mask'] = lv['mask'], 1
-            if i + 1 < len(self.lv):
-                cur = ops.downsample(cur, 2)
-                cur1 = ops.downsample(cur1, 2)
+            if not (i == 0 and self.full_res):
+                cur = ops.downsample(cur, 4 if (i == 0) else 2)
+            lv['mask_static'] = cur.reshape(1, lv['h'], lv['w']).contiguous()
+            lv['mask'] = lv['mask_static'].expand(B, -1, -1).contiguous()
+            lv['n_mask'] = B
+
+    def _image_and_mask_pyramid_scales(self):
+        """Downsampling factor from the previous level for every loss level."""
+        return [1 if (i == 0 and self.full_res) else (4 if i == 0 else 2) for i in range(len(self.lv))]
 
     # ------------------------------------------------------------------ forward
     def set_input(self, im1, im2, augment=None):
@@ -437,24 +596,25 @@ class FlowNetEngine:
         mean-free ones for the network, and a per-sample border mask (product of the two warped masks)."""
         B, N, H, W = self.B, self.N, self.H, self.W
         lib = _lib.lib()
+        st = self.stream()
         self.raw[:B].copy_(im1)
         self.raw[B:].copy_(im2)
         if augment is None:
             check(lib.unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(self.im01),
-                                            self.mean_host, cl(N * H * W), stream()), "prepare_images")
+                                            self.mean_host, cl(N * H * W), st), "prepare_images")
             if self._mask_aug:
                 for lv in self.lv:
-                    lv['mask'], lv['n_mask'] = lv['mask_static'], 1
+                    lv['mask'].copy_(lv['mask_static'].expand(B, -1, -1))
                 self._mask_aug = False
+            self._input_planes()
             return
         from . import augment as A
         if self._aug is None:
             z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
-            self._aug = dict(tmp=z(N, H, W, 3), mg=z(B, H, W, 1), ml=z(B, H, W, 1),
-                             masks=[z(B, lv['h'], lv['w'], 1) for lv in self.lv])
+            self._aug = dict(tmp=z(N, H, W, 3), mg=z(B, H, W, 1), ml=z(B, H, W, 1))
         a = self._aug
         check(lib.unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(a['tmp']), self.mean_host, cl(N * H * W),
-                                        stream()), "prepare_images")
+                                        st), "prepare_images")
         tg, tl = augment['theta_global'], augment['theta_local']
         A.transformer(a['tmp'], tg, out=self.im01, n_samples=N)            # im1_geo, first pass of im2 (:40-44)
         A.transformer(self.im01[B:], tl, out=a['tmp'][B:], n_samples=B)    # im2 locally (:47-50)
@@ -464,29 +624,36 @@ class FlowNetEngine:
             A.transformer(self.border0, tl, out=a['ml'], n_samples=B)
             a['mg'].mul_(a['ml'])                                          # border_mask_local * global (:51)
             from .. import ops
-            cur = ops.downsample(a['mg'], 4)
-            for i, lv in enumerate(self.lv):
-                a['masks'][i].copy_(cur)
-                lv['mask'], lv['n_mask'] = a['masks'][i].view(B, lv['h'], lv['w']), B
-                if i + 1 < len(self.lv):
-                    cur = ops.downsample(cur, 2)
+            cur = a['mg']
+            for lv, sc in zip(self.lv, self._image_and_mask_pyramid_scales()):
+                if sc != 1:
+                    cur = ops.downsample(cur, sc)
+                lv['mask'].copy_(cur.view(B, lv['h'], lv['w']))
             self._mask_aug = True
         A.photometric(self.im01, augment, out=self.x0, mean=CHANNEL_MEAN)  # im*_photo - channel_mean (:53-57,67-68)
+        self._input_planes()
+
+    def _input_planes(self):
+        """Operand planes of the network input for conv1 of a FlowNetC (FlowNetS stages build theirs after stack_input)."""
+        if self.X0.pl is not None and self.stages[0].is_c:
+            L.planes_from_f32(self.x0, self.X0.pl, C=4)
 
     def forward_net(self):
         """flownet(im1, im2, spec, backward_flow=True) (flownet.py:14-81): every stage in order; a refinement stage
         consumes the previous stage's finest flow."""
+        self.refresh_weight_planes()
         prev = None
-        for st in self.stages:
-            st.forward(prev)
-            prev = st.act['flow2']
+        with torch.cuda.device(self.dev):
+            for st in self.stages:
+                st.forward(prev)
+                prev = st.act['flow2']
 
     def forward_loss(self, with_grad=True):
         """compute_losses + the pyramid assembly (losses.py:16-87, unsupervised.py:85-150) over the directed batch;
         with_grad also leaves d(loss)/d(flowN) in self.grad['flowN'].  Terms enter iff their `<name>_weight` is set
         (unsupervised.py:136-141), exactly the pruning TF does."""
         lib = _lib.lib()
-        st = stream()
+        st = self.stream()
         N, B = self.N, self.B
         P = self.params
         wt = lambda k: float(P.get(k + '_weight') or 0.0)
@@ -494,13 +661,13 @@ class FlowNetEngine:
         occl = {'': 0, None: 0, 'fb': 1, 'disocc': 2}[P.get('mask_occlusion', '')]
         use_border = bool(P.get('border_mask'))
         levels = self.lv if P.get('pyramid_loss') else self.lv[:1]
-        # image pyramid: downsample(im, 4) then successive downsample(., 2) (unsupervised.py:99-100,145-146)
-        check(lib.unflow_downsample_fwd(ptr(self.act['im01']), ptr(self.lv[0]['im']), N, self.H, self.W, 3, 4, st),
-              "downsample")
-        for i in range(1, len(levels)):
-            p = self.lv[i - 1]
-            check(lib.unflow_downsample_fwd(ptr(p['im']), ptr(self.lv[i]['im']), N, p['h'], p['w'], 3, 2, st),
-                  "downsample")
+        # image pyramid: downsample(im, 4) then successive downsample(., 2) (unsupervised.py:99-100,145-146); with
+        # full_res level 0 is the image itself (unsupervised.py:92-93)
+        prev_im, ph, pw = self.act['im01'], self.H, self.W
+        for lv, sc in list(zip(self.lv, self._image_and_mask_pyramid_scales()))[:len(levels)]:
+            if sc != 1:
+                check(lib.unflow_downsample_fwd(ptr(prev_im), ptr(lv['im']), N, ph, pw, 3, sc, st), "downsample")
+            prev_im, ph, pw = lv['im'], lv['h'], lv['w']
         need_fbwarp = bool(wt('fb')) or occl == 1
         need_fwarp = bool(wt('sym')) or occl == 2
         need_mask_terms = need_fbwarp or need_fwarp or bool(wt('occ')) or not use_border
@@ -512,8 +679,7 @@ class FlowNetEngine:
             levels = []
         for i, lv in enumerate(levels):
             h, w = lv['h'], lv['w']
-            fs = FLOW_SCALE / (2 ** i)
-            lw = LAYER_WEIGHTS[i]
+            fs, lw = lv['fs'], lv['lw']
             flow, gflow = lv['flow'], lv['gflow']
             gf = ptr(gflow) if with_grad else ptr(None)
             n1 = B * h * w
@@ -564,7 +730,7 @@ class FlowNetEngine:
                     gflow.add_(lv['dimtmp'])
             # ---- data terms
             if wt('ternary'):
-                D = LAYER_PATCH_DISTANCES[i]
+                D = lv['pd']
                 check(lib.unflow_gray_pair(ptr(lv['im']), 3, ptr(flow), cf(fs), ptr(lv['gray1']), ptr(lv['gray2w']), B, N, h,
                                            w, st), "gray_pair")
                 check(lib.unflow_ternary_fwd(ptr(lv['gray1']), ptr(lv['gray2w']), ptr(mask), n_mask, ptr(lv['dist']),
@@ -604,13 +770,13 @@ class FlowNetEngine:
             arr = (Level * len(levels))()
             for i, lv in enumerate(levels):
                 n1 = self.B * lv['h'] * lv['w']
-                lw = LAYER_WEIGHTS[i]
+                lw = lv['lw']
                 a = arr[i]
                 a.im, a.flow, a.gray1, a.gray2w = lv['im'].data_ptr(), lv['flow'].data_ptr(), lv['gray1'].data_ptr(), \
                     lv['gray2w'].data_ptr()
                 a.mask, a.dist, a.d_flow = lv['mask'].data_ptr(), lv['dist'].data_ptr(), lv['gflow'].data_ptr()
-                a.H, a.W, a.n_mask, a.max_distance = lv['h'], lv['w'], lv['n_mask'], LAYER_PATCH_DISTANCES[i]
-                a.flow_scale = FLOW_SCALE / (2 ** i)
+                a.H, a.W, a.n_mask, a.max_distance = lv['h'], lv['w'], lv['n_mask'], lv['pd']
+                a.flow_scale = lv['fs']
                 f32 = np.float32    # the same fp32 quotient the per-level entry points form from (weight, normaliser)
                 a.ternary_scale = float(f32(lw * wt('ternary')) / f32(n1))            # normaliser B*H*W*1 (losses.py:311-312)
                 a.smooth_scale = float(f32(lw * wt('smooth_2nd')) / f32(n1 * 4))      # B*H*W*4 per flow channel
@@ -630,26 +796,26 @@ class FlowNetEngine:
     def backward_net(self, part=None):
         """Gradients of the trained (last) network; earlier stages are behind stop_gradient (flownet.py:51-54).
         part 0 / 1: the two halves used to overlap the data-parallel all-reduce (see grad_buckets)."""
-        self.stages[-1].backward(part)
-        if part in (None, 1):
-            if self.train_all:
-                for i in range(len(self.stages) - 1, 0, -1):
-                    self._stack_backward(self.stages[i], self.stages[i - 1])
-                    self.stages[i - 1].backward()
-            self._bias_grads()
+        with torch.cuda.device(self.dev):
+            self.stages[-1].backward(part)
+            if part in (None, 1):
+                if self.train_all:
+                    for i in range(len(self.stages) - 1, 0, -1):
+                        self._stack_backward(self.stages[i], self.stages[i - 1])
+                        self.stages[i - 1].backward()
+                self._bias_grads()
 
     def _stack_backward(self, st, prev):
         """d loss / d (flow2 of the previous network) through the stage input of `st` (train_all).  The previous
         network's coarser flows do not reach the loss directly (only flows[-1] enters it, unsupervised.py:82-83)."""
-        for lvl in (3, 4, 5, 6):
+        for lvl in prev.flow_levels:
             prev.grad['flow%d' % lvl].zero_()
         g2 = prev.grad['flow2']
-        g2.zero_()
         pf = prev.act['flow2']
         dx = st.grad['x0s']
-        check(_lib.lib().unflow_stack_input_bwd(ptr(dx), dx.shape[3], ptr(self.x0), ptr(pf), ptr(g2), self.B, self.N,
-                                                self.H, self.W, pf.shape[1], pf.shape[2], cf(4 * FLOW_SCALE), stream()),
-              "stack_input_bwd")
+        check(_lib.lib().unflow_stack_input_bwd(ptr(dx), dx.stride(2), ptr(self.x0), ptr(pf), ptr(g2), self.B, self.N,
+                                                self.H, self.W, pf.shape[1], pf.shape[2], cf(4 * FLOW_SCALE),
+                                                self.stream()), "stack_input_bwd")
 
     def grad_buckets(self):
         """Flat ranges of self.G: (early, late).  `early` = the weights whose gradients are complete after
@@ -684,7 +850,7 @@ class FlowNetEngine:
                 plan.append((n, xs, lds, npx, cs, outs, ws))
             self._bias_plan = plan
         for n, xs, lds, npx, cs, outs, ws in self._bias_plan:
-            check(lib.unflow_colsum_batched(n, xs, lds, npx, cs, outs, ptr(ws), _lib.csz(ws.numel() * 4), stream()),
+            check(lib.unflow_colsum_batched(n, xs, lds, npx, cs, outs, ptr(ws), _lib.csz(ws.numel() * 4), self.stream()),
                   "colsum_batched")
 
     # ------------------------------------------------------------------ optimiser
@@ -694,15 +860,16 @@ class FlowNetEngine:
         self.step_count += 1
         t = self.step_count
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        self._wplanes_version = None       # the parameters change behind torch's back: their operand planes are stale
         if self.defer_l2:   # the loss of THIS step gets its regularisation term from the pre-update parameters here
             check(_lib.lib().unflow_adam_step_regloss(ptr(self.P), ptr(self.G), ptr(self.M), ptr(self.V),
                                                       cl(self.n_params), cl(self.n_weights), cf(grad_scale), cf(L2_SCALE),
                                                       cf(lr_t), cf(beta1), cf(beta2), cf(eps), ptr(self.loss_acc),
-                                                      stream()), "adam")
+                                                      self.stream()), "adam")
             return
         check(_lib.lib().unflow_adam_step(ptr(self.P), ptr(self.G), ptr(self.M), ptr(self.V), cl(self.n_params),
                                           cl(self.n_weights), cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1),
-                                          cf(beta2), cf(eps), stream()), "adam")
+                                          cf(beta2), cf(eps), self.stream()), "adam")
 
     # ------------------------------------------------------------------ composite
     def fwd_bwd(self, im1=None, im2=None):
@@ -725,18 +892,24 @@ class FlowNetEngine:
         return loss
 
     def final_flows(self):
-        """final_flow_fw / _bw (unsupervised.py:103-104): resize_bilinear(flow2, im_shape) * 5 * 4."""
+        """final_flow_fw / _bw: resize_bilinear(flow2, im_shape) * 5 * 4 (unsupervised.py:103-104), or flow0 * 20 with
+        full_res (unsupervised.py:95-97)."""
+        if self.full_res:
+            torch.mul(self.act['flow0'], FLOW_SCALE * 4, out=self.final_flow)
+            return self.final_flow[:self.B], self.final_flow[self.B:]
         f2 = self.act['flow2']
         N, h, w, _ = f2.shape
         check(_lib.lib().unflow_resize_bilinear_tf1(ptr(f2), ptr(self.final_flow), N, h, w, 2, self.H, self.W,
-                                                    cf(FLOW_SCALE * 4), stream()), "resize_bilinear")
+                                                    cf(FLOW_SCALE * 4), self.stream()), "resize_bilinear")
         return self.final_flow[:self.B], self.final_flow[self.B:]
 
     def flows(self):
-        """(flows_fw, flows_bw): lists [flow2..flow6], NHWC, like flownet(..., backward_flow=True)[-1]."""
+        """(flows_fw, flows_bw): lists [flow2..flow6] ([flow0, flow1, flow2..] with full_res), NHWC, like
+        flownet(..., backward_flow=True)[-1]."""
         B = self.B
-        fw = [self.act['flow%d' % l][:B] for l in (2, 3, 4, 5, 6)]
-        bw = [self.act['flow%d' % l][B:] for l in (2, 3, 4, 5, 6)]
+        lv = self.stages[-1].flow_levels
+        fw = [self.act['flow%d' % l][:B] for l in lv]
+        bw = [self.act['flow%d' % l][B:] for l in lv]
         return fw, bw
 
 
@@ -746,7 +919,7 @@ def flow_error_avg(flow_1, flow_2, mask=None):
     out = torch.empty(2, dtype=torch.float32, device=f1.device)
     npix = f1.numel() // 2
     check(_lib.lib().unflow_flow_error_sums(ptr(f1), ptr(f2), ptr(None if mask is None else mask.contiguous()),
-                                            ptr(out), cl(npix), stream()), "flow_error")
+                                            ptr(out), cl(npix), stream(f1.device)), "flow_error")
     return out[0] / out[1]
 
 

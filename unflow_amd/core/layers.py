@@ -125,3 +125,139 @@ def leaky_bwd_inplace(dy, y):
     yp, ldy = nhwc(y)[:2]
     check(_lib.lib().unflow_leaky_bwd_inplace(dp, ldd, yp, ldy, _lib.cl(B * H * W), C, stream()), "leaky_bwd")
     return dy
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Operand planes (csrc/conv_planes.hip): the same layer calls with the tensors' 16-bit planes riding along.
+# ---------------------------------------------------------------------------------------------------------------
+def round8(c):
+    return (c + 7) // 8 * 8
+
+
+class PT:
+    """An NHWC fp32 tensor (or channel-slice view) together with its operand planes: `pl` is an int16 view
+    [P, N, H, W, Cp] of the same pixels (P = 3: bf16 hi/mid/lo, P = 1: fp16; Cp >= round8(C), pad channels zero), or None."""
+    __slots__ = ('t', 'pl')
+
+    def __init__(self, t, pl=None):
+        self.t, self.pl = t, pl
+
+    def sl(self, lo, hi):
+        """Channel slice [lo, hi): the planes view keeps the channels up to round8 of the slice width (zero pad or, for
+        an interior slice whose width is a multiple of 8, exactly the slice)."""
+        if self.pl is None:
+            return PT(self.t[..., lo:hi])
+        return PT(self.t[..., lo:hi], self.pl[..., lo:min(self.pl.shape[-1], lo + round8(hi - lo))])
+
+    @staticmethod
+    def alloc(shape, device, n_planes):
+        """Zero tensor + zero planes (n_planes 0: no planes)."""
+        import torch as _t
+        t = _t.zeros(*shape, dtype=_t.float32, device=device)
+        pl = _t.zeros(n_planes, *shape[:-1], round8(shape[-1]), dtype=_t.int16, device=device) if n_planes else None
+        return PT(t, pl)
+
+
+def _pt(x):
+    return x if isinstance(x, PT) else PT(x)
+
+
+def _ws_pl(device, B, H, W, Cin, Cout, k, stride, npl):
+    n = _lib.lib().unflow_conv_pl_workspace_bytes(B, H, W, Cin, Cout, k, stride, npl)
+    t = workspace(n, device, slot=_WS_SLOT[0])
+    return ptr(t), csz(t.numel() * 4)
+
+
+def _npl(*pts):
+    for q in pts:
+        if q.pl is not None:
+            return q.pl.shape[0]
+    return 0
+
+
+def planes_from_f32(x, out_pl, C=None):
+    """Fill the planes view `out_pl` [P,N,H,W,>=round8(C)] from the fp32 NHWC tensor / slice x (pad channels zeroed)."""
+    xp, ldx, B, H, W, Cx = nhwc(x)
+    check(_lib.lib().unflow_planes_from_f32(xp, ldx, _lib.cl(B * H * W), Cx if C is None else C, _lib.planes_of(out_pl),
+                                            stream()), "planes_from_f32")
+
+
+def conv_fwd(x, w, w_pl, bias, y, stride, leaky):
+    """conv2d_fwd on PTs; w_pl: the layer's TRANSPOSED weight planes [P, k*k, Cout, round8(Cin)] (or None)."""
+    x, y = _pt(x), _pt(y)
+    xp, ldx, B, H, W, Cin = nhwc(x.t)
+    yp, ldy, _, Ho, Wo, Cout = nhwc(y.t)
+    k = w.shape[0]
+    assert tuple(w.shape) == (k, k, Cin, Cout) and w.is_contiguous() and (Ho, Wo) == out_hw(H, W, stride)
+    wsp, wsn = _ws_pl(x.t.device, B, H, W, Cin, Cout, k, stride, _npl(x, y))
+    check(_lib.lib().unflow_conv2d_fwd_pl(xp, ldx, _lib.planes_of(x.pl), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp, ldy,
+                                          _lib.planes_of(y.pl), B, H, W, Cin, Cout, k, stride, int(bool(leaky)), wsp, wsn,
+                                          stream()), "conv2d_fwd_pl")
+
+
+def conv_bwd_data(dz, w, w_pl, dx, stride, accumulate=False, act_src=None, act_lo=0, act_hi=0):
+    """conv2d_bwd_data on PTs; w_pl: the DIRECT weight planes [P, k*k, Cin, round8(Cout)].  dx's planes receive the
+    channels [act_lo, act_hi) (final after this call)."""
+    dz, dx = _pt(dz), _pt(dx)
+    dzp, lddz, B, Ho, Wo, Cout = nhwc(dz.t)
+    dxp, lddx, _, H, W, Cin = nhwc(dx.t)
+    k = w.shape[0]
+    assert tuple(w.shape) == (k, k, Cin, Cout)
+    ap, lda = (ptr(None), 0)
+    if act_src is not None:
+        ap, lda = nhwc(_pt(act_src).t)[:2]
+    wsp, wsn = _ws_pl(dz.t.device, B, H, W, Cin, Cout, k, stride, _npl(dz, dx))
+    check(_lib.lib().unflow_conv2d_bwd_data_pl(dzp, lddz, _lib.planes_of(dz.pl), ptr(w), _lib.planes_of(w_pl), dxp, lddx,
+                                               _lib.planes_of(dx.pl), act_lo, act_hi, B, H, W, Cin, Cout, k, stride,
+                                               int(bool(accumulate)), ap, lda, act_lo, act_hi, wsp, wsn, stream()),
+          "conv2d_bwd_data_pl")
+
+
+def conv_bwd_filter(x, dz, dw, stride):
+    x, dz = _pt(x), _pt(dz)
+    xp, ldx, B, H, W, Cin = nhwc(x.t)
+    dzp, lddz, _, Ho, Wo, Cout = nhwc(dz.t)
+    k = dw.shape[0]
+    assert tuple(dw.shape) == (k, k, Cin, Cout) and dw.is_contiguous()
+    wsp, wsn = _ws_pl(x.t.device, B, H, W, Cin, Cout, k, stride, _npl(x, dz))
+    check(_lib.lib().unflow_conv2d_bwd_filter_pl(xp, ldx, _lib.planes_of(x.pl), dzp, lddz, _lib.planes_of(dz.pl), ptr(dw), B, H,
+                                                 W, Cin, Cout, k, stride, wsp, wsn, stream()), "conv2d_bwd_filter_pl")
+
+
+def deconv_fwd(x, w, w_pl, bias, y, leaky):
+    """conv2d_transpose_fwd on PTs; w_pl: the DIRECT weight planes [P, 16, Cout, round8(Cin)]."""
+    x, y = _pt(x), _pt(y)
+    xp, ldx, B, H, W, Cin = nhwc(x.t)
+    yp, ldy, _, Ho, Wo, Cout = nhwc(y.t)
+    assert tuple(w.shape) == (4, 4, Cout, Cin) and (Ho, Wo) == (2 * H, 2 * W)
+    wsp, wsn = _ws_pl(x.t.device, B, 2 * H, 2 * W, Cin, Cout, 4, 2, _npl(x, y))
+    check(_lib.lib().unflow_conv2d_transpose_fwd_pl(xp, ldx, _lib.planes_of(x.pl), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp,
+                                                    ldy, _lib.planes_of(y.pl), B, H, W, Cin, Cout, int(bool(leaky)), wsp, wsn,
+                                                    stream()), "conv2d_transpose_fwd_pl")
+
+
+def deconv_bwd_data(dz, w, w_pl, dx, accumulate=False, act_src=None, act_lo=0, act_hi=0):
+    """conv2d_transpose_bwd_data on PTs; w_pl: the TRANSPOSED weight planes [P, 16, Cin, round8(Cout)]."""
+    dz, dx = _pt(dz), _pt(dx)
+    dzp, lddz, B, Ho, Wo, Cout = nhwc(dz.t)
+    dxp, lddx, _, H, W, Cin = nhwc(dx.t)
+    assert tuple(w.shape) == (4, 4, Cout, Cin) and (Ho, Wo) == (2 * H, 2 * W)
+    ap, lda = (ptr(None), 0)
+    if act_src is not None:
+        ap, lda = nhwc(_pt(act_src).t)[:2]
+    wsp, wsn = _ws_pl(dz.t.device, B, Ho, Wo, Cin, Cout, 4, 2, _npl(dz, dx))
+    check(_lib.lib().unflow_conv2d_transpose_bwd_data_pl(dzp, lddz, _lib.planes_of(dz.pl), ptr(w), _lib.planes_of(w_pl), dxp,
+                                                         lddx, _lib.planes_of(dx.pl), act_lo, act_hi, B, H, W, Cin, Cout,
+                                                         int(bool(accumulate)), ap, lda, act_lo, act_hi, wsp, wsn, stream()),
+          "conv2d_transpose_bwd_data_pl")
+
+
+def deconv_bwd_filter(x, dz, dw):
+    x, dz = _pt(x), _pt(dz)
+    xp, ldx, B, H, W, Cin = nhwc(x.t)
+    dzp, lddz, _, Ho, Wo, Cout = nhwc(dz.t)
+    assert tuple(dw.shape) == (4, 4, Cout, Cin)
+    wsp, wsn = _ws_pl(x.t.device, B, Ho, Wo, Cin, Cout, 4, 2, _npl(x, dz))
+    check(_lib.lib().unflow_conv2d_transpose_bwd_filter_pl(xp, ldx, _lib.planes_of(x.pl), dzp, lddz, _lib.planes_of(dz.pl),
+                                                           ptr(dw), B, H, W, Cin, Cout, wsp, wsn, stream()),
+          "conv2d_transpose_bwd_filter_pl")

@@ -19,26 +19,14 @@
 // HBM side: 16-byte loads, 128 B contiguous per pixel-row of a tile (channels-last).
 // Deep layers (M = 384..6144 sites) use split-K so the launch covers the 256 CUs; partials go to a
 // caller workspace and a fixed-order reduce applies the epilogue (deterministic, no float atomics).
-#include <stdlib.h>
-#include <cstdint>
-#include <cstring>
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "igemm_shared.h"
 
 namespace {
+using namespace igemm;
 
-constexpr int BK = 32;
 constexpr int LDK = BK + 4;
 
-struct TapClass {
-  int nty, ntx;  // taps of this class
-  int dy0, dx0;  // source offset of tap (0,0); tap (ty,tx) -> dy0 + ty*dstep
-  int ky0, kx0;  // weight index of tap (0,0);  -> ky0 + ty*kstep
-  int py, px;    // destination parity offset
-};
-
-struct GatherParams {
+struct GatherParams : GatherGeom {
   const float* src;
   const float* w;
   const float* bias;
@@ -46,37 +34,14 @@ struct GatherParams {
   float* partial;  // split-K partials [nsplit][dst pixels][N] (nsplit > 1)
   const float* act_src;
   int lds, ldd, ld_act, act_lo, act_hi;
-  int B, Hg, Wg, Hs, Ws, sm;
-  int dstep, kstep, KW;
-  int Cs, N;
-  int Hd, Wd, so;
-  int ncls, nsplit;
+  int nsplit;
   int leaky, accumulate;
   unsigned cs_magic;  // ceil(2^32 / Cs)
   int dbg;            // ablation switches (UNFLOW_DBG env; 0 in production)
-  int wtaps;          // taps of the whole weight tensor (KH*KW)
-  TapClass cls[4];
+  PlaneOut pl;        // optional 16-bit operand planes of the output (conv_planes.hip consumers)
 };
 
-__device__ __forceinline__ unsigned fast_div(unsigned a, unsigned magic) { return __umulhi(a, magic); }
-
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// Raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor; an offset >= num_records returns 0
-// (hardware bounds check), which replaces every predicate/select of the zero-padding logic.  OOB_MARK is added
-// to (or used as) an offset to force that; two marks sum to 2^31, still out of range.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int OOB_MARK = 0x40000000;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(bytes > 0x3fffffffu ? 0x3fffffffu : bytes), 0x00020000);
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
 
 // ---- fp32-equivalent products on the bf16 matrix cores (MATH == 1) -------------------------------------------------------
 // x = hi + mid + lo with three bf16 values (3 x 8 significand bits = the 24 of fp32, same exponent range); a*b is summed
@@ -93,11 +58,6 @@ constexpr int LDH = BK;       // bf16 row pitch of one plane: 64 bytes, no paddi
 // ds_read_b128 serves per cycle (rows r .. r+15, same logical granule) then touch 16 different granule slots of 256 bytes.
 __device__ __forceinline__ int swz_off(int row, int kquad) {   // offset (in bf16 elements) of k = 4*kquad of `row`
   return row * LDH + 8 * ((kquad >> 1) ^ ((row >> 2) & 3)) + 4 * (kquad & 1);
-}
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
 }
 // four consecutive k of one row -> three planes, 8 bytes each
 __device__ __forceinline__ void split_store(unsigned short* __restrict__ dst, int plane_stride, const float4 v) {
@@ -433,6 +393,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
           if (p.accumulate) v += *d;
           if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
           *d = v;
+          store_planes(p.pl, (size_t)px, n, v);
         }
       }
     }
@@ -453,6 +414,7 @@ __global__ void splitk_reduce_epilogue_scalar_kernel(const GatherParams p) {
     if (p.accumulate) v += *d;
     if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[px * p.ld_act + n]);
     *d = v;
+    store_planes(p.pl, px, n, v);
   }
 }
 
@@ -490,19 +452,17 @@ __global__ void splitk_reduce_epilogue_kernel(const GatherParams p) {
       if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
     }
     *d = v;
+    store_planes4(p.pl, px, n, v);
   }
 }
 
 // ------------------------------------------------------------------ wgrad
-struct WgradParams {
+struct WgradParams : WgradGeom {
   const float* src;  // gathered operand [B,Hs,Ws,lds], channels a
   const float* dst;  // dense operand   [B,Hg,Wg,ldd], channels b
   float* out;        // dW [(tap,a)][b] (ld = Cb) when nsplit == 1
   float* partial;    // [nsplit][Mp][Cb] otherwise
   int lds, ldd;
-  int B, Hg, Wg, Hs, Ws, sm;
-  int KH, KW, dy0, dx0;  // tap (ky,kx) -> offset dy0 + ky
-  int Ca, Cb;
   int nsplit;
   unsigned ca_magic;
 };
@@ -788,40 +748,6 @@ __global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p
     }
 }
 
-// out[g][e] = sum_{k < fan} partial[g*fan + k][e]  (fixed order; g < ceil(S/fan)).  With S <= fan this is the
-// final sum.  Applied repeatedly it is a deterministic tree reduction whose serial depth is <= fan.
-__global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n, int S,
-                                    int fan) {
-  const int G = (S + fan - 1) / fan;
-  const size_t total = n * (size_t)G;
-  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const size_t g = t / n, e = t - g * n;
-    const int k1 = min(S, (int)(g + 1) * fan);
-    float v = 0.f;
-#pragma unroll 8
-    for (int k = (int)g * fan; k < k1; k++) v += partial[(size_t)k * n + e];
-    out[g * n + e] = v;
-  }
-}
-
-// float4 variant (n % 4 == 0): same fixed order per element, a quarter of the threads, 8 loads in flight.
-__global__ void sum_partials4_kernel(const float4* __restrict__ partial, float4* __restrict__ out, size_t nq, int S,
-                                     int fan) {
-  const int G = (S + fan - 1) / fan;
-  const size_t total = nq * (size_t)G;
-  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const size_t g = t / nq, e = t - g * nq;
-    const int k1 = min(S, (int)(g + 1) * fan);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int k = (int)g * fan; k < k1; k++) {
-      const float4 a = partial[(size_t)k * nq + e];
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    }
-    out[g * nq + e] = v;
-  }
-}
-
 // Column sums of a [npix, C] slice (bias gradients): block = 64 columns x 4 row-lanes.
 __global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, long npix, int C,
                                       float* __restrict__ partial) {
@@ -889,6 +815,7 @@ struct SkinnyBwdParams {
   const float* act_src; int ld_act, act_lo, act_hi;
   int accumulate;
   int B, H, W, Cin, k, pt, pl;
+  PlaneOut po;                 // optional 16-bit operand planes of dx (final pre-activation gradients)
 };
 
 // dx[pix, ci] (+)= sum_tap sum_co dz[pix + pad - tap, co] * w[tap, ci, co]; thread = (pixel, ci-quad).
@@ -926,6 +853,7 @@ __global__ __launch_bounds__(256) void skinny_conv_dgrad_kernel(const SkinnyBwdP
       if (p.accumulate) v += d[j];
       if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[pxl * p.ld_act + n]);
       d[j] = v;
+      store_planes(p.po, (size_t)pxl, n, v);
     }
   }
 }
@@ -1216,6 +1144,7 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
       }
     }
     *reinterpret_cast<float4*>(d) = v;
+    store_planes4(p.po, (size_t)pxl, c4 * 4, v);
   }
 }
 
@@ -1351,6 +1280,7 @@ __global__ __launch_bounds__(256) void pointwise32_dgrad_kernel(const SkinnyBwdP
       }
     }
     *reinterpret_cast<float4*>(d) = v;
+    store_planes4(p.po, (size_t)pxl, c4 * 4, v);
   }
 }
 
@@ -1359,7 +1289,7 @@ __global__ __launch_bounds__(256) void pointwise32_dgrad_kernel(const SkinnyBwdP
 template <int CI, int CO>
 __global__ void tiny_deconv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                        const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int H,
-                                       int W) {
+                                       int W, const PlaneOut po) {
   const int OH = 2 * H, OW = 2 * W;
   const long n = (long)B * OH * OW;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -1383,7 +1313,10 @@ __global__ void tiny_deconv_fwd_kernel(const float* __restrict__ x, int ldx, con
       }
     }
 #pragma unroll
-    for (int c = 0; c < CO; c++) y[e * ldy + c] = acc[c];
+    for (int c = 0; c < CO; c++) {
+      y[e * ldy + c] = acc[c];
+      store_planes(po, (size_t)e, c, acc[c]);
+    }
   }
 }
 
@@ -1592,119 +1525,12 @@ __global__ void leaky_bwd_inplace_kernel(float* __restrict__ dy, int lddy, const
 }
 
 // ------------------------------------------------------------------ host side
-inline void same_pads(int in, int k, int s, int* before, int* out) {
-  const int o = (in + s - 1) / s;
-  int total = (o - 1) * s + k - in;
-  if (total < 0) total = 0;
-  *before = total / 2;
-  *out = o;
-}
-
-inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
-
-// ---- geometry builders (shared by the launchers and the workspace query)
-inline void build_conv_fwd(GatherParams& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
-  int pt, pl, Ho, Wo;
-  same_pads(H, k, stride, &pt, &Ho);
-  same_pads(W, k, stride, &pl, &Wo);
-  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
-  p.dstep = 1; p.kstep = 1; p.KW = k; p.Cs = Cin; p.N = Cout; p.wtaps = k * k;
-  p.Hd = Ho; p.Wd = Wo; p.so = 1; p.ncls = 1;
-  p.cls[0] = TapClass{k, k, -pt, -pl, 0, 0, 0, 0};
-}
-
-inline int build_conv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
-  int pt, pl, Ho, Wo;
-  same_pads(H, k, stride, &pt, &Ho);
-  same_pads(W, k, stride, &pl, &Wo);
-  p.B = B; p.Hs = Ho; p.Ws = Wo; p.sm = 1;
-  p.dstep = -1; p.KW = k; p.Cs = Cout; p.N = Cin; p.wtaps = k * k;
-  p.Hd = H; p.Wd = W;
-  if (stride == 1) {
-    p.Hg = H; p.Wg = W; p.so = 1; p.ncls = 1; p.kstep = 1;
-    p.cls[0] = TapClass{k, k, pt, pl, 0, 0, 0, 0};
-    return UNFLOW_OK;
-  }
-  // input pixel (2*yg+py): contributing taps ky == (py+pt) mod 2, source row yg + (py+pt-ky)/2
-  if (H % 2 != 0 || W % 2 != 0) return UNFLOW_ERR_UNSUPPORTED;
-  p.Hg = H / 2; p.Wg = W / 2; p.so = 2; p.ncls = 4; p.kstep = 2;
-  for (int c = 0; c < 4; c++) {
-    const int py = c >> 1, px = c & 1;
-    const int ky0 = (py + pt) & 1, kx0 = (px + pl) & 1;
-    const int nty = ky0 < k ? (k - ky0 + 1) / 2 : 0, ntx = kx0 < k ? (k - kx0 + 1) / 2 : 0;
-    if (nty == 0 || ntx == 0) return UNFLOW_ERR_UNSUPPORTED;
-    p.cls[c] = TapClass{nty, ntx, (py + pt - ky0) / 2, (px + pl - kx0) / 2, ky0, kx0, py, px};
-  }
-  return UNFLOW_OK;
-}
-
-// conv_transpose k4 s2 'SAME': oy = 2*iy + ky - 1
-inline void build_deconv_fwd(GatherParams& p, int B, int H, int W, int Cin, int Cout) {
-  p.B = B; p.Hg = H; p.Wg = W; p.Hs = H; p.Ws = W; p.sm = 1;
-  p.dstep = -1; p.kstep = 2; p.KW = 4; p.Cs = Cin; p.N = Cout; p.wtaps = 16;
-  p.Hd = 2 * H; p.Wd = 2 * W; p.so = 2; p.ncls = 4;
-  for (int c = 0; c < 4; c++) {
-    const int py = c >> 1, px = c & 1;
-    const int ky0 = (py + 1) & 1, kx0 = (px + 1) & 1;
-    p.cls[c] = TapClass{2, 2, (py + 1 - ky0) / 2, (px + 1 - kx0) / 2, ky0, kx0, py, px};
-  }
-}
-
-inline void build_deconv_dgrad(GatherParams& p, int B, int H, int W, int Cin, int Cout) {
-  p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
-  p.dstep = 1; p.kstep = 1; p.KW = 4; p.Cs = Cout; p.N = Cin; p.wtaps = 16;
-  p.Hd = H; p.Wd = W; p.so = 1; p.ncls = 1;
-  p.cls[0] = TapClass{4, 4, -1, -1, 0, 0, 0, 0};
-}
-
-inline void build_conv_wgrad(WgradParams& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
-  int pt, pl, Ho, Wo;
-  same_pads(H, k, stride, &pt, &Ho);
-  same_pads(W, k, stride, &pl, &Wo);
-  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
-  p.KH = k; p.KW = k; p.dy0 = -pt; p.dx0 = -pl; p.Ca = Cin; p.Cb = Cout;
-}
-
-// dW[ky,kx,co,ci] = sum_{input sites} dz[2iy+ky-1, 2ix+kx-1, co] * x[iy,ix,ci]
-inline void build_deconv_wgrad(WgradParams& p, int B, int H, int W, int Cin, int Cout) {
-  p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
-  p.KH = 4; p.KW = 4; p.dy0 = -1; p.dx0 = -1; p.Ca = Cout; p.Cb = Cin;
-}
-
 // ---- planners
-constexpr int REDUCE_FAN = 32;
-
-// Bytes of scratch reduce_partials needs after the S*n partials themselves.
-inline size_t reduce_scratch_bytes(size_t n, int S) {
-  return S > REDUCE_FAN ? 2 * (size_t)((S + REDUCE_FAN - 1) / REDUCE_FAN) * n * sizeof(float) : 0;
-}
 
 struct GatherPlan {
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
   int nsplit;
 };
-
-// Resident workgroups per launch ("slots"): 256 CUs x blocks per CU of each tile config (LDS/VGPR bound:
-// 128x128 -> 3, 128x64 -> 4, 64x64 -> 6).  A split count is chosen so the launch is ONE full round of
-// resident blocks (blocks * nsplit <= slots, as close as possible): 1088 blocks on 768 slots run as 1.4 rounds.
-inline int fill_one_round(long blocks, int slots, int max_split) {
-  if (blocks >= slots) return 1;
-  int ns = (int)(slots / blocks);
-  if (ns > max_split) ns = max_split;
-  if (ns < 1) ns = 1;
-  // With only 2 resident 128x128 blocks per CU (bf16x3 tiles) one round can be badly filled (288 blocks on 512 slots):
-  // then a split that runs 2-3 well-filled rounds wins.  Take it only for a clear gain, and the fewest splits that get it.
-  auto eff = [&](int n) { const long b = blocks * n; return (double)b / (double)(((b + slots - 1) / slots) * slots); };
-  const double e1 = eff(ns);
-  if (e1 < 0.8) {
-    int best = ns;
-    double be = e1;
-    for (int n = ns + 1; n <= max_split && blocks * n <= 3L * slots; n++)
-      if (eff(n) > be + 0.02) { best = n; be = eff(n); }
-    if (be >= e1 + 0.15) ns = best;
-  }
-  return ns;
-}
 
 // The 128-row gather tiles (conv fwd / dgrad, deconv fwd / dgrad) compute on the bf16 matrix cores by default (3-way
 // split, six terms: fp32-equivalent, see split_store); UNFLOW_CONV_MATH=fp32 selects v_mfma_f32_32x32x2_f32 for them too.
@@ -1813,29 +1639,6 @@ inline int head_wgrad_blocks(int B, int H, int W, int Cin, int S, int* strips_pe
 constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)REDUCE_FAN * C * sizeof(float) + 512; }
 
 // ---- launchers
-// out[e] = sum_s partial[s][e]; `scratch` (reduce_scratch_bytes) is used when S > REDUCE_FAN.
-inline void launch_sum_partials(const float* partial, float* out, size_t n, int S, int G, hipStream_t st) {
-  const bool vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  if (vec)
-    sum_partials4_kernel<<<stream_grid((long)(n / 4 * G)), 256, 0, st>>>(reinterpret_cast<const float4*>(partial),
-                                                                        reinterpret_cast<float4*>(out), n / 4, S, REDUCE_FAN);
-  else
-    sum_partials_kernel<<<stream_grid((long)(n * G)), 256, 0, st>>>(partial, out, n, S, REDUCE_FAN);
-}
-
-inline int reduce_partials(const float* partial, float* scratch, float* out, size_t n, int S, hipStream_t st) {
-  while (S > REDUCE_FAN) {
-    const int G = (S + REDUCE_FAN - 1) / REDUCE_FAN;
-    launch_sum_partials(partial, scratch, n, S, G, st);
-    // next level reads `scratch`; its output must not alias: levels alternate between scratch halves
-    partial = scratch;
-    scratch = scratch + (size_t)G * n;
-    S = G;
-  }
-  launch_sum_partials(partial, out, n, S, 1, st);
-  return launch_status();
-}
-
 template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0, int PF = 1>
 int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
@@ -1960,6 +1763,22 @@ int run_colsum(const float* dz, int ld, long npix, int C, float* out, void* ws, 
 }  // namespace
 
 // ===================================================================== C ABI
+// *_po: the plain entry points plus optional output planes (called by the *_pl entry points of conv_planes.hip)
+int unflow_conv2d_fwd_po(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int leaky, const igemm::PlaneOut& po, void* workspace,
+                         size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_bwd_data_po(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W, int Cin,
+                              int Cout, int k, int stride, int accumulate, const float* act_src, int ld_act, int act_lo,
+                              int act_hi, const igemm::PlaneOut& po, void* workspace, size_t workspace_bytes,
+                              unflow_stream_t stream);
+int unflow_conv2d_transpose_fwd_po(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H,
+                                   int W, int Cin, int Cout, int leaky, const igemm::PlaneOut& po, void* workspace,
+                                   size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_transpose_bwd_data_po(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W,
+                                        int Cin, int Cout, int accumulate, const float* act_src, int ld_act, int act_lo,
+                                        int act_hi, const igemm::PlaneOut& po, void* workspace, size_t workspace_bytes,
+                                        unflow_stream_t stream);
+
 UNFLOW_API size_t unflow_conv_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride) {
   // Exact requirement of the fwd / bwd_data / bwd_filter entry points of a conv2d with these dims
   // (and, for k == 4 && stride == 2, of the conv2d_transpose whose OUTPUT is [B,H,W,Cout]).
@@ -1999,6 +1818,14 @@ UNFLOW_API size_t unflow_conv_workspace_bytes(int B, int H, int W, int Cin, int 
 UNFLOW_API int unflow_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B,
                                  int H, int W, int Cin, int Cout, int k, int stride, int leaky, void* workspace,
                                  size_t workspace_bytes, unflow_stream_t stream) {
+  return unflow_conv2d_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, k, stride, leaky, igemm::PlaneOut{}, workspace,
+                              workspace_bytes, stream);
+}
+
+// The same op with optional 16-bit operand planes of the output (conv_planes.hip consumers); Cout <= 4 heads write none.
+int unflow_conv2d_fwd_po(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int leaky, const igemm::PlaneOut& po, void* workspace,
+                         size_t workspace_bytes, unflow_stream_t stream) {
   if (!x || !w || !y) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
   if (Cin % 4 != 0 || ldx % 4 != 0 || ldx < Cin || ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
@@ -2032,6 +1859,7 @@ UNFLOW_API int unflow_conv2d_fwd(const float* x, int ldx, const float* w, const 
   build_conv_fwd(p, B, H, W, Cin, Cout, k, stride);
   p.src = x; p.w = w; p.bias = bias; p.dst = y; p.act_src = nullptr;
   p.lds = ldx; p.ldd = ldy; p.leaky = leaky; p.accumulate = 0;
+  p.pl = po;
   return run_gather<false>(p, workspace, workspace_bytes, st);
 }
 
@@ -2039,6 +1867,14 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
                                       int W, int Cin, int Cout, int k, int stride, int accumulate,
                                       const float* act_src, int ld_act, int act_lo, int act_hi, void* workspace,
                                       size_t workspace_bytes, unflow_stream_t stream) {
+  return unflow_conv2d_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, k, stride, accumulate, act_src, ld_act, act_lo,
+                                   act_hi, igemm::PlaneOut{}, workspace, workspace_bytes, stream);
+}
+
+int unflow_conv2d_bwd_data_po(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W, int Cin,
+                              int Cout, int k, int stride, int accumulate, const float* act_src, int ld_act, int act_lo,
+                              int act_hi, const igemm::PlaneOut& po, void* workspace, size_t workspace_bytes,
+                              unflow_stream_t stream) {
   if (!dz || !w || !dx) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || (stride != 1 && stride != 2)) return UNFLOW_ERR_SHAPE;
   if (Cin % 4 != 0 || lddx < Cin || lddz < Cout) return UNFLOW_ERR_UNSUPPORTED;
@@ -2048,7 +1884,7 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
     int pt, pl, Ho, Wo;
     same_pads(H, k, 1, &pt, &Ho);
     same_pads(W, k, 1, &pl, &Wo);
-    SkinnyBwdParams p{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, k, pt, pl};
+    SkinnyBwdParams p{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, k, pt, pl, po};
     const int S = (lddx % 4 == 0 && (!act_src || ld_act % 4 == 0)) ? head_strip(B, H, W, k, Cout) : 0;
     if (S) {
       const long jobs = (long)B * H * (W / S) * cdiv(Cin / 4, 64);
@@ -2067,7 +1903,7 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
   if (k == 1 && stride == 1 && Cout == PW_CO && lddx % 4 == 0 && (!act_src || ld_act % 4 == 0) &&
       (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(act_src) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
-    SkinnyBwdParams sp{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, 1, 0, 0};
+    SkinnyBwdParams sp{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, 1, 0, 0, po};
     const long jobs = (((long)B * H * W + PW_S - 1) / PW_S) * cdiv(Cin / 4, 64);
     pointwise32_dgrad_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(sp);
     return launch_status();
@@ -2078,6 +1914,7 @@ UNFLOW_API int unflow_conv2d_bwd_data(const float* dz, int lddz, const float* w,
   p.src = dz; p.w = w; p.bias = nullptr; p.dst = dx; p.act_src = act_src;
   p.lds = lddz; p.ldd = lddx; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
   p.leaky = 0; p.accumulate = accumulate;
+  p.pl = po;
   return run_gather<true>(p, workspace, workspace_bytes, st);
 }
 
@@ -2124,12 +1961,19 @@ UNFLOW_API int unflow_conv2d_bwd_filter(const float* x, int ldx, const float* dz
 UNFLOW_API int unflow_conv2d_transpose_fwd(const float* x, int ldx, const float* w, const float* bias, float* y,
                                            int ldy, int B, int H, int W, int Cin, int Cout, int leaky, void* workspace,
                                            size_t workspace_bytes, unflow_stream_t stream) {
+  return unflow_conv2d_transpose_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, leaky, igemm::PlaneOut{}, workspace,
+                                        workspace_bytes, stream);
+}
+
+int unflow_conv2d_transpose_fwd_po(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H,
+                                   int W, int Cin, int Cout, int leaky, const igemm::PlaneOut& po, void* workspace,
+                                   size_t workspace_bytes, unflow_stream_t stream) {
   if (!x || !w || !y) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
   if (Cin == 2 && Cout == 2) {
     if (leaky) return UNFLOW_ERR_UNSUPPORTED;
-    tiny_deconv_fwd_kernel<2, 2><<<stream_grid((long)B * 4 * H * W), 256, 0, st>>>(x, ldx, w, bias, y, ldy, B, H, W);
+    tiny_deconv_fwd_kernel<2, 2><<<stream_grid((long)B * 4 * H * W), 256, 0, st>>>(x, ldx, w, bias, y, ldy, B, H, W, po);
     return launch_status();
   }
   if (Cin % 4 != 0 || ldx % 4 != 0 || ldx < Cin || ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
@@ -2137,6 +1981,7 @@ UNFLOW_API int unflow_conv2d_transpose_fwd(const float* x, int ldx, const float*
   build_deconv_fwd(p, B, H, W, Cin, Cout);
   p.src = x; p.w = w; p.bias = bias; p.dst = y; p.act_src = nullptr;
   p.lds = ldx; p.ldd = ldy; p.leaky = leaky; p.accumulate = 0;
+  p.pl = po;
   return run_gather<true>(p, workspace, workspace_bytes, st);
 }
 
@@ -2144,6 +1989,14 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_data(const float* dz, int lddz, const
                                                 int H, int W, int Cin, int Cout, int accumulate, const float* act_src,
                                                 int ld_act, int act_lo, int act_hi, void* workspace,
                                                 size_t workspace_bytes, unflow_stream_t stream) {
+  return unflow_conv2d_transpose_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, accumulate, act_src, ld_act, act_lo,
+                                             act_hi, igemm::PlaneOut{}, workspace, workspace_bytes, stream);
+}
+
+int unflow_conv2d_transpose_bwd_data_po(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W,
+                                        int Cin, int Cout, int accumulate, const float* act_src, int ld_act, int act_lo,
+                                        int act_hi, const igemm::PlaneOut& po, void* workspace, size_t workspace_bytes,
+                                        unflow_stream_t stream) {
   if (!dz || !w || !dx) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
@@ -2158,6 +2011,7 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_data(const float* dz, int lddz, const
   p.src = dz; p.w = w; p.bias = nullptr; p.dst = dx; p.act_src = act_src;
   p.lds = lddz; p.ldd = lddx; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
   p.leaky = 0; p.accumulate = accumulate;
+  p.pl = po;
   return run_gather<false>(p, workspace, workspace_bytes, st);
 }
 

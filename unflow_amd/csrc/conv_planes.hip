@@ -1,0 +1,988 @@
+// conv / conv_transpose stacks of FlowNetC/S (src/e2eflow/core/flownet.py:89-237) as implicit GEMMs whose operands are
+// already 16-bit in HBM ("operand planes"):
+//
+//   n_planes == 3  bf16 hi / mid / lo with x = hi + mid + lo EXACTLY (3 x 8 significand bits): a*b is summed from the six
+//                  terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 with fp32 accumulation —
+//                  fp32-class accuracy (igemm_shared.h) at 6/16 of the matrix-core time of v_mfma_f32_32x32x2_f32;
+//   n_planes == 1  fp16 activations and weights, fp32 accumulation on v_mfma_f32_32x32x16_f16 (BASELINE configs[4]).
+//
+// The planes are written ONCE per element by whoever produces the tensor (the epilogues of these kernels, of the
+// flow-head / correlation / input kernels, and unflow_weight_planes for the parameters), so the K loops below contain no
+// conversion work at all: a 16-byte load is 8 consecutive channels of one plane = one MFMA operand granule; it goes
+// HBM/L2 -> register -> ds_write_b128 -> ds_read -> MFMA.  (conv_igemm.hip splits fp32 operands while staging them
+// instead: ~240 VALU instructions per thread and K tile, as much issue time as the 48 MFMAs they feed.)
+//
+//   igemm_pl_gather_kernel  conv fwd, conv dgrad (stride 2: 4 output-parity classes), deconv fwd, deconv dgrad:
+//        D[site, n] = sum_tap sum_c SRC[b, yg*sm + dy(tap), xg*sm + dx(tap), c] * W[tap][n][c]      (W: K-contiguous planes)
+//        LDS image per plane [row][32 k] bf16, 64-byte rows, 16-byte granules XOR-swizzled by bits 2..3 of the row:
+//        conflict-free ds_write_b128 / ds_read_b128 (the image of conv_igemm.hip's MATH == 1 path).
+//   igemm_pl_wgrad_kernel   filter gradients dW[(tap,a), b] = sum_site SRC[gather(site,tap), a] * DST[site, b]: both
+//        operands are site-major in HBM, so a tile is staged as [k = site][channel] rows (256 contiguous bytes per site)
+//        and the MFMA fragments (8 consecutive k of one channel) come out of LDS through ds_read_b64_tr_b16, the
+//        gfx950 transposing read (semantics probed in tools/microbench/probe_semantics.hip): no per-lane dword gathers.
+#include "igemm_shared.h"
+
+namespace {
+using namespace igemm;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int LDH = BK;   // 16-bit elements per LDS row of the gather image (64 bytes)
+
+struct PlGatherParams : GatherGeom {
+  const unsigned short* src;   // source planes, channel 0 of the consumed slice; [pixel][lds] per plane
+  long src_ps;                 // plane stride (elements)
+  const unsigned short* w;     // weight planes [tap][N][Cs] (K-contiguous)
+  long w_ps;
+  const float* bias;
+  float* dst;
+  float* partial;
+  const float* act_src;
+  int lds, ldd, ld_act, act_lo, act_hi;
+  int nsplit;
+  int leaky, accumulate;
+  PlaneOut pl;
+};
+
+template <int NPL, bool F16>
+__device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (&bv)[NPL], f32x16& acc, int t) {
+  if constexpr (F16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bv[0]), acc, 0, 0, 0);
+  } else if constexpr (NPL == 1) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[0]), __builtin_bit_cast(bf16x8, bv[0]), acc, 0, 0, 0);
+  } else {
+    constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ta[t]]), __builtin_bit_cast(bf16x8, bv[tb[t]]), acc,
+                                                  0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gather kernel
+// 256 threads = 4 waves.  Loads: thread (kq = tid & 3, r = tid >> 2) fetches granule kq (8 consecutive k) of rows r, r + 64
+// of each operand and plane: a wave instruction covers 16 rows x 64 contiguous bytes.  The loads of tile t+1 sit between
+// the MFMA groups of tile t (sched_barrier fences); single LDS stage, 3 blocks per CU resident and out of phase.
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_gather_kernel(const PlGatherParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "row passes of 64");
+  constexpr int A_PLANE = BM * LDH, B_PLANE = BN * LDH;
+  constexpr int AR = BM / 64, NB = BN / 64;
+  constexpr int NT = NPL == 3 ? 6 : 1;           // product terms per K16 slab
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* Ah = smem16;
+  unsigned short* Bh = Ah + NPL * A_PLANE;
+  int* pix = reinterpret_cast<int*>(Bh + NPL * B_PLANE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int cls_id = blockIdx.z % p.ncls, split = blockIdx.z / p.ncls;
+  const TapClass tc = p.cls[cls_id];
+  const int M = p.B * p.Hg * p.Wg;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ntaps = tc.nty * tc.ntx;
+  const int Cg = p.Cs >> 3;                      // granules per tap
+  const int Kg = ntaps * Cg;
+  const int KT = (Kg + 3) >> 2;
+  const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
+  const int kt0 = split * kt_per;
+  const int kt1 = min(KT, kt0 + kt_per);
+
+  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
+    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
+  }
+
+  const int kq = tid & 3;
+  const int lds2 = p.lds * 2;
+  int a_yx[AR], a_lin[AR];     // (y << 16 | x) of the site's source origin; byte offset of that pixel (or the OOB mark)
+#pragma unroll
+  for (int i = 0; i < AR; i++) {
+    const int m = m0 + (tid >> 2) + 64 * i;
+    if (m < M) {
+      const int xg = m % p.Wg, t = m / p.Wg;
+      const int yg = t % p.Hg, b = t / p.Hg;
+      const int y = yg * p.sm, x = xg * p.sm;
+      a_yx[i] = (y << 16) | x;
+      a_lin[i] = (b * p.Hs * p.Ws + y * p.Ws + x) * lds2;
+    } else {
+      a_yx[i] = 0;
+      a_lin[i] = OOB_MARK;   // rows past M: every load out of range (zeros)
+    }
+  }
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int v = -1;
+    if (m < M) {
+      const int xg = m % p.Wg, t = m / p.Wg;
+      const int yg = t % p.Hg, b = t / p.Hg;
+      v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
+    }
+    pix[tid] = v;
+  }
+  int b_row[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int n = n0 + (tid >> 2) + 64 * i;
+    b_row[i] = n < p.N ? n * p.Cs * 2 : OOB_MARK;
+  }
+
+  // K walker in granules: (tap, granule-in-tap) of the 16-byte column this thread loads, advanced by 4 per tile
+  const int adv_t = 4 / Cg, adv_c = 4 - adv_t * Cg;
+  const unsigned ntx_magic = (65536u + (unsigned)tc.ntx - 1u) / (unsigned)tc.ntx;  // exact for tap < 2^10
+  int q_tap, q_cg;
+  {
+    const unsigned q = (unsigned)kt0 * 4u + (unsigned)kq;
+    q_tap = (int)(q / (unsigned)Cg);
+    q_cg = (int)(q - (unsigned)q_tap * (unsigned)Cg);
+  }
+  bool live = kt0 < kt1;
+
+  u32x4 ra[AR][NPL], rb[NB][NPL];
+  int dy, dx, a_tile, w_tile;
+
+  auto piece_begin = [&]() {
+    const int ty = (int)(((unsigned)q_tap * ntx_magic) >> 16), tx = q_tap - ty * tc.ntx;
+    const bool kvalid = live && q_tap < ntaps;
+    dy = tc.dy0 + ty * p.dstep;
+    dx = tc.dx0 + tx * p.dstep;
+    const int cofs = q_cg * 16;
+    a_tile = kvalid ? (dy * p.Ws + dx) * lds2 + cofs : OOB_MARK;
+    const int widx = (tc.ky0 + ty * p.kstep) * p.KW + tc.kx0 + tx * p.kstep;
+    w_tile = kvalid ? widx * p.N * p.Cs * 2 + cofs : OOB_MARK;
+  };
+  auto piece_a = [&](int i) {
+    const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
+    const bool inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+    const int voff = inb ? a_lin[i] + a_tile : OOB_MARK;
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
+  };
+  auto piece_b = [&](int i) {
+    const int voff = b_row[i] + w_tile;
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
+  };
+  auto piece_end = [&]() {
+    q_cg += adv_c;
+    q_tap += adv_t;
+    const bool wrap = q_cg >= Cg;
+    q_cg -= wrap ? Cg : 0;
+    q_tap += wrap ? 1 : 0;
+  };
+  constexpr int NPIECE = AR + NB + 2;
+  auto piece = [&](int step) {
+    if (step == 0) piece_begin();
+    if (step >= 1 && step <= AR) piece_a(step - 1);
+    if (step > AR && step <= AR + NB) piece_b(step - AR - 1);
+    if (step == AR + NB + 1) piece_end();
+  };
+  auto swz = [](int row, int g) { return row * LDH + 8 * (g ^ ((row >> 2) & 3)); };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; i++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        *reinterpret_cast<u32x4*>(Ah + pl * A_PLANE + swz((tid >> 2) + 64 * i, kq)) = ra[i][pl];
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        *reinterpret_cast<u32x4*>(Bh + pl * B_PLANE + swz((tid >> 2) + 64 * i, kq)) = rb[i][pl];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int st = 0; st < NPIECE; st++) piece(st);
+  store_tile();
+  __syncthreads();
+  const unsigned short* ah_rd = Ah + (wm * WM + l31) * LDH;
+  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
+  const int gsw = lh ^ ((l31 >> 2) & 3);     // swizzled granule of K16 slab 0 (slab 1: ^ 2); tile bases are multiples of 32
+  constexpr int NGROUP = 2 * TM * NT;        // MFMA groups per tile between which the load pieces are placed
+  constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
+
+  for (int kt = kt0; kt < kt1; kt++) {
+    live = kt + 1 < kt1;
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++) {
+      // B fragments of the slab stay live; A fragments are read per 32-row sub-tile (keeps the 128x128 kernel at 3 waves/SIMD)
+      s16x8 bv[TN][NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          bv[j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        s16x8 av[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+          av[pl] = *reinterpret_cast<const s16x8*>(ah_rd + pl * A_PLANE + i * 32 * LDH + 8 * (gsw ^ (2 * slab)));
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t);
+#pragma unroll
+          for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t) * PPG + q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading this tile
+    store_tile();     // (last iteration: zeros, never read)
+    __syncthreads();
+  }
+
+  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool to_partial = p.nsplit > 1;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int px = pix[row];
+      if (px < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        if (to_partial) {
+          p.partial[((size_t)split * ((size_t)p.B * p.Hd * p.Wd) + px) * p.N + n] = v;
+        } else {
+          if (p.bias) v += p.bias[n];
+          if (p.leaky) v = leaky_relu(v);
+          float* d = p.dst + (size_t)px * p.ldd + n;
+          if (p.accumulate) v += *d;
+          if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
+          *d = v;
+          store_planes(p.pl, (size_t)px, n, v);
+        }
+      }
+    }
+}
+
+// Fixed-order sum of the split-K partials + the epilogue (+ the output planes).  One float4 per thread.
+__global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec) {
+  const size_t npix = (size_t)p.B * p.Hd * p.Wd;
+  const size_t total = npix * p.N;
+  if (vec) {
+    const unsigned nq = (unsigned)(p.N >> 2);
+    const size_t totq = total >> 2;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < totq; q += (size_t)gridDim.x * blockDim.x) {
+      const size_t px = q / nq;
+      const int n = (int)(q - px * nq) * 4;
+      const float4* src = reinterpret_cast<const float4*>(p.partial) + q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int s = 0; s < p.nsplit; s++) {
+        const float4 t = src[(size_t)s * totq];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
+      if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
+      float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
+      if (p.accumulate) {
+        const float4 e = *d;
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+      }
+      if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
+        const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
+        if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
+        if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
+        if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
+        if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
+      }
+      *d = v;
+      store_planes4(p.pl, px, n, v);
+    }
+    return;
+  }
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = e / p.N;
+    const int n = (int)(e - px * p.N);
+    float v = 0.f;
+    for (int s = 0; s < p.nsplit; s++) v += p.partial[(size_t)s * total + e];
+    if (p.bias) v += p.bias[n];
+    if (p.leaky) v = leaky_relu(v);
+    float* d = p.dst + px * p.ldd + n;
+    if (p.accumulate) v += *d;
+    if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[px * p.ld_act + n]);
+    *d = v;
+    store_planes(p.pl, px, n, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filter gradient
+struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multiple of 8); Cb: columns of dW
+  const unsigned short* src;   // gathered operand planes [B,Hs,Ws,lds]
+  long src_ps;
+  const unsigned short* dst;   // dense operand planes [B,Hg,Wg,ldd]
+  long dst_ps;
+  float* out;                  // dW [(tap, a < Ca_out)][b < Cb]
+  float* partial;              // [nsplit][taps*Ca_out][Cb]
+  int lds, ldd;
+  int Ca_out;                  // rows per tap of dW (the weight tensor's own channel padding, <= Ca)
+  int nsplit;
+  unsigned cag_magic;          // ceil(2^32 / (Ca/8))
+};
+
+// LDS image of one operand plane: [k = 32 sites][ROWS channels], rows of ROWS*2 bytes; 32-byte pairs of granules
+// XOR-swizzled by the row so that the 8 (row, pair) segments one half-wave's ds_read_b64_tr_b16 touches are distinct
+// 32-byte slots of a 256-byte bank row.
+template <int ROWS>
+__device__ __forceinline__ int tr_swz(int k, int granule) {
+  const int pair = granule >> 1;
+  const int sw = ROWS == 128 ? ((k & 3) << 1) : (((k >> 1) & 1) << 1);   // 256-byte rows: 4 rows differ; 128-byte: 2 per bank row
+  return k * ROWS + (((pair ^ sw) << 1) | (granule & 1)) * 8;
+}
+
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_wgrad_kernel(const PlWgradParams p) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "swizzle forms");
+  constexpr int A_PLANE = BK * BM, B_PLANE = BK * BN;
+  constexpr int AJ = BM / 8, BJ = BN / 8;        // granules per k row
+  constexpr int AKS = 256 / AJ, BKS = 256 / BJ;  // k rows per pass
+  constexpr int AR = BK / AKS, BR = BK / BKS;    // passes
+  constexpr int NT = NPL == 3 ? 6 : 1;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* Ah = smem16;
+  unsigned short* Bh = Ah + NPL * A_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int taps = p.KH * p.KW;
+  const int Cag = p.Ca >> 3;
+  const int Mg = taps * Cag;                     // row granules of the (padded) problem
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int S = p.B * p.Hg * p.Wg;               // reduction length (sites)
+  const int KT = (S + BK - 1) / BK;
+  const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
+  const int kt0 = blockIdx.z * kt_per, kt1 = min(KT, kt0 + kt_per);
+
+  __amdgpu_buffer_rsrc_t src_rs[NPL], dst_rs[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Ca) * 2);
+    dst_rs[pl] = make_rsrc(p.dst + pl * p.dst_ps, (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
+  }
+
+  // gathered operand: this thread's row granule (tap, 8 channels) — fixed
+  const int aj = tid % AJ, ak = tid / AJ;
+  const int mg = (m0 >> 3) + aj;
+  const bool m_ok = mg < Mg;
+  const unsigned tap = fast_div((unsigned)mg, p.cag_magic);
+  const int ag = mg - (int)tap * Cag;
+  const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
+  const int dy = p.dy0 + ky, dx = p.dx0 + kx;
+  const int lds2 = p.lds * 2;
+  const int a_lane_off = (dy * p.Ws + dx) * lds2 + ag * 16;   // may be negative; added to the site's base offset
+  // dense operand: this thread's column granule
+  const int bj = tid % BJ, bk = tid / BJ;
+  const int nbq = (n0 >> 3) + bj;
+  const bool b_ok = nbq * 8 < p.Cb;
+  const int b_lane_off = nbq * 16;
+  const int ldd2 = p.ldd * 2;
+  const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
+
+  u32x4 ra[AR][NPL], rb[BR][NPL];
+  auto piece_a = [&](int i, int kt) {
+    const unsigned sidx = (unsigned)(kt * BK + ak + AKS * i);
+    const unsigned q = fast_div(sidx, magW);
+    const int xg = (int)(sidx - q * (unsigned)p.Wg);
+    const unsigned bb = fast_div(q, magH);
+    const int yg = (int)(q - bb * (unsigned)p.Hg);
+    const int yb = yg * p.sm, xb = xg * p.sm;
+    const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
+    const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
+  };
+  auto piece_b = [&](int i, int kt) {
+    const int sidx = kt * BK + bk + BKS * i;
+    const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(dst_rs[pl], voff);
+  };
+  constexpr int NPIECE = AR + BR;
+  auto piece = [&](int step, int kt) {
+    if (step < AR) piece_a(step, kt);
+    else if (step < AR + BR) piece_b(step - AR, kt);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; i++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        *reinterpret_cast<u32x4*>(Ah + pl * A_PLANE + tr_swz<BM>(ak + AKS * i, aj)) = ra[i][pl];
+#pragma unroll
+    for (int i = 0; i < BR; i++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        *reinterpret_cast<u32x4*>(Bh + pl * B_PLANE + tr_swz<BN>(bk + BKS * i, bj)) = rb[i][pl];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // transposing reads: within a 16-lane group, lane i16 supplies the address of 4 consecutive channels (i16 & 3) of k row
+  // (i16 >> 2) and receives channel i16 of those 4 k rows.  Lane l: group = l >> 4 -> channels 16*(group & 1).., k half
+  // group >> 1 (the MFMA's lane >> 5).
+  const int i16 = lane & 15, grp = lane >> 4, lh = grp >> 1;
+  const int krow = 8 * lh + (i16 >> 2);     // + 16*slab + 4*half at read time (multiples of 4: the swizzle term is unchanged)
+  int a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const int c = wm * WM + i * 32 + 16 * (grp & 1) + 4 * (i16 & 3);    // first of the 4 channels this lane addresses
+    a_rd[i] = tr_swz<BM>(krow, c >> 3) + (c & 7);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int c = wn * WN + j * 32 + 16 * (grp & 1) + 4 * (i16 & 3);
+    b_rd[j] = tr_swz<BN>(krow, c >> 3) + (c & 7);
+  }
+#pragma unroll
+  for (int st = 0; st < NPIECE; st++) piece(st, kt0);
+  store_tile();
+  __syncthreads();
+  constexpr int NGROUP = 2 * NT;
+  constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
+  const int l31 = lane & 31;
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;   // past the last tile: every load is out of range (zeros)
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++) {
+      s16x8 av[TM][NPL], bv[TN][NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          const unsigned short* b0 = Ah + pl * A_PLANE + a_rd[i] + (16 * slab) * BM;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BM));
+          av[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const unsigned short* b0 = Bh + pl * B_PLANE + b_rd[j] + (16 * slab) * BN;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BN));
+          bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], t);
+#pragma unroll
+        for (int q = 0; q < PPG; q++) piece((slab * NT + t) * PPG + q, ktn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+  }
+
+  float* o = p.nsplit > 1 ? p.partial + (size_t)blockIdx.z * taps * p.Ca_out * p.Cb : p.out;
+  const int lh5 = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh5;
+      const int mgr = m >> 3;
+      if (mgr >= Mg) continue;
+      const unsigned tp = fast_div((unsigned)mgr, p.cag_magic);
+      const int a = (mgr - (int)tp * Cag) * 8 + (m & 7);
+      if (a >= p.Ca_out) continue;
+      float* orow = o + ((size_t)tp * p.Ca_out + a) * p.Cb;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n < p.Cb) orow[n] = acc[i][j][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ plane producers
+// fp32 [npix][ldx] (C channels used) -> planes [npix][ldp] with channels C .. Cp-1 zero-filled (Cp = round-up-8 of C, <= ldp)
+__global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, long npix, int C, PlaneOut o) {
+  const int Cp = (C + 7) & ~7;
+  const int nq = Cp >> 2;
+  const long total = npix * nq;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long px = e / nq;
+    const int n = (int)(e - px * nq) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* s = x + px * ldx + n;
+    if (n < C) v.x = s[0];
+    if (n + 1 < C) v.y = s[1];
+    if (n + 2 < C) v.z = s[2];
+    if (n + 3 < C) v.w = s[3];
+    store_planes4(o, (size_t)px, n, v);
+  }
+}
+
+// Weight planes of one tensor W[taps][R][Cc] (fp32):
+//   direct     D[p][tap][R][Cc8]   (K = Cc contiguous; Cc8 = round-up-8(Cc), zero padded)
+//   transposed T[p][tap][Cc][R8]   (K = R contiguous)
+// One launch covers a table of tensors (all layers of a network): block -> (tensor, tap, 64 x 64 tile).
+struct WPlaneDesc {
+  const float* w;
+  unsigned short* direct;
+  unsigned short* transposed;
+  int taps, R, Cc;
+  int tiles_r, tiles_c;
+  int block0;
+};
+constexpr int MAX_WDESC = 64;
+struct WPlaneBatch {
+  WPlaneDesc d[MAX_WDESC];
+  int n, n_planes;
+};
+
+__device__ __forceinline__ void put_planes(unsigned short* base, long ps, int n_planes, size_t idx, float v) {
+  if (n_planes == 1) {
+    base[idx] = to_f16_bits(v);
+  } else {
+    unsigned short h, m, l;
+    split3(v, h, m, l);
+    base[idx] = h;
+    base[idx + ps] = m;
+    base[idx + 2 * ps] = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b) {
+  __shared__ float tile[64][65];
+  int di = 0;
+  while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].block0) di++;
+  const WPlaneDesc d = b.d[di];
+  int lb = blockIdx.x - d.block0;
+  const int tc = lb % d.tiles_c; lb /= d.tiles_c;
+  const int tr = lb % d.tiles_r; lb /= d.tiles_r;
+  const int tap = lb;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int Cc8 = (d.Cc + 7) & ~7, R8 = (d.R + 7) & ~7;
+  const float* w = d.w + (size_t)tap * d.R * d.Cc;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    tile[r][c] = (r0 + r < d.R && c0 + c < d.Cc) ? w[(size_t)(r0 + r) * d.Cc + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  if (d.direct) {
+    const long ps = (long)d.taps * d.R * Cc8;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      if (r0 + r < d.R && c0 + c < Cc8) put_planes(d.direct, ps, b.n_planes, ((size_t)tap * d.R + r0 + r) * Cc8 + c0 + c, tile[r][c]);
+    }
+  }
+  if (d.transposed) {
+    const long ps = (long)d.taps * d.Cc * R8;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int c = e >> 6, r = e & 63;
+      if (c0 + c < d.Cc && r0 + r < R8) put_planes(d.transposed, ps, b.n_planes, ((size_t)tap * d.Cc + c0 + c) * R8 + r0 + r, tile[r][c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct PlPlan {
+  int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
+  int nsplit;
+};
+
+inline int pl_smem_gather(int bm, int bn, int npl) { return npl * (bm + bn) * LDH * 2 + bm * 4; }
+
+// blocks per CU by LDS (160 KB) and registers (<= 168: 3 waves per SIMD)
+inline int pl_blocks_per_cu(int bm, int bn, int npl) {
+  const int byl = (160 * 1024) / pl_smem_gather(bm, bn, npl);
+  const int byr = bm == 128 && bn == 128 ? 3 : bm == 128 ? 4 : 6;
+  return byl < byr ? byl : byr;
+}
+
+inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
+  PlPlan pl;
+  const long M = (long)p.B * p.Hg * p.Wg;
+  if (p.N <= 32) pl.cfg = 2;
+  else if (p.N <= 64) pl.cfg = 1;
+  else pl.cfg = 0;
+  int maxtaps = 0;
+  for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
+  const int KT = (maxtaps * (p.Cs >> 3) + 3) >> 2;
+  static const int min_kt = getenv("UNFLOW_GATHER_MIN_KT") ? max(1, atoi(getenv("UNFLOW_GATHER_MIN_KT"))) : 8;   // tuning knob
+  const int max_by_k = min(16, KT / min_kt > 0 ? KT / min_kt : 1);
+  if (pl.cfg == 0) {
+    const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
+    if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
+  }
+  const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
+  const int slots = 256 * pl_blocks_per_cu(bm, bn, npl);
+  const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
+  pl.nsplit = fill_one_round(blocks, slots, max_by_k);
+  return pl;
+}
+
+inline size_t pl_gather_partial_bytes(const GatherGeom& p, int nsplit) {
+  return nsplit > 1 ? (size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
+  const int M = p.B * p.Hg * p.Wg;
+  const int smem = pl_smem_gather(BM, BN, NPL);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)attr;
+  dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
+  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(p);
+  return launch_status();
+}
+
+template <int NPL, bool F16>
+int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch_pl_gather<128, 128, 64, 64, NPL, F16>(p, st);
+    case 1: return launch_pl_gather<128, 64, 64, 32, NPL, F16>(p, st);
+    default: return launch_pl_gather<64, 64, 32, 32, NPL, F16>(p, st);
+  }
+}
+
+int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStream_t st) {
+  const PlPlan pl = plan_pl_gather(p, npl);
+  p.nsplit = pl.nsplit;
+  p.partial = nullptr;
+  if (p.nsplit > 1) {
+    if (!ws || ws_bytes < pl_gather_partial_bytes(p, p.nsplit)) p.nsplit = 1;  // no scratch: un-split (same result up to fp32 order)
+    else p.partial = reinterpret_cast<float*>(ws);
+  }
+  const int code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
+  if (code != UNFLOW_OK) return code;
+  if (p.nsplit > 1) {
+    const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
+                         reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0);
+    const bool vec = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0 &&
+                     (!p.pl.n_planes || p.pl.ld % 4 == 0);
+    pl_splitk_reduce_epilogue_kernel<<<stream_grid((long)(vec ? total / 4 : total)), 256, 0, st>>>(p, vec ? 1 : 0);
+    return launch_status();
+  }
+  return UNFLOW_OK;
+}
+
+inline int pl_wgrad_cfg(const WgradGeom& p) { return p.Cb <= 64 ? 1 : 0; }   // 0: 128x128, 1: 128x64
+
+inline int plan_pl_wgrad(const WgradGeom& p, int npl) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int cfg = pl_wgrad_cfg(p);
+  const int bn = cfg == 1 ? 64 : 128;
+  const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
+  const long S = (long)p.B * p.Hg * p.Wg;
+  const int KT = (int)((S + BK - 1) / BK);
+  static const int min_kt = getenv("UNFLOW_WGRAD_MIN_KT") ? max(1, atoi(getenv("UNFLOW_WGRAD_MIN_KT"))) : 8;     // tuning knob
+  const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
+  const int per_cu = min((160 * 1024) / (npl * (128 + bn) * BK * 2), cfg == 1 ? 4 : 3);
+  return fill_one_round(blocks, 256 * per_cu, max_by_k);
+}
+
+inline size_t pl_wgrad_partial_bytes(const WgradGeom& p, int ca_out, int nsplit) {
+  const size_t n = (size_t)p.KH * p.KW * ca_out * p.Cb;
+  return nsplit > 1 ? (size_t)nsplit * n * sizeof(float) + reduce_scratch_bytes(n, nsplit) : 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int smem = NPL * (BM + BN) * BK * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)attr;
+  dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
+  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(p);
+  return launch_status();
+}
+
+int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
+  p.cag_magic = magic_u32((unsigned)(p.Ca >> 3));
+  const size_t wsize = (size_t)p.KH * p.KW * p.Ca_out * p.Cb;
+  int ns = plan_pl_wgrad(p, npl);
+  if (ns > 1 && (!ws || ws_bytes < pl_wgrad_partial_bytes(p, p.Ca_out, ns))) {
+    ns = ws ? (int)min((size_t)REDUCE_FAN, ws_bytes / (wsize * sizeof(float))) : 1;
+    if (ns < 1) ns = 1;
+  }
+  p.nsplit = ns;
+  p.partial = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
+  *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
+  const int cfg = pl_wgrad_cfg(p);
+  int code;
+  if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
+  else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
+  if (code != UNFLOW_OK) return code;
+  if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);
+  return UNFLOW_OK;
+}
+
+inline bool planes_ok(const unflow_planes* t, int channels) {
+  return t && t->base && (t->n_planes == 1 || t->n_planes == 3) && t->ld % 4 == 0 && t->ld >= ((channels + 7) & ~7) &&
+         (reinterpret_cast<uintptr_t>(t->base) & 7) == 0;
+}
+
+inline PlaneOut plane_out(const unflow_planes* t, int lo, int hi) {
+  PlaneOut o{};
+  if (t && t->base && t->n_planes) {
+    o.base = reinterpret_cast<unsigned short*>(t->base);
+    o.plane_stride = t->plane_stride;
+    o.ld = t->ld;
+    o.lo = lo;
+    o.hi = hi;
+    o.n_planes = t->n_planes;
+  }
+  return o;
+}
+
+}  // namespace
+
+// The fp32-operand kernels of conv_igemm.hip, used by the *_pl entry points for the shapes the plane kernels do not take
+// (Cout <= 4 flow heads, 2 -> 2 deconvs, 1x1 x 32 data gradient): same arithmetic as the plain entry points, plus the
+// optional output planes.
+int unflow_conv2d_fwd_po(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int leaky, const igemm::PlaneOut& po, void* workspace,
+                         size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_bwd_data_po(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W, int Cin,
+                              int Cout, int k, int stride, int accumulate, const float* act_src, int ld_act, int act_lo,
+                              int act_hi, const igemm::PlaneOut& po, void* workspace, size_t workspace_bytes,
+                              unflow_stream_t stream);
+int unflow_conv2d_transpose_fwd_po(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H,
+                                   int W, int Cin, int Cout, int leaky, const igemm::PlaneOut& po, void* workspace,
+                                   size_t workspace_bytes, unflow_stream_t stream);
+int unflow_conv2d_transpose_bwd_data_po(const float* dz, int lddz, const float* w, float* dx, int lddx, int B, int H, int W,
+                                        int Cin, int Cout, int accumulate, const float* act_src, int ld_act, int act_lo,
+                                        int act_hi, const igemm::PlaneOut& po, void* workspace, size_t workspace_bytes,
+                                        unflow_stream_t stream);
+
+// ===================================================================== C ABI
+UNFLOW_API int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, const unflow_planes* out,
+                                      unflow_stream_t stream) {
+  if (!x || !out || !out->base) return UNFLOW_ERR_NULL;
+  if (npix <= 0 || C <= 0) return UNFLOW_OK;
+  if (!planes_ok(out, C) || ldx < C) return UNFLOW_ERR_UNSUPPORTED;
+  const int Cp = (C + 7) & ~7;
+  planes_from_f32_kernel<<<stream_grid(npix * (Cp / 4)), 256, 0, as_stream(stream)>>>(x, ldx, npix, C, plane_out(out, 0, Cp));
+  return launch_status();
+}
+
+UNFLOW_API size_t unflow_weight_planes_elems(int taps, int R, int Cc, int transposed) {
+  return transposed ? (size_t)taps * Cc * ((R + 7) & ~7) : (size_t)taps * R * ((Cc + 7) & ~7);
+}
+
+UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const int* taps, const int* R, const int* Cc,
+                                            void* const* direct, void* const* transposed, int n_planes,
+                                            unflow_stream_t stream) {
+  if (!w || !taps || !R || !Cc || !direct || !transposed) return UNFLOW_ERR_NULL;
+  if (n_planes != 1 && n_planes != 3) return UNFLOW_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  for (int i0 = 0; i0 < n; i0 += MAX_WDESC) {
+    WPlaneBatch b{};
+    b.n = min(n - i0, MAX_WDESC);
+    b.n_planes = n_planes;
+    int blocks = 0;
+    for (int i = 0; i < b.n; i++) {
+      WPlaneDesc& d = b.d[i];
+      if (!w[i0 + i] || taps[i0 + i] <= 0 || R[i0 + i] <= 0 || Cc[i0 + i] <= 0) return UNFLOW_ERR_SHAPE;
+      d.w = w[i0 + i];
+      d.direct = reinterpret_cast<unsigned short*>(direct[i0 + i]);
+      d.transposed = reinterpret_cast<unsigned short*>(transposed[i0 + i]);
+      d.taps = taps[i0 + i]; d.R = R[i0 + i]; d.Cc = Cc[i0 + i];
+      d.tiles_r = cdiv((d.R + 7) & ~7, 64);
+      d.tiles_c = cdiv((d.Cc + 7) & ~7, 64);
+      d.block0 = blocks;
+      blocks += d.taps * d.tiles_r * d.tiles_c;
+    }
+    if (blocks > 0) weight_planes_kernel<<<blocks, 256, 0, st>>>(b);
+  }
+  return launch_status();
+}
+
+UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes) {
+  // Exact requirement of the *_pl entry points of a conv2d with these dims (and, for k == 4 && stride == 2, of the
+  // conv2d_transpose whose OUTPUT is [B,H,W,Cout]); Cin / Cout as passed to those entry points.
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return 0;
+  size_t need = unflow_conv_workspace_bytes(B, H, W, (Cin + 3) & ~3, Cout, k, stride);     // fp32-operand fallbacks
+  if (Cout <= 4 || (n_planes != 1 && n_planes != 3)) return need;
+  const int Ci8 = (Cin + 7) & ~7, Co8 = (Cout + 7) & ~7;
+  GatherGeom g{};
+  build_conv_fwd(g, B, H, W, Ci8, Cout, k, stride);
+  need = max(need, pl_gather_partial_bytes(g, plan_pl_gather(g, n_planes).nsplit));
+  GatherGeom d{};
+  if ((stride == 1 || stride == 2) && build_conv_dgrad(d, B, H, W, Cin, Co8, k, stride) == UNFLOW_OK)
+    need = max(need, pl_gather_partial_bytes(d, plan_pl_gather(d, n_planes).nsplit));
+  WgradGeom wg{};
+  build_conv_wgrad(wg, B, H, W, Ci8, Cout, k, stride);
+  need = max(need, pl_wgrad_partial_bytes(wg, Cin, plan_pl_wgrad(wg, n_planes)));
+  if (k == 4 && stride == 2 && H % 2 == 0 && W % 2 == 0) {
+    GatherGeom tf{};
+    build_deconv_fwd(tf, B, H / 2, W / 2, Ci8, Cout);
+    need = max(need, pl_gather_partial_bytes(tf, plan_pl_gather(tf, n_planes).nsplit));
+    GatherGeom td{};
+    build_deconv_dgrad(td, B, H / 2, W / 2, Cin, Co8);
+    need = max(need, pl_gather_partial_bytes(td, plan_pl_gather(td, n_planes).nsplit));
+    WgradGeom tw{};
+    build_deconv_wgrad(tw, B, H / 2, W / 2, Cin, Co8);
+    need = max(need, pl_wgrad_partial_bytes(tw, Cout, plan_pl_wgrad(tw, n_planes)));
+  }
+  return need + 1024;
+}
+
+static bool use_planes(const unflow_planes* a, int ca, const unflow_planes* b, int cb, int Cout_or_n) {
+  return Cout_or_n > 4 && planes_ok(a, ca) && planes_ok(b, cb) && a->n_planes == b->n_planes;
+}
+
+UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* w,
+                                    const unflow_planes* w_pl, const float* bias, float* y, int ldy,
+                                    const unflow_planes* y_pl, int B, int H, int W, int Cin, int Cout, int k, int stride,
+                                    int leaky, void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
+  if (!y || (!x && !x_pl)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
+  const int Ci8 = (Cin + 7) & ~7;
+  if (!use_planes(x_pl, Cin, w_pl, Cin, Cout) || w_pl->ld != Ci8)
+    return unflow_conv2d_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, k, stride, leaky, plane_out(y_pl, 0, Cout), workspace,
+                                workspace_bytes, stream);
+  if (ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  PlGatherParams p{};
+  build_conv_fwd(p, B, H, W, Ci8, Cout, k, stride);
+  p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
+  p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.bias = bias; p.dst = y; p.ldd = ldy; p.act_src = nullptr; p.leaky = leaky; p.accumulate = 0;
+  p.pl = plane_out(y_pl, 0, Cout);
+  return run_pl_gather(p, x_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
+}
+
+UNFLOW_API int unflow_conv2d_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
+                                         const unflow_planes* w_pl, float* dx, int lddx, const unflow_planes* dx_pl,
+                                         int pl_lo, int pl_hi, int B, int H, int W, int Cin, int Cout, int k, int stride,
+                                         int accumulate, const float* act_src, int ld_act, int act_lo, int act_hi,
+                                         void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
+  if (!dx || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || (stride != 1 && stride != 2)) return UNFLOW_ERR_SHAPE;
+  const int Co8 = (Cout + 7) & ~7;
+  const bool pointwise32 = k == 1 && stride == 1 && Cout == 32;      // conv_redir: the streaming kernel of conv_igemm.hip
+  if (pointwise32 || !use_planes(dz_pl, Cout, w_pl, Cout, Cout) || w_pl->ld != Co8)
+    return unflow_conv2d_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, k, stride, accumulate, act_src, ld_act, act_lo,
+                                     act_hi, plane_out(dx_pl, pl_lo, pl_hi), workspace, workspace_bytes, stream);
+  if (lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
+  PlGatherParams p{};
+  const int bc = build_conv_dgrad(p, B, H, W, Cin, Co8, k, stride);
+  if (bc != UNFLOW_OK) return bc;
+  p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
+  p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_src = act_src; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
+  p.leaky = 0; p.accumulate = accumulate;
+  p.pl = plane_out(dx_pl, pl_lo, pl_hi);
+  return run_pl_gather(p, dz_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
+}
+
+UNFLOW_API int unflow_conv2d_bwd_filter_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* dz, int lddz,
+                                           const unflow_planes* dz_pl, float* dw, int B, int H, int W, int Cin, int Cout,
+                                           int k, int stride, void* workspace, size_t workspace_bytes,
+                                           unflow_stream_t stream) {
+  if (!dw || (!x && !x_pl) || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
+  if (!use_planes(x_pl, Cin, dz_pl, Cout, Cout) || Cout % 4 != 0)
+    return unflow_conv2d_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, stream);
+  PlWgradParams p{};
+  build_conv_wgrad(p, B, H, W, (Cin + 7) & ~7, Cout, k, stride);
+  p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
+  p.dst = reinterpret_cast<const unsigned short*>(dz_pl->base); p.dst_ps = dz_pl->plane_stride; p.ldd = dz_pl->ld;
+  p.out = dw; p.Ca_out = Cin;
+  size_t used = 0;
+  return run_pl_wgrad(p, x_pl->n_planes, workspace, workspace_bytes, &used, as_stream(stream));
+}
+
+UNFLOW_API int unflow_conv2d_transpose_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* w,
+                                              const unflow_planes* w_pl, const float* bias, float* y, int ldy,
+                                              const unflow_planes* y_pl, int B, int H, int W, int Cin, int Cout, int leaky,
+                                              void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
+  if (!y || (!x && !x_pl)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
+  const int Ci8 = (Cin + 7) & ~7;
+  if (!use_planes(x_pl, Cin, w_pl, Cin, Cout) || w_pl->ld != Ci8)
+    return unflow_conv2d_transpose_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, leaky, plane_out(y_pl, 0, Cout), workspace,
+                                          workspace_bytes, stream);
+  if (ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  PlGatherParams p{};
+  build_deconv_fwd(p, B, H, W, Ci8, Cout);
+  p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
+  p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.bias = bias; p.dst = y; p.ldd = ldy; p.act_src = nullptr; p.leaky = leaky; p.accumulate = 0;
+  p.pl = plane_out(y_pl, 0, Cout);
+  return run_pl_gather(p, x_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
+}
+
+UNFLOW_API int unflow_conv2d_transpose_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
+                                                   const unflow_planes* w_pl, float* dx, int lddx,
+                                                   const unflow_planes* dx_pl, int pl_lo, int pl_hi, int B, int H, int W,
+                                                   int Cin, int Cout, int accumulate, const float* act_src, int ld_act,
+                                                   int act_lo, int act_hi, void* workspace, size_t workspace_bytes,
+                                                   unflow_stream_t stream) {
+  if (!dx || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
+  const int Co8 = (Cout + 7) & ~7;
+  if (!use_planes(dz_pl, Cout, w_pl, Cout, Cout) || w_pl->ld != Co8 || Cin <= 4)
+    return unflow_conv2d_transpose_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, accumulate, act_src, ld_act, act_lo,
+                                               act_hi, plane_out(dx_pl, pl_lo, pl_hi), workspace, workspace_bytes, stream);
+  if (lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
+  PlGatherParams p{};
+  build_deconv_dgrad(p, B, H, W, Cin, Co8);
+  p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
+  p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_src = act_src; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
+  p.leaky = 0; p.accumulate = accumulate;
+  p.pl = plane_out(dx_pl, pl_lo, pl_hi);
+  return run_pl_gather(p, dz_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
+}
+
+UNFLOW_API int unflow_conv2d_transpose_bwd_filter_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* dz,
+                                                     int lddz, const unflow_planes* dz_pl, float* dw, int B, int H, int W,
+                                                     int Cin, int Cout, void* workspace, size_t workspace_bytes,
+                                                     unflow_stream_t stream) {
+  if (!dw || (!x && !x_pl) || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
+  if (!use_planes(x_pl, Cin, dz_pl, Cout, Cout) || Cin % 4 != 0 || Cin <= 4)
+    return unflow_conv2d_transpose_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, workspace, workspace_bytes, stream);
+  // dW[ky,kx,co,ci]: gathered operand = dz (rows (tap, co)), dense operand = x (columns ci)
+  PlWgradParams p{};
+  build_deconv_wgrad(p, B, H, W, Cin, (Cout + 7) & ~7);
+  p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
+  p.dst = reinterpret_cast<const unsigned short*>(x_pl->base); p.dst_ps = x_pl->plane_stride; p.ldd = x_pl->ld;
+  p.out = dw; p.Ca_out = Cout;
+  size_t used = 0;
+  return run_pl_wgrad(p, x_pl->n_planes, workspace, workspace_bytes, &used, as_stream(stream));
+}

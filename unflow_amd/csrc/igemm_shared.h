@@ -1,0 +1,301 @@
+// Geometry, planning and reduction helpers shared by the implicit-GEMM conv kernels: conv_igemm.hip (fp32 operands from
+// HBM: fp32 MFMA, or the 3-way bf16 split done while staging) and conv_planes.hip (operands pre-split into 16-bit planes).
+// Layer geometry follows slim.conv2d / conv2d_transpose with TF 'SAME' padding (src/e2eflow/core/flownet.py:89-237).
+#pragma once
+#include <stdlib.h>
+#include <cstdint>
+#include <cstring>
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace igemm {
+
+constexpr int BK = 32;
+
+struct TapClass {
+  int nty, ntx;  // taps of this class
+  int dy0, dx0;  // source offset of tap (0,0); tap (ty,tx) -> dy0 + ty*dstep
+  int ky0, kx0;  // weight index of tap (0,0);  -> ky0 + ty*kstep
+  int py, px;    // destination parity offset
+};
+
+// D[site, n] = sum_tap sum_c SRC[b, yg*sm + dy(tap), xg*sm + dx(tap), c] * W(tap, c, n): sites = a regular grid
+// [B,Hg,Wg] written to destination pixel (yg*so + py, xg*so + px) of [B,Hd,Wd]; up to 4 output-parity classes.
+struct GatherGeom {
+  int B, Hg, Wg, Hs, Ws, sm;
+  int dstep, kstep, KW;
+  int Cs, N;
+  int Hd, Wd, so;
+  int ncls;
+  int wtaps;  // taps of the whole weight tensor (KH*KW)
+  TapClass cls[4];
+};
+
+// dW[(tap,a), b] = sum_site SRC[gather(site, tap), a] * DST[site, b]
+struct WgradGeom {
+  int B, Hg, Wg, Hs, Ws, sm;
+  int KH, KW, dy0, dx0;  // tap (ky,kx) -> offset dy0 + ky
+  int Ca, Cb;
+};
+
+// Optional second output of an epilogue: the value's 16-bit operand planes for channels [lo, hi) of the destination
+// (n_planes 3: bf16 hi/mid/lo with x = hi + mid + lo exactly; 1: fp16), plane p at base + p*plane_stride (elements).
+struct PlaneOut {
+  unsigned short* base;
+  long plane_stride;
+  int ld, lo, hi, n_planes;   // n_planes == 0: no plane output
+};
+
+__device__ __forceinline__ unsigned fast_div(unsigned a, unsigned magic) { return __umulhi(a, magic); }
+
+// Raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor; an offset >= num_records returns 0
+// (hardware bounds check), which replaces every predicate/select of the zero-padding logic.  OOB_MARK is added
+// to (or used as) an offset to force that; two marks sum to 2^31, still out of range.
+constexpr int OOB_MARK = 0x40000000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x3fffffffu ? 0x3fffffffu : bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ u32x4 buf_ld16(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// ---- fp32 -> 16-bit operand planes -------------------------------------------------------------------------------------
+// x = hi + mid + lo with three bf16 values (3 x 8 significand bits = the 24 of fp32, same exponent range); a*b is summed
+// from the six terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 (fp32 accumulation); the
+// dropped terms are <= 2^-23 |a||b|.  Measured (tools/microbench/bf16x3_accuracy.hip, K = 4608): rms error 2.5e-8 of
+// sum|a||b| against 2.8e-8 for v_mfma_f32_32x32x2_f32 — the same accuracy class.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// one value -> its three bf16 planes (round-to-nearest-even at every level; the two subtractions are exact)
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const unsigned hh = cvt_pk_bf16(x, 0.f) & 0xffffu;
+  const float r = x - __uint_as_float(hh << 16);
+  const unsigned mm = cvt_pk_bf16(r, 0.f) & 0xffffu;
+  const float s = r - __uint_as_float(mm << 16);
+  h = (unsigned short)hh;
+  m = (unsigned short)mm;
+  l = (unsigned short)(cvt_pk_bf16(s, 0.f) & 0xffffu);
+}
+__device__ __forceinline__ unsigned short to_f16_bits(float x) {
+  const _Float16 h = (_Float16)x;   // v_cvt_f16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned short, h);
+}
+// store the planes of one output element (channel n of destination pixel px); no-op outside [lo, hi) / without planes
+__device__ __forceinline__ void store_planes(const PlaneOut& o, size_t px, int n, float v) {
+  if (o.n_planes == 0 || n < o.lo || n >= o.hi) return;
+  unsigned short* d = o.base + px * (size_t)o.ld + n;
+  if (o.n_planes == 1) {
+    *d = to_f16_bits(v);
+  } else {
+    unsigned short h, m, l;
+    split3(v, h, m, l);
+    d[0] = h;
+    d[o.plane_stride] = m;
+    d[2 * o.plane_stride] = l;
+  }
+}
+// four consecutive channels n .. n+3 (n % 4 == 0, 8-byte aligned destination): one 8-byte store per plane
+__device__ __forceinline__ void store_planes4(const PlaneOut& o, size_t px, int n, const float4 v) {
+  if (o.n_planes == 0 || n + 3 < o.lo || n >= o.hi) return;
+  if (n < o.lo || n + 4 > o.hi) {   // straddles the range: element-wise
+    store_planes(o, px, n, v.x); store_planes(o, px, n + 1, v.y); store_planes(o, px, n + 2, v.z); store_planes(o, px, n + 3, v.w);
+    return;
+  }
+  unsigned short* d = o.base + px * (size_t)o.ld + n;
+  if (o.n_planes == 1) {
+    const unsigned a = (unsigned)to_f16_bits(v.x) | ((unsigned)to_f16_bits(v.y) << 16);
+    const unsigned b = (unsigned)to_f16_bits(v.z) | ((unsigned)to_f16_bits(v.w) << 16);
+    *reinterpret_cast<uint2*>(d) = make_uint2(a, b);
+    return;
+  }
+  const unsigned h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+  const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+  const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+  const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m0 & 0xffff0000u);
+  const float s2 = r2 - __uint_as_float(m1 << 16), s3 = r3 - __uint_as_float(m1 & 0xffff0000u);
+  *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(d + o.plane_stride) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(d + 2 * o.plane_stride) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
+}
+
+// ------------------------------------------------------------------ host side: geometry
+inline void same_pads(int in, int k, int s, int* before, int* out) {
+  const int o = (in + s - 1) / s;
+  int total = (o - 1) * s + k - in;
+  if (total < 0) total = 0;
+  *before = total / 2;
+  *out = o;
+}
+
+inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+
+inline void build_conv_fwd(GatherGeom& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
+  p.dstep = 1; p.kstep = 1; p.KW = k; p.Cs = Cin; p.N = Cout; p.wtaps = k * k;
+  p.Hd = Ho; p.Wd = Wo; p.so = 1; p.ncls = 1;
+  p.cls[0] = TapClass{k, k, -pt, -pl, 0, 0, 0, 0};
+}
+
+inline int build_conv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  p.B = B; p.Hs = Ho; p.Ws = Wo; p.sm = 1;
+  p.dstep = -1; p.KW = k; p.Cs = Cout; p.N = Cin; p.wtaps = k * k;
+  p.Hd = H; p.Wd = W;
+  if (stride == 1) {
+    p.Hg = H; p.Wg = W; p.so = 1; p.ncls = 1; p.kstep = 1;
+    p.cls[0] = TapClass{k, k, pt, pl, 0, 0, 0, 0};
+    return UNFLOW_OK;
+  }
+  // input pixel (2*yg+py): contributing taps ky == (py+pt) mod 2, source row yg + (py+pt-ky)/2
+  if (H % 2 != 0 || W % 2 != 0) return UNFLOW_ERR_UNSUPPORTED;
+  p.Hg = H / 2; p.Wg = W / 2; p.so = 2; p.ncls = 4; p.kstep = 2;
+  for (int c = 0; c < 4; c++) {
+    const int py = c >> 1, px = c & 1;
+    const int ky0 = (py + pt) & 1, kx0 = (px + pl) & 1;
+    const int nty = ky0 < k ? (k - ky0 + 1) / 2 : 0, ntx = kx0 < k ? (k - kx0 + 1) / 2 : 0;
+    if (nty == 0 || ntx == 0) return UNFLOW_ERR_UNSUPPORTED;
+    p.cls[c] = TapClass{nty, ntx, (py + pt - ky0) / 2, (px + pl - kx0) / 2, ky0, kx0, py, px};
+  }
+  return UNFLOW_OK;
+}
+
+// conv_transpose k4 s2 'SAME': oy = 2*iy + ky - 1
+inline void build_deconv_fwd(GatherGeom& p, int B, int H, int W, int Cin, int Cout) {
+  p.B = B; p.Hg = H; p.Wg = W; p.Hs = H; p.Ws = W; p.sm = 1;
+  p.dstep = -1; p.kstep = 2; p.KW = 4; p.Cs = Cin; p.N = Cout; p.wtaps = 16;
+  p.Hd = 2 * H; p.Wd = 2 * W; p.so = 2; p.ncls = 4;
+  for (int c = 0; c < 4; c++) {
+    const int py = c >> 1, px = c & 1;
+    const int ky0 = (py + 1) & 1, kx0 = (px + 1) & 1;
+    p.cls[c] = TapClass{2, 2, (py + 1 - ky0) / 2, (px + 1 - kx0) / 2, ky0, kx0, py, px};
+  }
+}
+
+inline void build_deconv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cout) {
+  p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
+  p.dstep = 1; p.kstep = 1; p.KW = 4; p.Cs = Cout; p.N = Cin; p.wtaps = 16;
+  p.Hd = H; p.Wd = W; p.so = 1; p.ncls = 1;
+  p.cls[0] = TapClass{4, 4, -1, -1, 0, 0, 0, 0};
+}
+
+inline void build_conv_wgrad(WgradGeom& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
+  int pt, pl, Ho, Wo;
+  same_pads(H, k, stride, &pt, &Ho);
+  same_pads(W, k, stride, &pl, &Wo);
+  p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
+  p.KH = k; p.KW = k; p.dy0 = -pt; p.dx0 = -pl; p.Ca = Cin; p.Cb = Cout;
+}
+
+// dW[ky,kx,co,ci] = sum_{input sites} dz[2iy+ky-1, 2ix+kx-1, co] * x[iy,ix,ci]
+inline void build_deconv_wgrad(WgradGeom& p, int B, int H, int W, int Cin, int Cout) {
+  p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
+  p.KH = 4; p.KW = 4; p.dy0 = -1; p.dx0 = -1; p.Ca = Cout; p.Cb = Cin;
+}
+
+// ------------------------------------------------------------------ host side: split planning
+// Resident workgroups per launch ("slots"): 256 CUs x blocks per CU of a tile config.  A split count is chosen so the
+// launch is ONE full round of resident blocks (blocks * nsplit <= slots, as close as possible): 1088 blocks on 768 slots
+// run as 1.4 rounds.
+inline int fill_one_round(long blocks, int slots, int max_split) {
+  if (blocks >= slots) return 1;
+  int ns = (int)(slots / blocks);
+  if (ns > max_split) ns = max_split;
+  if (ns < 1) ns = 1;
+  // A badly filled single round (288 blocks on 512 slots): a split that runs 2-3 well-filled rounds wins.  Take it only
+  // for a clear gain, and the fewest splits that get it.
+  auto eff = [&](int n) { const long b = blocks * n; return (double)b / (double)(((b + slots - 1) / slots) * slots); };
+  const double e1 = eff(ns);
+  if (e1 < 0.8) {
+    int best = ns;
+    double be = e1;
+    for (int n = ns + 1; n <= max_split && blocks * n <= 3L * slots; n++)
+      if (eff(n) > be + 0.02) { best = n; be = eff(n); }
+    if (be >= e1 + 0.15) ns = best;
+  }
+  return ns;
+}
+
+// ------------------------------------------------------------------ fixed-order partial sums (deterministic split-K)
+constexpr int REDUCE_FAN = 32;
+
+// out[g][e] = sum_{k < fan} partial[g*fan + k][e]  (fixed order; g < ceil(S/fan)).  With S <= fan this is the
+// final sum.  Applied repeatedly it is a deterministic tree reduction whose serial depth is <= fan.
+static __global__ void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, size_t n, int S,
+                                           int fan) {
+  const int G = (S + fan - 1) / fan;
+  const size_t total = n * (size_t)G;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = t / n, e = t - g * n;
+    const int k1 = min(S, (int)(g + 1) * fan);
+    float v = 0.f;
+#pragma unroll 8
+    for (int k = (int)g * fan; k < k1; k++) v += partial[(size_t)k * n + e];
+    out[g * n + e] = v;
+  }
+}
+
+// float4 variant (n % 4 == 0): same fixed order per element, a quarter of the threads, 8 loads in flight.
+static __global__ void sum_partials4_kernel(const float4* __restrict__ partial, float4* __restrict__ out, size_t nq, int S,
+                                            int fan) {
+  const int G = (S + fan - 1) / fan;
+  const size_t total = nq * (size_t)G;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = t / nq, e = t - g * nq;
+    const int k1 = min(S, (int)(g + 1) * fan);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = (int)g * fan; k < k1; k++) {
+      const float4 a = partial[(size_t)k * nq + e];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    out[g * nq + e] = v;
+  }
+}
+
+// Bytes of scratch reduce_partials needs after the S*n partials themselves.
+inline size_t reduce_scratch_bytes(size_t n, int S) {
+  return S > REDUCE_FAN ? 2 * (size_t)((S + REDUCE_FAN - 1) / REDUCE_FAN) * n * sizeof(float) : 0;
+}
+
+inline void launch_sum_partials(const float* partial, float* out, size_t n, int S, int G, hipStream_t st) {
+  const bool vec = n % 4 == 0 && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec)
+    sum_partials4_kernel<<<stream_grid((long)(n / 4 * G)), 256, 0, st>>>(reinterpret_cast<const float4*>(partial),
+                                                                        reinterpret_cast<float4*>(out), n / 4, S, REDUCE_FAN);
+  else
+    sum_partials_kernel<<<stream_grid((long)(n * G)), 256, 0, st>>>(partial, out, n, S, REDUCE_FAN);
+}
+
+// out[e] = sum_s partial[s][e]; `scratch` (reduce_scratch_bytes) is used when S > REDUCE_FAN.
+inline int reduce_partials(const float* partial, float* scratch, float* out, size_t n, int S, hipStream_t st) {
+  while (S > REDUCE_FAN) {
+    const int G = (S + REDUCE_FAN - 1) / REDUCE_FAN;
+    launch_sum_partials(partial, scratch, n, S, G, st);
+    // next level reads `scratch`; its output must not alias: levels alternate between scratch halves
+    partial = scratch;
+    scratch = scratch + (size_t)G * n;
+    S = G;
+  }
+  launch_sum_partials(partial, out, n, S, 1, st);
+  return launch_status();
+}
+
+}  // namespace igemm
