@@ -131,15 +131,25 @@ _FLOWNETC_ACTS = [('catc', 0, 32), ('cat3', 0, 256), ('c4', 0, 512), ('cat4', 0,
 _FLOWNETS_ACTS = [('c1', 0, 64), ('cat2', 0, 128), ('c3', 0, 256)] + [('cat3', 0, 256)] + _FLOWNETC_ACTS[2:]
 
 
-def flownet_c_order(B):
-    """flownet.py:30-44: features of im1, features of im2, flownet_c forward direction, flownet_c backward direction."""
-    return [(a, slice(0, B)) for a in _FEATURE_ACTS] + [(a, slice(B, 2 * B)) for a in _FEATURE_ACTS] + \
-           [(a, slice(0, B)) for a in _FLOWNETC_ACTS] + [(a, slice(B, 2 * B)) for a in _FLOWNETC_ACTS]
+def flownet_c_order(B, act=None):
+    """flownet.py:30-44: features of im1, features of im2, flownet_c forward direction, flownet_c backward direction.
+    Entries: (buffer spec, sample slice, activation dict of the stage or None = the one given to BranchAligned)."""
+    return [(a, slice(0, B), act) for a in _FEATURE_ACTS] + [(a, slice(B, 2 * B), act) for a in _FEATURE_ACTS] + \
+           [(a, slice(0, B), act) for a in _FLOWNETC_ACTS] + [(a, slice(B, 2 * B), act) for a in _FLOWNETC_ACTS]
 
 
-def flownet_s_order(B):
+def flownet_s_order(B, act=None):
     """flownet.py:58-67: flownet_s on the forward inputs, then on the backward inputs."""
-    return [(a, slice(0, B)) for a in _FLOWNETS_ACTS] + [(a, slice(B, 2 * B)) for a in _FLOWNETS_ACTS]
+    return [(a, slice(0, B), act) for a in _FLOWNETS_ACTS] + [(a, slice(B, 2 * B), act) for a in _FLOWNETS_ACTS]
+
+
+def engine_order(eng):
+    """Leaky-ReLU call order of the oracle's flownet() for the engine's whole (possibly stacked) spec."""
+    out = []
+    for st in eng.stages:
+        assert st.kind in 'CS' and not st.full_res, "full-width nets without full_res only"
+        out += flownet_c_order(eng.B, st.act) if st.is_c else flownet_s_order(eng.B, st.act)
+    return out
 
 
 class BranchAligned:
@@ -157,9 +167,9 @@ class BranchAligned:
         self.act, self.order, self.calls, self.flips, self.units = act, order, 0, 0, 0
 
     def _hook(self, x):
-        (name, lo, hi), smp = self.order[self.calls]
+        (name, lo, hi), smp, act = self.order[self.calls]
         self.calls += 1
-        y = self.act[name][smp, :, :, lo:hi]
+        y = (self.act if act is None else act)[name][smp, :, :, lo:hi]
         mask = (y > 0).permute(0, 3, 1, 2).cpu()
         assert mask.shape == x.shape, (name, mask.shape, x.shape)
         self.flips += int(((x.detach() > 0) != mask).sum())

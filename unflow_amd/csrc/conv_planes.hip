@@ -44,8 +44,16 @@ struct PlGatherParams : GatherGeom {
   int lds, ldd, ld_act, act_lo, act_hi;
   int nsplit;
   int leaky, accumulate;
+  int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   PlaneOut pl;
 };
+
+// LDS bytes of one gather block: the operand tiles, or (larger for n_planes == 1) the four wave-private staging areas of
+// the epilogue (32 rows x (WN + 4) floats each); the destination-pixel table follows.
+constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
+  const int tiles = npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4;
+  return tiles > stage ? tiles : stage;
+}
 
 template <int NPL, bool F16>
 __device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (&bv)[NPL], f32x16& acc, int t) {
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* Ah = smem16;
   unsigned short* Bh = Ah + NPL * A_PLANE;
-  int* pix = reinterpret_cast<int*>(Bh + NPL * B_PLANE);
+  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_gather_main_bytes(BM, BN, WN, NPL));
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
@@ -251,6 +259,53 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 
   // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool to_partial = p.nsplit > 1;
+  if (p.vec_epi) {
+    // Through LDS (free after the K loop; wave-private areas, no barrier): the accumulator layout — lane = column, 16
+    // scattered rows — becomes lane = (row, 4 consecutive columns), so that every global access of the epilogue is a
+    // 16-byte one (fp32) or an 8-byte one (each output plane) covering 256 / 128 contiguous bytes per row.  With one
+    // dword + three 2-byte stores per ELEMENT the epilogue was store-issue bound: conv2's data gradient (25 M outputs)
+    // took 614 us instead of 290.
+    constexpr int EP = WN + 4;                 // staging row pitch (floats)
+    constexpr int QPR = WN / 4, RPI = 64 / QPR;
+    float* stg = reinterpret_cast<float*>(smem16) + wid * (32 * EP);
+    const size_t npix_d = (size_t)p.B * p.Hd * p.Wd;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; it++) {
+        const int rr = it * RPI + lane / QPR, q = lane % QPR;
+        float4 v = *reinterpret_cast<const float4*>(stg + rr * EP + 4 * q);
+        const int px = pix[wm * WM + i * 32 + rr];
+        const int n = n0 + wn * WN + 4 * q;
+        if (px < 0 || n >= p.N) continue;
+        if (to_partial) {
+          *reinterpret_cast<float4*>(p.partial + ((size_t)split * npix_d + px) * p.N + n) = v;
+          continue;
+        }
+        if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
+        if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
+        float4* d = reinterpret_cast<float4*>(p.dst + (size_t)px * p.ldd + n);
+        if (p.accumulate) {
+          const float4 e = *d;
+          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
+          const float4 a = *reinterpret_cast<const float4*>(p.act_src + (size_t)px * p.ld_act + n);
+          if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
+          if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
+          if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
+          if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
+        }
+        *d = v;
+        store_planes4(p.pl, (size_t)px, n, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -391,7 +446,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   const int aj = tid % AJ, ak = tid / AJ;
   const int mg = (m0 >> 3) + aj;
   const bool m_ok = mg < Mg;
-  const unsigned tap = fast_div((unsigned)mg, p.cag_magic);
+  const unsigned tap = p.cag_magic ? fast_div((unsigned)mg, p.cag_magic) : (unsigned)mg;   // magic 0: Ca == 8, one granule per tap
   const int ag = mg - (int)tap * Cag;
   const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
   const int dy = p.dy0 + ky, dx = p.dx0 + kx;
@@ -520,7 +575,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
       const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh5;
       const int mgr = m >> 3;
       if (mgr >= Mg) continue;
-      const unsigned tp = fast_div((unsigned)mgr, p.cag_magic);
+      const unsigned tp = p.cag_magic ? fast_div((unsigned)mgr, p.cag_magic) : (unsigned)mgr;
       const int a = (mgr - (int)tp * Cag) * 8 + (m & 7);
       if (a >= p.Ca_out) continue;
       float* orow = o + ((size_t)tp * p.Ca_out + a) * p.Cb;
@@ -569,16 +624,28 @@ struct WPlaneBatch {
   int n, n_planes;
 };
 
-__device__ __forceinline__ void put_planes(unsigned short* base, long ps, int n_planes, size_t idx, float v) {
+// eight consecutive plane elements (16 bytes per plane) from eight fp32 values
+__device__ __forceinline__ void put_planes8(unsigned short* base, long ps, int n_planes, size_t idx, const float (&v)[8]) {
   if (n_planes == 1) {
-    base[idx] = to_f16_bits(v);
-  } else {
-    unsigned short h, m, l;
-    split3(v, h, m, l);
-    base[idx] = h;
-    base[idx + ps] = m;
-    base[idx + 2 * ps] = l;
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (unsigned)to_f16_bits(v[2 * i]) | ((unsigned)to_f16_bits(v[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(base + idx) = o;
+    return;
   }
+  u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned hh = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hh << 16), rb = b - __uint_as_float(hh & 0xffff0000u);
+    const unsigned mm = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
+    h[i] = hh; m[i] = mm; l[i] = cvt_pk_bf16(sa, sb);
+  }
+  *reinterpret_cast<u32x4*>(base + idx) = h;
+  *reinterpret_cast<u32x4*>(base + idx + ps) = m;
+  *reinterpret_cast<u32x4*>(base + idx + 2 * ps) = l;
 }
 
 __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b) {
@@ -598,18 +665,27 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b)
     tile[r][c] = (r0 + r < d.R && c0 + c < d.Cc) ? w[(size_t)(r0 + r) * d.Cc + c0 + c] : 0.f;
   }
   __syncthreads();
+  // one 16-byte store per plane and thread: 8 consecutive K elements (zero beyond the tensor: the tile is zero-filled)
   if (d.direct) {
     const long ps = (long)d.taps * d.R * Cc8;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      if (r0 + r < d.R && c0 + c < Cc8) put_planes(d.direct, ps, b.n_planes, ((size_t)tap * d.R + r0 + r) * Cc8 + c0 + c, tile[r][c]);
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int r = e >> 3, c8 = (e & 7) * 8;
+      if (r0 + r >= d.R || c0 + c8 >= Cc8) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = tile[r][c8 + i];
+      put_planes8(d.direct, ps, b.n_planes, ((size_t)tap * d.R + r0 + r) * Cc8 + c0 + c8, v);
     }
   }
   if (d.transposed) {
     const long ps = (long)d.taps * d.Cc * R8;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-      const int c = e >> 6, r = e & 63;
-      if (c0 + c < d.Cc && r0 + r < R8) put_planes(d.transposed, ps, b.n_planes, ((size_t)tap * d.Cc + c0 + c) * R8 + r0 + r, tile[r][c]);
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int r8 = (e & 7) * 8, c = e >> 3;      // 8 lanes write 128 contiguous bytes of one output row
+      if (c0 + c >= d.Cc || r0 + r8 >= R8) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = tile[r8 + i][c];
+      put_planes8(d.transposed, ps, b.n_planes, ((size_t)tap * d.Cc + c0 + c) * R8 + r0 + r8, v);
     }
   }
 }
@@ -620,7 +696,7 @@ struct PlPlan {
   int nsplit;
 };
 
-inline int pl_smem_gather(int bm, int bn, int npl) { return npl * (bm + bn) * LDH * 2 + bm * 4; }
+inline int pl_smem_gather(int bm, int bn, int npl) { return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl) + bm * 4; }
 
 // blocks per CU by LDS (160 KB) and registers (<= 168: 3 waves per SIMD)
 inline int pl_blocks_per_cu(int bm, int bn, int npl) {
@@ -684,6 +760,12 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     if (!ws || ws_bytes < pl_gather_partial_bytes(p, p.nsplit)) p.nsplit = 1;  // no scratch: un-split (same result up to fp32 order)
     else p.partial = reinterpret_cast<float*>(ws);
   }
+  {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
+                         reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0);
+    p.vec_epi = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0 &&
+                (!p.pl.n_planes || p.pl.ld % 4 == 0);
+  }
   const int code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1) {
@@ -731,7 +813,7 @@ int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
 }
 
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
-  p.cag_magic = magic_u32((unsigned)(p.Ca >> 3));
+  p.cag_magic = p.Ca == 8 ? 0u : magic_u32((unsigned)(p.Ca >> 3));   // 2^32 / 1 does not fit: 0 marks 'no division'
   const size_t wsize = (size_t)p.KH * p.KW * p.Ca_out * p.Cb;
   int ns = plan_pl_wgrad(p, npl);
   if (ns > 1 && (!ws || ws_bytes < pl_wgrad_partial_bytes(p, p.Ca_out, ns))) {
