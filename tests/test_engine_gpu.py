@@ -209,6 +209,13 @@ def test_flownet_s_and_stacks_vs_oracle(spec, dev):
     eng = FlowNetEngine(B, H, W, params=params, device=dev, seed=None)
     tf_params = M.init_params_spec(spec, seed=7)
     assert [l.name for l in eng.layers] == [k[:-8] for k in tf_params if k.endswith('/weights')]
+    if len(spec) > 1:
+        # random-initialised stacks blow the flow up to hundreds of pixels, where warp sample points sit within fp32 noise
+        # of pixel boundaries (the derivative of bilinear interpolation jumps there): keep the flows in the regime of a
+        # trained stack (see tests/test_parity_fullsize_gpu.py::test_flownet_css_768x1024_vs_oracle)
+        for k in tf_params:
+            if k.split('/')[-2].startswith('flow') and k.endswith('/weights'):
+                tf_params[k] = tf_params[k] * 0.3
     eng.load_tf_params(tf_params)
     g = torch.Generator().manual_seed(8)
     im1 = torch.rand(B, H, W, 3, generator=g) * 255

@@ -45,6 +45,7 @@ struct PlGatherParams : GatherGeom {
   int nsplit;
   int leaky, accumulate;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
+  int tiles_y, tiles_x;        // halo kernel: 8 x 16-site tiles per image
   PlaneOut pl;
 };
 
@@ -66,6 +67,89 @@ __device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ta[t]]), __builtin_bit_cast(bf16x8, bv[tb[t]]), acc,
                                                   0, 0, 0);
   }
+}
+
+// Epilogue shared by the gather kernels: bias / leaky-ReLU / accumulate / leaky derivative, fp32 result + output planes, or
+// the split-K partial.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int WM, int WN>
+__device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x16 (&acc)[WM / 32][WN / 32], const int* pix,
+                                                   unsigned short* smem16, int wm, int wn, int wid, int lane, int n0,
+                                                   int split) {
+  constexpr int TM = WM / 32, TN = WN / 32;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool to_partial = p.nsplit > 1;
+  if (p.vec_epi) {
+    // Through LDS (free after the K loop; wave-private areas, no barrier): the accumulator layout — lane = column, 16
+    // scattered rows — becomes lane = (row, 4 consecutive columns), so that every global access of the epilogue is a
+    // 16-byte one (fp32) or an 8-byte one (each output plane) covering 256 / 128 contiguous bytes per row.  With one
+    // dword + three 2-byte stores per ELEMENT the epilogue was store-issue bound: conv2's data gradient (25 M outputs)
+    // took 614 us instead of 290.
+    constexpr int EP = WN + 4;                 // staging row pitch (floats)
+    constexpr int QPR = WN / 4, RPI = 64 / QPR;
+    float* stg = reinterpret_cast<float*>(smem16) + wid * (32 * EP);
+    const size_t npix_d = (size_t)p.B * p.Hd * p.Wd;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; it++) {
+        const int rr = it * RPI + lane / QPR, q = lane % QPR;
+        float4 v = *reinterpret_cast<const float4*>(stg + rr * EP + 4 * q);
+        const int px = pix[wm * WM + i * 32 + rr];
+        const int n = n0 + wn * WN + 4 * q;
+        if (px < 0 || n >= p.N) continue;
+        if (to_partial) {
+          *reinterpret_cast<float4*>(p.partial + ((size_t)split * npix_d + px) * p.N + n) = v;
+          continue;
+        }
+        if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
+        if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
+        float4* d = reinterpret_cast<float4*>(p.dst + (size_t)px * p.ldd + n);
+        if (p.accumulate) {
+          const float4 e = *d;
+          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
+          const float4 a = *reinterpret_cast<const float4*>(p.act_src + (size_t)px * p.ld_act + n);
+          if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
+          if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
+          if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
+          if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
+        }
+        *d = v;
+        store_planes4(p.pl, (size_t)px, n, v);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int px = pix[row];
+      if (px < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r];
+        if (to_partial) {
+          p.partial[((size_t)split * ((size_t)p.B * p.Hd * p.Wd) + px) * p.N + n] = v;
+        } else {
+          if (p.bias) v += p.bias[n];
+          if (p.leaky) v = leaky_relu(v);
+          float* d = p.dst + (size_t)px * p.ldd + n;
+          if (p.accumulate) v += *d;
+          if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
+          *d = v;
+          store_planes(p.pl, (size_t)px, n, v);
+        }
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ gather kernel
@@ -257,80 +341,204 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
     __syncthreads();
   }
 
-  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool to_partial = p.nsplit > 1;
-  if (p.vec_epi) {
-    // Through LDS (free after the K loop; wave-private areas, no barrier): the accumulator layout — lane = column, 16
-    // scattered rows — becomes lane = (row, 4 consecutive columns), so that every global access of the epilogue is a
-    // 16-byte one (fp32) or an 8-byte one (each output plane) covering 256 / 128 contiguous bytes per row.  With one
-    // dword + three 2-byte stores per ELEMENT the epilogue was store-issue bound: conv2's data gradient (25 M outputs)
-    // took 614 us instead of 290.
-    constexpr int EP = WN + 4;                 // staging row pitch (floats)
-    constexpr int QPR = WN / 4, RPI = 64 / QPR;
-    float* stg = reinterpret_cast<float*>(smem16) + wid * (32 * EP);
-    const size_t npix_d = (size_t)p.B * p.Hd * p.Wd;
+  pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
+}
+
+// ------------------------------------------------------------------------------------------------ halo gather kernel
+// Source stride 1 (3x3 / 1x1 stride-1 convs, every conv data gradient incl. the 4 parity classes of stride 2, conv_transpose
+// forward): the taps of a site are its neighbours, so a spatially compact tile re-reads almost the same pixels for every
+// tap.  igemm_pl_gather_kernel fetches them once PER TAP (its 128-site tiles are image rows; the re-reads miss L1 and,
+// with ~100 resident tiles per XCD, L2 too: conv2's data gradient moved 1.9 GB for 0.6 GB of operands and ran at the
+// Infinity-Cache rate, 64 TFLOP/s).  Here a block owns an 8 x 16-site tile and walks K chunk-major: for every 32-channel
+// chunk the (8 + nty - 1) x (16 + ntx - 1) halo of source pixels is loaded ONCE into LDS ([pixel][32 ch], 80-byte pitch:
+// conflict-free b128 reads of consecutive pixels) and serves all taps through a per-tap address offset; only the weight
+// tile streams per tap.  A-operand loads drop by taps * 128 / halo (6.4x for 3x3), all loads by ~1.7x.
+constexpr int TH = 8, TW = 16, TWL = 4;     // tile = TH x TW = 128 sites
+constexpr int HPITCH = 40;                  // 16-bit elements per halo pixel row: 32 channels + 8 pad (80 bytes)
+
+constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
+  const int tiles = npl * (hp * HPITCH + bn * LDH) * 2, stage = 4 * 32 * (wn + 4) * 4;
+  return tiles > stage ? tiles : stage;
+}
+
+template <int BN, int WM, int WN, int NPL, bool F16>
+__global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams p, int HPmax) {
+  constexpr int BM = 128;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  constexpr int B_PLANE = BN * LDH;
+  constexpr int NB = BN / 64;
+  constexpr int NH = 4;                          // halo granules per thread and plane (covers 256 pixels)
+  constexpr int NT = NPL == 3 ? 6 : 1;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  const int H_PLANE = HPmax * HPITCH;
+  unsigned short* Hh = smem16;
+  unsigned short* Bh = Hh + NPL * H_PLANE;
+  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_halo_main_bytes(BN, WN, NPL, HPmax));
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int cls_id = blockIdx.z % p.ncls, split = blockIdx.z / p.ncls;
+  const TapClass tc = p.cls[cls_id];
+  const int n0 = blockIdx.y * BN;
+  const int ntaps = tc.nty * tc.ntx;
+  const int Cg = p.Cs >> 3;
+  const int nchunk = (Cg + 3) >> 2;
+  const int ch_per = (nchunk + p.nsplit - 1) / p.nsplit;
+  const int kt0 = split * ch_per * ntaps, kt1 = min(nchunk, (split + 1) * ch_per) * ntaps;
+
+  // tile -> (image, tile row, tile column)
+  int t = blockIdx.x;
+  const int txi = t % p.tiles_x; t /= p.tiles_x;
+  const int tyi = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int y0 = tyi * TH, x0 = txi * TW;
+  // halo geometry of this class: source rows y0 + dmin_y .. + HR - 1
+  const int dmin_y = p.dstep > 0 ? tc.dy0 : tc.dy0 - (tc.nty - 1);
+  const int dmin_x = p.dstep > 0 ? tc.dx0 : tc.dx0 - (tc.ntx - 1);
+  const int HC = TW + tc.ntx - 1, HR = TH + tc.nty - 1, HP = HR * HC;
+
+  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
+    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
+  }
+  const int kq = tid & 3;
+  const int lds2 = p.lds * 2;
+  // this thread's halo granules: pixel hp = (tid >> 2) + 64 j, granule kq of the chunk
+  int h_off[NH];
 #pragma unroll
-      for (int j = 0; j < TN; j++)
+  for (int j = 0; j < NH; j++) {
+    const int hp = (tid >> 2) + 64 * j;
+    const int hy = hp / HC, hx = hp - hy * HC;
+    const int y = y0 + dmin_y + hy, x = x0 + dmin_x + hx;
+    const bool ok = hp < HP && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+    h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
+  }
+  if (tid < BM) {
+    const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
+    pix[tid] = (yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px : -1;
+  }
+  int b_row[NB];
 #pragma unroll
-        for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
+  for (int i = 0; i < NB; i++) {
+    const int n = n0 + (tid >> 2) + 64 * i;
+    b_row[i] = n < p.N ? n * p.Cs * 2 + kq * 16 : OOB_MARK;
+  }
+
+  u32x4 rh[NH][NPL], rb[NB][NPL];
+  // loads of K tile kk = (chunk, tap): weights always, the halo when the tile opens a chunk
+  auto load_b = [&](int i, int kk) {
+    const int chunk = kk / ntaps, tap = kk - chunk * ntaps;
+    const int ty = tap / tc.ntx, tx = tap - ty * tc.ntx;
+    const int widx = (tc.ky0 + ty * p.kstep) * p.KW + tc.kx0 + tx * p.kstep;
+    const bool ok = kk < kt1 && chunk * 4 + kq < Cg;
+    const int voff = ok ? b_row[i] + widx * p.N * p.Cs * 2 + chunk * 64 : OOB_MARK;
 #pragma unroll
-      for (int it = 0; it < 32 / RPI; it++) {
-        const int rr = it * RPI + lane / QPR, q = lane % QPR;
-        float4 v = *reinterpret_cast<const float4*>(stg + rr * EP + 4 * q);
-        const int px = pix[wm * WM + i * 32 + rr];
-        const int n = n0 + wn * WN + 4 * q;
-        if (px < 0 || n >= p.N) continue;
-        if (to_partial) {
-          *reinterpret_cast<float4*>(p.partial + ((size_t)split * npix_d + px) * p.N + n) = v;
-          continue;
-        }
-        if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
-        if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
-        float4* d = reinterpret_cast<float4*>(p.dst + (size_t)px * p.ldd + n);
-        if (p.accumulate) {
-          const float4 e = *d;
-          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
-        }
-        if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
-          const float4 a = *reinterpret_cast<const float4*>(p.act_src + (size_t)px * p.ld_act + n);
-          if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
-          if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
-          if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
-          if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
-        }
-        *d = v;
-        store_planes4(p.pl, (size_t)px, n, v);
+    for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
+  };
+  auto load_h = [&](int j, int kk) {
+    const int chunk = kk / ntaps;
+    const bool ok = kk < kt1 && chunk * 4 + kq < Cg;
+    const int voff = ok ? h_off[j] + chunk * 64 : OOB_MARK;
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) rh[j][pl] = buf_ld16(src_rs[pl], voff);
+  };
+  auto swz = [](int row, int g) { return row * LDH + 8 * (g ^ ((row >> 2) & 3)); };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        *reinterpret_cast<u32x4*>(Bh + pl * B_PLANE + swz((tid >> 2) + 64 * i, kq)) = rb[i][pl];
+  };
+  auto store_h = [&]() {
+#pragma unroll
+    for (int j = 0; j < NH; j++) {
+      const int hp = (tid >> 2) + 64 * j;
+      if (hp < HPmax) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+          *reinterpret_cast<u32x4*>(Hh + pl * H_PLANE + hp * HPITCH + kq * 8) = rh[j][pl];
       }
     }
-    return;
-  }
+  };
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int px = pix[row];
-      if (px < 0) continue;
+    for (int j = 0; j < TN; j++)
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        if (to_partial) {
-          p.partial[((size_t)split * ((size_t)p.B * p.Hd * p.Wd) + px) * p.N + n] = v;
-        } else {
-          if (p.bias) v += p.bias[n];
-          if (p.leaky) v = leaky_relu(v);
-          float* d = p.dst + (size_t)px * p.ldd + n;
-          if (p.accumulate) v += *d;
-          if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
-          *d = v;
-          store_planes(p.pl, (size_t)px, n, v);
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  // A fragment of sub-tile i: site s = wm*WM + i*32 + l31 -> halo pixel (s / TW) * HC + s % TW (+ the tap's offset)
+  int a_rd[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const int sidx = wm * WM + i * 32 + l31;
+    a_rd[i] = ((sidx >> TWL) * HC + (sidx & (TW - 1))) * HPITCH + lh * 8;
+  }
+  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
+  const int gsw = lh ^ ((l31 >> 2) & 3);
+
+  if (kt0 < kt1) {
+#pragma unroll
+    for (int j = 0; j < NH; j++) load_h(j, kt0);
+#pragma unroll
+    for (int i = 0; i < NB; i++) load_b(i, kt0);
+  }
+  store_h();
+  store_b();
+  __syncthreads();
+  constexpr int NGROUP = 2 * TM * NT;
+  constexpr int NPIECE = NB + NH;
+  constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
+  int tap = 0;                                   // kt0 is a chunk boundary
+  for (int kk = kt0; kk < kt1; kk++) {
+    const int ty = tap / tc.ntx, tx = tap - ty * tc.ntx;
+    const int hyi = (tc.dy0 + ty * p.dstep) - dmin_y, hxi = (tc.dx0 + tx * p.dstep) - dmin_x;
+    const int tapoff = (hyi * HC + hxi) * HPITCH;
+    const bool new_chunk = tap + 1 == ntaps;    // the next tile opens a chunk: its halo is loaded during this tile
+    auto piece = [&](int step) {
+      if (step < NB) load_b(step, kk + 1);
+      else if (step < NB + NH && new_chunk) load_h(step - NB, kk + 1);
+    };
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++) {
+      s16x8 bv[TN][NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          bv[j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        s16x8 av[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+          av[pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
+#pragma unroll
+        for (int t2 = 0; t2 < NT; t2++) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
+#pragma unroll
+          for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+    __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
+    store_b();
+    if (new_chunk) store_h();
+    __syncthreads();
+    tap = new_chunk ? 0 : tap + 1;
+  }
+  pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
 }
 
 // Fixed-order sum of the split-K partials + the epilogue (+ the output planes).  One float4 per thread.
@@ -752,8 +960,59 @@ int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
   }
 }
 
+// ---- halo kernel: eligibility, plan, launch
+inline bool pl_halo_ok(const GatherGeom& p) {
+  static const bool off = getenv("UNFLOW_NO_HALO") && atoi(getenv("UNFLOW_NO_HALO")) != 0;     // A/B knob
+  if (off || p.sm != 1 || (p.dstep != 1 && p.dstep != -1) || p.Hg < 16 || p.Wg < 16 || p.N <= 32) return false;
+  for (int c = 0; c < p.ncls; c++)
+    if (p.cls[c].nty < 1 || p.cls[c].ntx < 1 || (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1) > 256) return false;
+  return true;
+}
+inline int pl_halo_pixels(const GatherGeom& p) {
+  int hp = 0;
+  for (int c = 0; c < p.ncls; c++) hp = max(hp, (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1));
+  return hp;
+}
+inline int pl_halo_smem(const GatherGeom& p, int bn, int npl) {
+  return pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, npl, pl_halo_pixels(p)) + 128 * 4;
+}
+inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
+  const int bn = p.N <= 64 ? 64 : 128;
+  *bn_out = bn;
+  const int smem = pl_halo_smem(p, bn, npl);
+  const int per_cu = min((160 * 1024) / smem, bn == 128 ? 2 : 3);
+  const long blocks = (long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) * cdiv(p.N, bn) * p.ncls;
+  const int nchunk = ((p.Cs >> 3) + 3) >> 2;
+  int maxtaps = 0;
+  for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
+  const int max_by_k = max(1, min(16, nchunk * maxtaps / 16));      // >= 16 K tiles per split, whole chunks
+  return min(nchunk, fill_one_round(blocks, 256 * per_cu, max_by_k));
+}
+
+template <int BN, int WN, int NPL, bool F16>
+int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
+  const int hp = pl_halo_pixels(p);
+  const int smem = pl_halo_main_bytes(BN, WN, NPL, hp) + 128 * 4;
+  static int smem_set = 0;      // grow-only (the halo size depends on the layer): benign race, idempotent
+  if (smem > smem_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, 64, WN, NPL, F16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    smem_set = smem;
+  }
+  dim3 grid(p.B * p.tiles_y * p.tiles_x, cdiv(p.N, BN), p.ncls * p.nsplit);
+  igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<grid, 256, smem, st>>>(p, hp);
+  return launch_status();
+}
+
 int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStream_t st) {
-  const PlPlan pl = plan_pl_gather(p, npl);
+  const bool halo = pl_halo_ok(p);
+  int halo_bn = 128;
+  PlPlan pl = plan_pl_gather(p, npl);
+  if (halo) {
+    pl.nsplit = plan_pl_halo(p, npl, &halo_bn);
+    p.tiles_y = cdiv(p.Hg, TH);
+    p.tiles_x = cdiv(p.Wg, TW);
+  }
   p.nsplit = pl.nsplit;
   p.partial = nullptr;
   if (p.nsplit > 1) {
@@ -766,7 +1025,13 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     p.vec_epi = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0 &&
                 (!p.pl.n_planes || p.pl.ld % 4 == 0);
   }
-  const int code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
+  int code;
+  if (halo) {
+    if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
+    else code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
+  } else {
+    code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
+  }
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1) {
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
@@ -913,6 +1178,11 @@ UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const 
   return launch_status();
 }
 
+static int pl_gather_nsplit(const GatherGeom& g, int npl) {
+  int bn;
+  return pl_halo_ok(g) ? plan_pl_halo(g, npl, &bn) : plan_pl_gather(g, npl).nsplit;
+}
+
 UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes) {
   // Exact requirement of the *_pl entry points of a conv2d with these dims (and, for k == 4 && stride == 2, of the
   // conv2d_transpose whose OUTPUT is [B,H,W,Cout]); Cin / Cout as passed to those entry points.
@@ -922,20 +1192,20 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
   const int Ci8 = (Cin + 7) & ~7, Co8 = (Cout + 7) & ~7;
   GatherGeom g{};
   build_conv_fwd(g, B, H, W, Ci8, Cout, k, stride);
-  need = max(need, pl_gather_partial_bytes(g, plan_pl_gather(g, n_planes).nsplit));
+  need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
   GatherGeom d{};
   if ((stride == 1 || stride == 2) && build_conv_dgrad(d, B, H, W, Cin, Co8, k, stride) == UNFLOW_OK)
-    need = max(need, pl_gather_partial_bytes(d, plan_pl_gather(d, n_planes).nsplit));
+    need = max(need, pl_gather_partial_bytes(d, pl_gather_nsplit(d, n_planes)));
   WgradGeom wg{};
   build_conv_wgrad(wg, B, H, W, Ci8, Cout, k, stride);
   need = max(need, pl_wgrad_partial_bytes(wg, Cin, plan_pl_wgrad(wg, n_planes)));
   if (k == 4 && stride == 2 && H % 2 == 0 && W % 2 == 0) {
     GatherGeom tf{};
     build_deconv_fwd(tf, B, H / 2, W / 2, Ci8, Cout);
-    need = max(need, pl_gather_partial_bytes(tf, plan_pl_gather(tf, n_planes).nsplit));
+    need = max(need, pl_gather_partial_bytes(tf, pl_gather_nsplit(tf, n_planes)));
     GatherGeom td{};
     build_deconv_dgrad(td, B, H / 2, W / 2, Cin, Co8);
-    need = max(need, pl_gather_partial_bytes(td, plan_pl_gather(td, n_planes).nsplit));
+    need = max(need, pl_gather_partial_bytes(td, pl_gather_nsplit(td, n_planes)));
     WgradGeom tw{};
     build_deconv_wgrad(tw, B, H / 2, W / 2, Cin, Co8);
     need = max(need, pl_wgrad_partial_bytes(tw, Cout, plan_pl_wgrad(tw, n_planes)));
