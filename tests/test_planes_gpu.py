@@ -102,11 +102,11 @@ CONV_CASES = [
     (2, 12, 16, 256, 32, 1, 1),    # conv_redir: 64x64 tile (fwd), pointwise kernel (dgrad)
     (1, 10, 14, 40, 44, 3, 1),     # M and N tails
     (2, 12, 16, 96, 12, 1, 1),     # 3/8-width conv_redir: Cout 12 (K tail granule of the dgrad reads zeros)
-    # halo kernel (source stride 1, maps >= 16 x 16): 8 x 16-site tiles, chunk-major K
+    # halo kernel (source stride 1, maps >= 8 x 32): 4 x 32-site tiles, chunk-major K
     (2, 64, 64, 64, 128, 5, 2),    # data gradient: 4 parity classes (3x3 / 3x2 / 2x3 / 2x2 taps), 32 x 32 site grid
-    (2, 16, 16, 256, 256, 3, 1),   # few tiles: split over chunks + reduce epilogue
+    (2, 8, 32, 256, 256, 3, 1),    # few tiles: split over chunks + reduce epilogue
     (1, 16, 32, 388, 64, 3, 1),    # 49 granules per tap: partial last chunk; N = 64 tile
-    (1, 24, 40, 128, 96, 3, 1),    # tile tails in both directions (24 = 3 x 8, 40 = 2.5 x 16), N tail
+    (1, 10, 40, 128, 96, 3, 1),    # tile tails in both directions (10 = 2.5 x 4, 40 = 1.25 x 32), N tail
     (1, 32, 32, 64, 64, 1, 1),     # 1x1: halo = tile
 ]
 

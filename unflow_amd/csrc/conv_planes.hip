@@ -45,7 +45,7 @@ struct PlGatherParams : GatherGeom {
   int nsplit;
   int leaky, accumulate;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
-  int tiles_y, tiles_x;        // halo kernel: 8 x 16-site tiles per image
+  int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
   PlaneOut pl;
 };
 
@@ -349,11 +349,14 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 // forward): the taps of a site are its neighbours, so a spatially compact tile re-reads almost the same pixels for every
 // tap.  igemm_pl_gather_kernel fetches them once PER TAP (its 128-site tiles are image rows; the re-reads miss L1 and,
 // with ~100 resident tiles per XCD, L2 too: conv2's data gradient moved 1.9 GB for 0.6 GB of operands and ran at the
-// Infinity-Cache rate, 64 TFLOP/s).  Here a block owns an 8 x 16-site tile and walks K chunk-major: for every 32-channel
-// chunk the (8 + nty - 1) x (16 + ntx - 1) halo of source pixels is loaded ONCE into LDS ([pixel][32 ch], 80-byte pitch:
+// Infinity-Cache rate, 64 TFLOP/s).  Here a block owns a 4 x 32-site tile and walks K chunk-major: for every 32-channel
+// chunk the (4 + nty - 1) x (32 + ntx - 1) halo of source pixels is loaded ONCE into LDS ([pixel][32 ch], 80-byte pitch:
 // conflict-free b128 reads of consecutive pixels) and serves all taps through a per-tap address offset; only the weight
 // tile streams per tap.  A-operand loads drop by taps * 128 / halo (6.4x for 3x3), all loads by ~1.7x.
-constexpr int TH = 8, TW = 16, TWL = 4;     // tile = TH x TW = 128 sites
+// Tile = 4 rows x 32 sites: an MFMA sub-tile (32 lanes) is 32 CONSECUTIVE halo pixels, which with the 80-byte pitch makes
+// every 16-lane group of a ds_read_b128 hit 16 distinct 16-byte bank slots (an 8 x 16 tile puts two image rows into one
+// sub-tile: SQ_LDS_BANK_CONFLICT was 85 % of the LDS-active cycles).
+constexpr int TH = 4, TW = 32, TWL = 5;     // tile = TH x TW = 128 sites
 constexpr int HPITCH = 40;                  // 16-bit elements per halo pixel row: 32 channels + 8 pad (80 bytes)
 
 constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
@@ -430,22 +433,28 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   }
 
   u32x4 rh[NH][NPL], rb[NB][NPL];
-  // loads of K tile kk = (chunk, tap): weights always, the halo when the tile opens a chunk
-  auto load_b = [&](int i, int kk) {
-    const int chunk = kk / ntaps, tap = kk - chunk * ntaps;
-    const int ty = tap / tc.ntx, tx = tap - ty * tc.ntx;
-    const int widx = (tc.ky0 + ty * p.kstep) * p.KW + tc.kx0 + tx * p.kstep;
-    const bool ok = kk < kt1 && chunk * 4 + kq < Cg;
-    const int voff = ok ? b_row[i] + widx * p.N * p.Cs * 2 + chunk * 64 : OOB_MARK;
+  // loads of the NEXT K tile (chunk ld_chunk, tap (ld_ty, ld_tx); advanced once per tile, no divisions in the loop):
+  // weights always, the halo when the tile opens a chunk
+  int ld_chunk = kt0 / ntaps, ld_ty = 0, ld_tx = 0;
+  bool ld_live = kt0 < kt1;
+  auto load_b = [&](int i) {
+    const int widx = (tc.ky0 + ld_ty * p.kstep) * p.KW + tc.kx0 + ld_tx * p.kstep;
+    const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
+    const int voff = ok ? b_row[i] + widx * p.N * p.Cs * 2 + ld_chunk * 64 : OOB_MARK;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
   };
-  auto load_h = [&](int j, int kk) {
-    const int chunk = kk / ntaps;
-    const bool ok = kk < kt1 && chunk * 4 + kq < Cg;
-    const int voff = ok ? h_off[j] + chunk * 64 : OOB_MARK;
+  auto load_h = [&](int j) {
+    const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
+    const int voff = ok ? h_off[j] + ld_chunk * 64 : OOB_MARK;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) rh[j][pl] = buf_ld16(src_rs[pl], voff);
+  };
+  auto ld_advance = [&](int kk_next) {     // the loads now target tile kk_next + 1... called after tile kk_next's loads
+    ld_tx++;
+    if (ld_tx == tc.ntx) { ld_tx = 0; ld_ty++; }
+    if (ld_ty == tc.nty) { ld_ty = 0; ld_chunk++; }
+    ld_live = kk_next + 1 < kt1;
   };
   auto swz = [](int row, int g) { return row * LDH + 8 * (g ^ ((row >> 2) & 3)); };
   auto store_b = [&]() {
@@ -486,49 +495,86 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
   const int gsw = lh ^ ((l31 >> 2) & 3);
 
-  if (kt0 < kt1) {
 #pragma unroll
-    for (int j = 0; j < NH; j++) load_h(j, kt0);
+  for (int j = 0; j < NH; j++) load_h(j);
 #pragma unroll
-    for (int i = 0; i < NB; i++) load_b(i, kt0);
-  }
+  for (int i = 0; i < NB; i++) load_b(i);
+  ld_advance(kt0);
   store_h();
   store_b();
   __syncthreads();
   constexpr int NGROUP = 2 * TM * NT;
   constexpr int NPIECE = NB + NH;
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
-  int tap = 0;                                   // kt0 is a chunk boundary
+  int ty = 0, tx = 0;                            // tap of the tile being multiplied (kt0 is a chunk boundary)
   for (int kk = kt0; kk < kt1; kk++) {
-    const int ty = tap / tc.ntx, tx = tap - ty * tc.ntx;
     const int hyi = (tc.dy0 + ty * p.dstep) - dmin_y, hxi = (tc.dx0 + tx * p.dstep) - dmin_x;
     const int tapoff = (hyi * HC + hxi) * HPITCH;
-    const bool new_chunk = tap + 1 == ntaps;    // the next tile opens a chunk: its halo is loaded during this tile
+    const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
     auto piece = [&](int step) {
-      if (step < NB) load_b(step, kk + 1);
-      else if (step < NB + NH && new_chunk) load_h(step - NB, kk + 1);
+      if (step < NB) load_b(step);
+      else if (step < NB + NH && new_chunk) load_h(step - NB);
     };
+    if constexpr (BN == 128) {
+      // software-pipelined over the 2 x TM (slab, sub-tile) steps: the fragments of step s+1 are read from LDS while the
+      // MFMAs of step s run (two waves per SIMD are not enough to hide a ds_read round trip in front of every step)
+      s16x8 bv[2][TN][NPL], av[2][NPL];
+      auto read_b = [&](int slab) {
+  #pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+  #pragma unroll
+          for (int j = 0; j < TN; j++)
+            bv[slab & 1][j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
+      };
+      auto read_a = [&](int step) {
+        const int slab = step / TM, i = step % TM;
+  #pragma unroll
+        for (int pl = 0; pl < NPL; pl++)
+          av[step & 1][pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
+      };
+      read_b(0);
+      read_a(0);
+  #pragma unroll
+      for (int step = 0; step < 2 * TM; step++) {
+        const int slab = step / TM, i = step % TM;
+        if (step + 1 < 2 * TM) {
+          if ((step + 1) / TM != slab) read_b(slab + 1);
+          read_a(step + 1);
+        }
+  #pragma unroll
+        for (int t2 = 0; t2 < NT; t2++) {
+  #pragma unroll
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
+  #pragma unroll
+          for (int q = 0; q < PPG; q++) piece((step * NT + t2) * PPG + q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      // N = 64 tile: 6 MFMAs per step and three waves per SIMD — occupancy hides the LDS latency, the second fragment set
+      // would cost a wave
 #pragma unroll
-    for (int slab = 0; slab < 2; slab++) {
-      s16x8 bv[TN][NPL];
-#pragma unroll
-      for (int pl = 0; pl < NPL; pl++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-          bv[j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-#pragma unroll
-      for (int i = 0; i < TM; i++) {
-        s16x8 av[NPL];
+      for (int slab = 0; slab < 2; slab++) {
+        s16x8 bv[TN][NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; pl++)
-          av[pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
 #pragma unroll
-        for (int t2 = 0; t2 < NT; t2++) {
+          for (int j = 0; j < TN; j++)
+            bv[j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
 #pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
+        for (int i = 0; i < TM; i++) {
+          s16x8 av[NPL];
 #pragma unroll
-          for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int pl = 0; pl < NPL; pl++)
+            av[pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
+#pragma unroll
+          for (int t2 = 0; t2 < NT; t2++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
+#pragma unroll
+            for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -536,7 +582,8 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
     store_b();
     if (new_chunk) store_h();
     __syncthreads();
-    tap = new_chunk ? 0 : tap + 1;
+    ty = ld_ty; tx = ld_tx;
+    ld_advance(kk + 1);
   }
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
 }
@@ -616,8 +663,8 @@ __device__ __forceinline__ int tr_swz(int k, int granule) {
   return k * ROWS + (((pair ^ sw) << 1) | (granule & 1)) * 8;
 }
 
-template <int BM, int BN, int WM, int WN, int NPL, bool F16>
-__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_wgrad_kernel(const PlWgradParams p) {
+template <int BM, int BN, int WM, int WN, int NPL, bool F16, bool PIPE = false>
+__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ? 2 : 3) : 1) void igemm_pl_wgrad_kernel(const PlWgradParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
@@ -738,9 +785,9 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   const int l31 = lane & 31;
   for (int kt = kt0; kt < kt1; kt++) {
     const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;   // past the last tile: every load is out of range (zeros)
-#pragma unroll
-    for (int slab = 0; slab < 2; slab++) {
-      s16x8 av[TM][NPL], bv[TN][NPL];
+    s16x8 av[PIPE ? 2 : 1][TM][NPL], bv[PIPE ? 2 : 1][TN][NPL];
+    auto read_slab = [&](int slab) {
+      const int q = PIPE ? slab : 0;
 #pragma unroll
       for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
@@ -748,24 +795,32 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
           const unsigned short* b0 = Ah + pl * A_PLANE + a_rd[i] + (16 * slab) * BM;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BM));
-          av[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          av[q][i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
           const unsigned short* b0 = Bh + pl * B_PLANE + b_rd[j] + (16 * slab) * BN;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BN));
-          bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          bv[q][j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
+    };
+    // PIPE: both K16 slabs' fragments are requested before the first MFMA (the second set lands under the first slab's
+    // MFMAs; two waves per SIMD).  Otherwise one set at a time (three waves per SIMD hide the read latency).
+    if constexpr (PIPE) { read_slab(0); read_slab(1); }
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++) {
+      if constexpr (!PIPE) read_slab(slab);
+      const int q = PIPE ? slab : 0;
 #pragma unroll
       for (int t = 0; t < NT; t++) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], t);
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[q][i], bv[q][j], acc[i][j], t);
 #pragma unroll
-        for (int q = 0; q < PPG; q++) piece((slab * NT + t) * PPG + q, ktn);
+        for (int q2 = 0; q2 < PPG; q2++) piece((slab * NT + t) * PPG + q2, ktn);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -963,7 +1018,7 @@ int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
 // ---- halo kernel: eligibility, plan, launch
 inline bool pl_halo_ok(const GatherGeom& p) {
   static const bool off = getenv("UNFLOW_NO_HALO") && atoi(getenv("UNFLOW_NO_HALO")) != 0;     // A/B knob
-  if (off || p.sm != 1 || (p.dstep != 1 && p.dstep != -1) || p.Hg < 16 || p.Wg < 16 || p.N <= 32) return false;
+  if (off || p.sm != 1 || (p.dstep != 1 && p.dstep != -1) || p.Hg < 2 * TH || p.Wg < TW || p.N <= 32) return false;
   for (int c = 0; c < p.ncls; c++)
     if (p.cls[c].nty < 1 || p.cls[c].ntx < 1 || (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1) > 256) return false;
   return true;
@@ -1065,16 +1120,21 @@ inline size_t pl_wgrad_partial_bytes(const WgradGeom& p, int ca_out, int nsplit)
   return nsplit > 1 ? (size_t)nsplit * n * sizeof(float) + reduce_scratch_bytes(n, nsplit) : 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+template <int BM, int BN, int WM, int WN, int NPL, bool F16, bool PIPE = false>
 int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = NPL * (BM + BN) * BK * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
   dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
-  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(p);
+  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE><<<grid, 256, smem, st>>>(p);
   return launch_status();
+}
+
+inline bool pl_wgrad_pipe() {   // UNFLOW_WGRAD_PIPE=1: both slabs' fragments in flight, two waves per SIMD (A/B knob)
+  static const bool on = getenv("UNFLOW_WGRAD_PIPE") && atoi(getenv("UNFLOW_WGRAD_PIPE")) != 0;
+  return on;
 }
 
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
@@ -1090,7 +1150,9 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
   *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
   const int cfg = pl_wgrad_cfg(p);
   int code;
-  if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
+  if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st)
+                     : pl_wgrad_pipe() ? launch_pl_wgrad<128, 128, 64, 64, 3, false, true>(p, st)
+                                       : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
   if (code != UNFLOW_OK) return code;
   if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);
