@@ -46,6 +46,7 @@ struct PlGatherParams : GatherGeom {
   int leaky, accumulate;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
+  int dbg;                     // ablation switches (UNFLOW_DBG env; 0 in production): 1 no loads in the loop, 2 no LDS stores
   PlaneOut pl;
 };
 
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   };
   constexpr int NPIECE = AR + NB + 2;
   auto piece = [&](int step) {
+    if (p.dbg & 1) return;
     if (step == 0) piece_begin();
     if (step >= 1 && step <= AR) piece_a(step - 1);
     if (step > AR && step <= AR + NB) piece_b(step - AR - 1);
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
       }
     }
     __syncthreads();  // every wave is done reading this tile
-    store_tile();     // (last iteration: zeros, never read)
+    if (!(p.dbg & 2)) store_tile();     // (last iteration: zeros, never read)
     __syncthreads();
   }
 
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
     const int tapoff = (hyi * HC + hxi) * HPITCH;
     const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
     auto piece = [&](int step) {
+      if (p.dbg & 1) return;
       if (step < NB) load_b(step);
       else if (step < NB + NH && new_chunk) load_h(step - NB);
     };
@@ -579,8 +582,10 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
       }
     }
     __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
-    store_b();
-    if (new_chunk) store_h();
+    if (!(p.dbg & 2)) {
+      store_b();
+      if (new_chunk) store_h();
+    }
     __syncthreads();
     ty = ld_ty; tx = ld_tx;
     ld_advance(kk + 1);
@@ -650,6 +655,7 @@ struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multi
   int lds, ldd;
   int Ca_out;                  // rows per tap of dW (the weight tensor's own channel padding, <= Ca)
   int nsplit;
+  int dbg;
   unsigned cag_magic;          // ceil(2^32 / (Ca/8))
 };
 
@@ -736,10 +742,12 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
   };
   constexpr int NPIECE = AR + BR;
   auto piece = [&](int step, int kt) {
+    if (p.dbg & 1) return;
     if (step < AR) piece_a(step, kt);
     else if (step < AR + BR) piece_b(step - AR, kt);
   };
   auto store_tile = [&]() {
+    if (p.dbg & 2) return;
 #pragma unroll
     for (int i = 0; i < AR; i++)
 #pragma unroll
@@ -1059,7 +1067,13 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   return launch_status();
 }
 
+inline int pl_dbg() {
+  static const int dbg = getenv("UNFLOW_DBG") ? atoi(getenv("UNFLOW_DBG")) : 0;
+  return dbg;
+}
+
 int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStream_t st) {
+  p.dbg = pl_dbg();
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
   PlPlan pl = plan_pl_gather(p, npl);
@@ -1138,6 +1152,7 @@ inline bool pl_wgrad_pipe() {   // UNFLOW_WGRAD_PIPE=1: both slabs' fragments in
 }
 
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
+  p.dbg = pl_dbg();
   p.cag_magic = p.Ca == 8 ? 0u : magic_u32((unsigned)(p.Ca >> 3));   // 2^32 / 1 does not fit: 0 marks 'no division'
   const size_t wsize = (size_t)p.KH * p.KW * p.Ca_out * p.Cb;
   int ns = plan_pl_wgrad(p, npl);
