@@ -91,7 +91,7 @@ def main():
     import torch
     import torch.distributed as dist
     from unflow_amd.core.engine import FlowNetCEngine
-    from unflow_amd.core.data_parallel import GradAllReducer
+    from unflow_amd.core.train import StepRunner
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,66 +108,30 @@ def main():
     B, H, W = args.batch, args.height, args.width
     from unflow_amd.core.engine import DEFAULT_PARAMS
     eng = FlowNetCEngine(B, H, W, params=dict(DEFAULT_PARAMS, flownet=args.flownet), device=dev, seed=0)   # same weights on every rank
-    eng.defer_l2 = True      # the L2 term of the loss is accumulated by the Adam kernel's pass over the parameters
     g = torch.Generator().manual_seed(1234 + rank)               # distinct shard per rank
     NBATCH = 4                                                   # raw minibatches resident in HBM, rotated through
     batches = [((torch.rand(B, H, W, 3, generator=g) * 255).to(dev), (torch.rand(B, H, W, 3, generator=g) * 255).to(dev))
                for _ in range(NBATCH)]
-    reducer = GradAllReducer(eng.G, world, force=force_dist) if (world > 1 or force_dist) else None
     lr = 1e-4
     parity = None
     if rank == 0 and world == 1 and args.flownet == 'C' and not args.no_parity:
         parity = measure_parity(eng, batches[0])      # step-1 loss and flows vs the CPU oracle, BEFORE any timing
     step_no = [0]
-
-    graphs = None
-    early, late = eng.grad_buckets()
-
-    def part_a():       # forward, losses, backward of the decoder and conv6_1..conv4 (94 % of the gradient bytes)
-        eng.forward_net()
-        eng.forward_loss(with_grad=True)
-        eng.backward_net(0)
-
-    def part_b():       # backward of conv3_1 .. conv1 + bias gradients (~3 ms: hides the big bucket's exchange)
-        eng.backward_net(1)
+    # forward + loss + backward as hipGraph replays; with more than one rank the backward pass is cut into parts, and each
+    # part's gradients are all-reduced and Adam-updated on the communication stream under the rest of the backward pass
+    # (unflow_amd/core/train.py).  One rank: one graph, one Adam launch.
+    runner = StepRunner(eng, world, use_graph=not args.no_graph, force_reducer=force_dist)
 
     def step():
         # input preparation is part of the step (unsupervised.py:29-31,67-68): next raw minibatch -> /255, mean
         # subtraction (eager launches in front of the graph replay)
-        eng.set_input(*batches[step_no[0] % NBATCH])
+        im1, im2 = batches[step_no[0] % NBATCH]
         step_no[0] += 1
-        if graphs is not None:
-            graphs[0].replay()
-        else:
-            part_a()
-        if reducer is not None:
-            reducer.start_ranges(early)
-        if graphs is not None:
-            graphs[1].replay()
-        else:
-            part_b()
-        if reducer is not None:
-            reducer.start_ranges(late)
-            reducer.finish()
-        eng.adam_step(lr, grad_scale=1.0 / world)
+        runner.step(im1, im2, lr)
 
-    # first eager step grows the workspaces; then capture fwd+loss+bwd (~230 launches) into two hipGraphs (the
-    # gradient exchange of the first, large bucket is launched between them)
-    step()
+    step()      # captures the graphs (an eager pass first grows the workspaces), then runs the first step
     torch.cuda.synchronize()
-    if not args.no_graph:
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            part_a()
-            part_b()
-        torch.cuda.current_stream().wait_stream(s)
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            part_a()
-        with torch.cuda.graph(gb, pool=ga.pool()):
-            part_b()
-        graphs = (ga, gb)
+    graphs = runner.graphs
     for _ in range(args.warmup):
         step()
 

@@ -351,8 +351,10 @@ typedef struct unflow_planes {
   int n_planes;
 } unflow_planes;
 
-/* fp32 [npix][ldx] (C channels) -> planes; channels C .. round_up_8(C)-1 are zero-filled. */
-int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, const unflow_planes* out, unflow_stream_t stream);
+/* fp32 [npix][ldx] (C channels) -> planes; plane channels C .. C_fill-1 are zero-filled (C <= C_fill <= round_up_8(C),
+ * C_fill a multiple of 4: a slice that ends the buffer row before the next multiple of 8 passes the row's end). */
+int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, int C_fill, const unflow_planes* out,
+                           unflow_stream_t stream);
 
 /* Planes of weight tensors W[taps][R][Cc] (conv: HWIO, R = Cin, Cc = Cout; conv_transpose: R = Cout, Cc = Cin):
  *   direct[i]     [p][tap][R][round_up_8(Cc)]  — operand of conv2d_bwd_data_pl and conv2d_transpose_fwd_pl

@@ -153,3 +153,51 @@ def test_engine_layer_table_matches_reference_variables():
     assert n_logical == 39175298
     assert engine.LAYER_WEIGHTS == [12.7, 4.35, 3.9, 3.4, 1.1] and engine.LAYER_PATCH_DISTANCES == [3, 2, 2, 1, 1]
     assert engine.LAYER_WEIGHTS_FULL_RES == [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]
+
+
+def _worker_buckets(rank, world, port, out_dir):
+    """The bucketed exchange over the ENGINE's flat gradient layout: every part's ranges are all-reduced, then the part's
+    optimizer callback runs (StepRunner's order), on gloo."""
+    _init(rank, world, port)
+    from unflow_amd.core.data_parallel import GradAllReducer
+    from unflow_amd.core.engine import FlowNetEngine
+    from unflow_amd.core.train import DEFAULT_BUCKET_CUTS
+    eng = FlowNetEngine(1, 64, 64, params=dict(flownet='CS'), device='cpu', layout_only=True)
+    nparts = eng.set_backward_parts(DEFAULT_BUCKET_CUTS)
+    buckets, frozen = eng.part_buckets(), eng.frozen_ranges()
+    g = torch.Generator().manual_seed(100 + rank)
+    eng.G.copy_(torch.randn(eng.n_params, generator=g))
+    for lo, hi in frozen:
+        eng.G[lo:hi] = 0                                  # frozen networks: zero data gradient on every rank
+    local = eng.G.clone()
+    red = GradAllReducer(eng.G, world, bucket_bytes=1 << 20)
+    seen = torch.zeros(eng.n_params, dtype=torch.int32)
+    order = []
+    for k in range(nparts):
+        def fn(r=buckets[k], k=k):
+            for lo, hi in r:
+                seen[lo:hi] += 1
+                order.append((k, lo, hi, eng.G[lo:hi].clone()))
+        red.reduce_then(buckets[k], fn)
+    red.finish()
+    for lo, hi in frozen:
+        seen[lo:hi] += 1
+    torch.save(dict(local=local, reduced=eng.G.clone(), seen=seen, nparts=nparts, buckets=buckets, frozen=frozen,
+                    at_callback=[(k, lo, hi, t) for k, lo, hi, t in order]), os.path.join(out_dir, "b%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_engine_buckets_cover_the_gradient_once_and_reduce_to_the_sum(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_buckets, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "b%d.pt" % i)) for i in range(2)]
+    want = r[0]['local'] + r[1]['local']
+    for i in range(2):
+        assert r[i]['nparts'] == 3
+        assert torch.all(r[i]['seen'] == 1)               # buckets + frozen ranges: a partition of the flat buffer
+        assert torch.equal(r[i]['reduced'], want)         # gloo SUM is exact: same order on both ranks
+        for k, lo, hi, t in r[i]['at_callback']:          # the optimizer callback of a bucket saw the REDUCED gradient
+            assert torch.equal(t, want[lo:hi])
+    # the first bucket is the big one (decoder + conv6_1 + conv6): it leaves while two thirds of the backward pass remain
+    (lo, hi), = r[0]['buckets'][0]
+    assert (hi - lo) * 4 > 100e6

@@ -64,6 +64,29 @@ class GradAllReducer:
                 else:
                     dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
 
+    def reduce_then(self, ranges, fn):
+        """Enqueue on the side stream: the SUM all-reduce of flat ranges [(lo, hi), ...] (ordered after everything the
+        current stream has queued so far), then fn() — launched with the side stream current, i.e. ordered after the
+        exchange and running concurrently with whatever the compute stream does next (the bucketed optimizer update:
+        train.py StepRunner).  Returns immediately; finish() joins."""
+        if self.world <= 1 and not self.force:
+            fn()
+            return
+        if not self.cuda:
+            for lo, hi in ranges:
+                for a in range(lo, hi, self.per):
+                    dist.all_reduce(self.g[a:min(hi, a + self.per)], op=dist.ReduceOp.SUM, group=self.group)
+            fn()
+            return
+        cur = torch.cuda.current_stream(self.g.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            works = [dist.all_reduce(self.g[a:min(hi, a + self.per)], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for lo, hi in ranges for a in range(lo, hi, self.per)]
+            for w in works:
+                w.wait()          # stream-level: the side stream waits for the collective, the host does not
+            fn()
+
     def finish(self):
         if self.world <= 1 and not self.force:
             return

@@ -267,7 +267,25 @@ class _Stage:
                     act_lo, act_hi = rng[0][0], rng[-1][1]
             self.bwd.append((op, first, act_lo, act_hi))
         names = [op.l.name.split('/')[-1] if op.kind == 'layer' else 'corr' for op, _, _, _ in self.bwd]
+        self.bwd_names = names
         self.split_at = names.index('conv4') + 1            # part 0 = [0, split_at): decoder + conv6_1 .. conv4
+        self.part_bounds = [0, self.split_at, len(self.bwd)]
+
+    def set_parts(self, last_layers):
+        """Cut the backward list after each of the named layers (in backward order), e.g. ('conv6', 'conv4'):
+        part 0 = decoder + conv6_1 + conv6, part 1 = conv5_1 .. conv4, part 2 = the rest."""
+        cuts = [self.bwd_names.index(n) + 1 for n in last_layers]
+        assert cuts == sorted(cuts) and (not cuts or cuts[-1] < len(self.bwd))
+        self.part_bounds = [0] + cuts + [len(self.bwd)]
+
+    def part_weight_range(self, part):
+        """Flat range of eng.G holding the filter gradients that are complete after backward(part) (the layers of a part
+        are a contiguous run of the forward order, hence of the flat weight region)."""
+        ls = [op.l for op, _, _, _ in self.bwd[self.part_bounds[part]:self.part_bounds[part + 1]] if op.kind == 'layer']
+        G = self.eng.G
+        lo = min(l.dw.data_ptr() for l in ls) - G.data_ptr()
+        hi = max(l.dw.data_ptr() + l.dw.numel() * 4 for l in ls) - G.data_ptr()
+        return lo // 4, hi // 4
 
     # -------------------------------------------------------------- buffers
     def alloc(self):
@@ -338,10 +356,11 @@ class _Stage:
 
     # -------------------------------------------------------------- backward
     def backward(self, part=None):
-        """part None: everything; 0: decoder + conv6_1..conv4 (94 % of the parameters — their gradients are final
-        afterwards, so their all-reduce can start); 1: conv3_1 .. conv1."""
+        """part None: everything; k: the k-th slice of the backward list (default cuts: 0 = decoder + conv6_1..conv4 — 94 %
+        of the parameters, whose gradients are final afterwards so that their all-reduce can start — 1 = conv3_1 ..
+        conv1; set_parts() changes the cuts)."""
         e = self.eng
-        lo, hi = {None: (0, len(self.bwd)), 0: (0, self.split_at), 1: (self.split_at, len(self.bwd))}[part]
+        lo, hi = (0, len(self.bwd)) if part is None else (self.part_bounds[part], self.part_bounds[part + 1])
         B, N = e.B, e.N
         for op, first, act_lo, act_hi in self.bwd[lo:hi]:
             if op.kind == 'corr':
@@ -364,7 +383,9 @@ class _Stage:
             else:
                 L.deconv_bwd_filter(x, dz, l.dw)
             sb = op.src[0]
-            if sb == 'x0' or sb not in self.Gd or (sb == self.bin and not self.need_in_grad):
+            is_input = sb == 'x0' or (sb == self.bin and op.src[1] == 0 and op.src[2] == pad4(self.in_ch)
+                                      and op.l.name.endswith('conv1'))
+            if sb not in self.Gd or (is_input and not self.need_in_grad):
                 continue                              # inputs are data (or behind stop_gradient, flownet.py:51-54)
             dx = self.pt(op.src, True)
             # the loss wrote d flowN first (flow buffers): everything after it accumulates
@@ -386,7 +407,9 @@ class FlowNetEngine:
     into the earlier networks.  params['full_res'] adds the full-resolution decoder levels to the LAST network
     (flownet.py:21,133-153; a FlowNetS) and the loss pyramid then has 7 levels (unsupervised.py:89-96)."""
 
-    def __init__(self, batch, height, width, params=None, device=None, seed=0):
+    def __init__(self, batch, height, width, params=None, device=None, seed=0, layout_only=False):
+        """layout_only: build the layer table and the flat parameter / gradient buffers (on `device`, which may then be the
+        CPU) but no activations — for tools and the data-parallel tests that only need the flat layout and its buckets."""
         assert height % 64 == 0 and width % 64 == 0, "FlowNet needs H, W divisible by 64"
         self.params = dict(DEFAULT_PARAMS) if params is None else dict(params)
         if self.params.get('mask_occlusion', '') not in ('', 'fb', 'disocc'):   # unsupervised.py:125-126
@@ -402,22 +425,26 @@ class FlowNetEngine:
         self.dev = torch.device('cuda:0') if device is None else torch.device(device)
         self.math = conv_math_mode()
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
-        with torch.cuda.device(self.dev):
+        if layout_only:
+            self.n_planes = 0
+        import contextlib
+        with (torch.cuda.device(self.dev) if self.dev.type == 'cuda' else contextlib.nullcontext()):
             self.stages = [_Stage(self, k, i, self.full_res and i == len(spec) - 1) for i, k in enumerate(spec)]
             for st in self.stages[:-1]:
                 st.trainable = self.train_all
             self.layers = [l for st in self.stages for l in st.layers]
             self.by_name = self.stages[-1].by_name
             self._alloc_params()
-            self._alloc_activations()
-            self._build_masks()
+            if not layout_only:
+                self._alloc_activations()
+                self._build_masks()
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
         self.defer_l2 = False      # True: forward_loss leaves the L2 term to adam_step (train_step / bench)
         self.fused_pyramid = os.environ.get('UNFLOW_FUSED_PYRAMID', '1') != '0'   # default loss terms: 4 launches for all levels
         self._pyr_cache = None
         self._wplanes_version = None
-        if seed is not None:
+        if seed is not None and not layout_only:
             self.init_params(seed)
 
     def stream(self):
@@ -796,9 +823,10 @@ class FlowNetEngine:
     def backward_net(self, part=None):
         """Gradients of the trained (last) network; earlier stages are behind stop_gradient (flownet.py:51-54).
         part 0 / 1: the two halves used to overlap the data-parallel all-reduce (see grad_buckets)."""
+        last_part = len(self.stages[-1].part_bounds) - 2
         with torch.cuda.device(self.dev):
             self.stages[-1].backward(part)
-            if part in (None, 1):
+            if part in (None, last_part):
                 if self.train_all:
                     for i in range(len(self.stages) - 1, 0, -1):
                         self._stack_backward(self.stages[i], self.stages[i - 1])
@@ -817,17 +845,54 @@ class FlowNetEngine:
                                                 self.H, self.W, pf.shape[1], pf.shape[2], cf(4 * FLOW_SCALE),
                                                 self.stream()), "stack_input_bwd")
 
-    def grad_buckets(self):
-        """Flat ranges of self.G: (early, late).  `early` = the weights whose gradients are complete after
-        backward_net(0) (conv4 .. flow2 of the trained network: a contiguous tail of the weight region);
-        `late` = everything else (conv1 .. conv3_1 weights, all biases, and the never-written zeros of frozen stages)."""
-        if self.train_all:      # earlier networks are still accumulating until the very end
-            return [], [(0, self.n_params)]
+    def set_backward_parts(self, last_layers=('conv4',)):
+        """Cut the trained network's backward pass after the named layers (see _Stage.set_parts); returns the part count."""
+        self.stages[-1].set_parts(tuple(last_layers))
+        return len(self.stages[-1].part_bounds) - 1
+
+    def part_buckets(self):
+        """One list of flat ranges of self.G per backward part: the gradients that are FINAL once backward_net(part) has
+        run, so that their all-reduce (and their Adam update) may start while the later parts still compute.  The last
+        part also carries everything else: the biases (their column sums are the last launch) and the parameters of
+        frozen / earlier stages (train_all: earlier networks accumulate until the very end, so one bucket)."""
         st = self.stages[-1]
-        first = st.by_name['conv4']
-        lo = first.dw.data_ptr() - self.G.data_ptr()
-        lo //= 4
-        return [(lo, self.n_weights)], [(0, lo), (self.n_weights, self.n_params)]
+        nparts = len(st.part_bounds) - 1
+        if self.train_all:
+            return [[] for _ in range(nparts - 1)] + [[(0, self.n_params)]]
+        out, covered = [], []
+        for k in range(nparts):
+            lo, hi = st.part_weight_range(k)
+            out.append([(lo, hi)])
+            covered.append((lo, hi))
+        covered += self.frozen_ranges()
+        covered.sort()
+        rest, pos = [], 0
+        for lo, hi in covered:
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.n_params:
+            rest.append((pos, self.n_params))
+        out[-1] = out[-1] + rest
+        return out
+
+    def frozen_ranges(self):
+        """Flat weight ranges of the networks behind stop_gradient (flownet.py:51-54): their data gradient is identically
+        zero on every rank — nothing to exchange (train.py:388-422 skips None gradients) — but the optimizer still
+        applies the L2 term to them."""
+        if self.train_all:
+            return []
+        out = []
+        for stg in self.stages[:-1]:
+            lo = min(l.dw.data_ptr() for l in stg.layers) - self.G.data_ptr()
+            hi = max(l.dw.data_ptr() + l.dw.numel() * 4 for l in stg.layers) - self.G.data_ptr()
+            out.append((lo // 4, hi // 4))
+        return out
+
+    def grad_buckets(self):
+        """(early, late) flat ranges for the default two-part cut (kept for callers of the two-part API)."""
+        pb = self.part_buckets()
+        return [r for part in pb[:-1] for r in part], pb[-1]
 
     def _bias_grads(self):
         """db = column sums of every layer's dz, batched (unflow_colsum_batched)."""
@@ -854,6 +919,30 @@ class FlowNetEngine:
                   "colsum_batched")
 
     # ------------------------------------------------------------------ optimiser
+    def adam_begin(self, lr, beta1=0.9, beta2=0.999):
+        """Start optimizer step t: returns the TF-form step size lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) for
+        adam_range() calls (bucketed update: each flat range as soon as its reduced gradient has landed)."""
+        self.step_count += 1
+        t = self.step_count
+        self._wplanes_version = None
+        return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+    def adam_range(self, lo, hi, lr_t, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """The fused L2 + Adam update of flat range [lo, hi) on the CURRENT stream (weights first in the flat layout: the
+        regularised prefix of the range is what lies below n_weights)."""
+        if hi <= lo:
+            return
+        nreg = max(0, min(hi, self.n_weights) - lo)
+        sl = lambda t: ptr(t[lo:hi])                                        # noqa: E731
+        if self.defer_l2:
+            check(_lib.lib().unflow_adam_step_regloss(sl(self.P), sl(self.G), sl(self.M), sl(self.V), cl(hi - lo), cl(nreg),
+                                                      cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1), cf(beta2), cf(eps),
+                                                      ptr(self.loss_acc), self.stream()), "adam")
+        else:
+            check(_lib.lib().unflow_adam_step(sl(self.P), sl(self.G), sl(self.M), sl(self.V), cl(hi - lo), cl(nreg),
+                                              cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1), cf(beta2), cf(eps),
+                                              self.stream()), "adam")
+
     def adam_step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
         """tf.train.AdamOptimizer(beta1=0.9, beta2=0.999) update (train.py:151-152), TF formulation, with the
         slim.l2_regularizer(0.0004) gradient added for the weight tensors (biases are not regularised)."""

@@ -178,8 +178,10 @@ def _npl(*pts):
 def planes_from_f32(x, out_pl, C=None):
     """Fill the planes view `out_pl` [P,N,H,W,>=round8(C)] from the fp32 NHWC tensor / slice x (pad channels zeroed)."""
     xp, ldx, B, H, W, Cx = nhwc(x)
-    check(_lib.lib().unflow_planes_from_f32(xp, ldx, _lib.cl(B * H * W), Cx if C is None else C, _lib.planes_of(out_pl),
-                                            stream()), "planes_from_f32")
+    C = Cx if C is None else C
+    fill = min(round8(C), out_pl.shape[-1])         # a slice may end the buffer row before the next multiple of 8
+    check(_lib.lib().unflow_planes_from_f32(xp, ldx, _lib.cl(B * H * W), C, fill, _lib.planes_of(out_pl), stream()),
+          "planes_from_f32")
 
 
 def conv_fwd(x, w, w_pl, bias, y, stride, leaky):

@@ -1,15 +1,28 @@
-"""Mirror of the hot-path parts of src/e2eflow/core/train.py: optimizer + tower/gradient averaging
-(get_train_and_loss_ops :147-185, average_gradients :388-422) and the learning-rate schedule (:225-244).
-Checkpoint restore, evaluation and TF summaries (:23-65, :265-385) are out of scope."""
+"""Mirror of the hot-path parts of src/e2eflow/core/train.py: the training op (get_train_and_loss_ops :147-185:
+AdamOptimizer + towers + average_gradients :388-422), the learning-rate schedule (:225-244) and the loop body
+(:247-251).  Checkpoint restore, evaluation and TF summaries (:23-65, :265-385) are out of scope.
+
+One process per GPU.  A training step is
+
+    set_input (+ augmentation)                        eager launches
+    forward + losses + backward part 0                hipGraph replay
+      -> all-reduce of part 0's gradients, then their fused L2 + Adam update      } on the communication stream,
+    backward part 1 ...                               hipGraph replay             } under the remaining backward
+      -> all-reduce + Adam of part 1 ...
+    join
+
+so the optimizer update of a bucket overlaps the exchange and the backward pass of the earlier layers (a layer's weights are
+only read by its own forward / data-gradient launches, which are complete when its bucket is released).  With one rank
+there is no exchange: one graph, one Adam launch."""
 import torch
 import torch.distributed as dist
 
 from .data_parallel import GradAllReducer
-from .engine import FlowNetCEngine
+from .engine import FlowNetEngine
 
 
 def learning_rate_at(params, decay_iters):
-    """train.py:225-244."""
+    """train.py:225-244: the manual piecewise schedule has priority; else halve every decay_interval after decay_after."""
     if 'manual_decay_lrs' in params and 'manual_decay_iters' in params:
         decay_index, iter_counter = 0, 0
         for decay_i, manual_decay_iter in enumerate(params['manual_decay_iters']):
@@ -18,6 +31,8 @@ def learning_rate_at(params, decay_iters):
                 decay_index = decay_i
                 break
         return params['manual_decay_lrs'][decay_index]
+    if 'decay_interval' not in params:
+        return params['learning_rate']
     decay_interval = params['decay_interval']
     decay_after = params.get('decay_after', 0)
     if decay_iters >= decay_after:
@@ -26,26 +41,116 @@ def learning_rate_at(params, decay_iters):
     return params['learning_rate']
 
 
-class Trainer:
-    """One process per GPU.  `params` carries the reference's [train] keys (learning_rate, decay_interval,
-    decay_after, loss weights ...).  With torch.distributed initialised, every rank trains on its own shard of the
-    minibatch and the gradients are averaged with one RCCL all-reduce (average_gradients semantics)."""
+# default cuts of the backward pass for the bucketed exchange (layers after which a bucket is released): decoder + conv6_1 +
+# conv6 (118 MB of FlowNetC's 157 MB of gradients), conv5_1 .. conv4 (33 MB), the rest + all biases
+DEFAULT_BUCKET_CUTS = ('conv6', 'conv4')
 
-    def __init__(self, batch_size, height, width, params, device=None, seed=0):
+
+class StepRunner:
+    """Runs training steps of an engine: hipGraph replay of forward + loss + backward (cut into parts when gradients are
+    exchanged), bucketed RCCL all-reduce and bucketed Adam on a communication stream.  Used by bench.py and Trainer."""
+
+    def __init__(self, engine, world=1, use_graph=True, force_reducer=False, bucket_cuts=DEFAULT_BUCKET_CUTS,
+                 bucket_bytes=64 << 20, group=None):
+        self.eng = engine
+        self.world = world
+        self.dist = world > 1 or force_reducer
+        self.reducer = GradAllReducer(engine.G, world, bucket_bytes=bucket_bytes, group=group, force=force_reducer) \
+            if self.dist else None
+        self.nparts = engine.set_backward_parts(bucket_cuts if (self.dist and not engine.train_all) else ())
+        self.buckets = engine.part_buckets()
+        self.frozen = engine.frozen_ranges()
+        self.use_graph = use_graph
+        self.graphs = None
+        engine.defer_l2 = True      # the L2 term of the loss rides on the pass Adam makes over the parameters
+
+    # ---- the pieces of a step
+    def _part(self, k):
+        e = self.eng
+        if k == 0:
+            e.forward_net()
+            e.forward_loss(with_grad=True)
+        e.backward_net(k)
+
+    def capture(self):
+        """One eager pass (grows the workspaces), then one hipGraph per backward part."""
+        e = self.eng
+        for k in range(self.nparts):
+            self._part(k)
+        torch.cuda.synchronize(e.dev)
+        if not self.use_graph:
+            return
+        s = torch.cuda.Stream(e.dev)
+        s.wait_stream(torch.cuda.current_stream(e.dev))
+        with torch.cuda.stream(s):
+            for k in range(self.nparts):
+                self._part(k)
+        torch.cuda.current_stream(e.dev).wait_stream(s)
+        graphs, pool = [], None
+        for k in range(self.nparts):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self._part(k)
+            pool = g.pool()
+            graphs.append(g)
+        self.graphs = graphs
+
+    def step(self, im1, im2, lr, augment=None):
+        """One optimisation step on the minibatch (im1, im2) [B,H,W,3] in [0,255]; returns the loss tensor [1] (complete
+        when the stream has drained)."""
+        e = self.eng
+        if self.graphs is None and self.use_graph:
+            e.set_input(im1, im2, augment=augment)
+            self.capture()
+        e.set_input(im1, im2, augment=augment)
+        lr_t = e.adam_begin(lr)
+        scale = 1.0 / self.world
+        if self.reducer is not None and self.frozen:
+            # frozen networks: zero data gradient everywhere, nothing to exchange; their L2 update runs on the side stream
+            self.reducer.reduce_then([], lambda: [e.adam_range(lo, hi, lr_t, scale) for lo, hi in self.frozen])
+        for k in range(self.nparts):
+            if self.graphs is not None:
+                self.graphs[k].replay()
+            else:
+                self._part(k)
+            if self.reducer is not None:
+                ranges = self.buckets[k]
+                self.reducer.reduce_then(ranges, lambda r=ranges: [e.adam_range(lo, hi, lr_t, scale) for lo, hi in r])
+        if self.reducer is not None:
+            self.reducer.finish()
+        else:
+            e.adam_range(0, e.n_params, lr_t, scale)
+        return e.loss_acc
+
+
+class Trainer:
+    """One process per GPU.  `params` carries the reference's [train] keys (learning_rate, decay_interval, decay_after,
+    manual_decay_*, flownet, train_all, full_res, loss weights, mask modes ...).  With torch.distributed initialised,
+    every rank trains on its own shard of the minibatch and the gradients are averaged with a bucketed RCCL all-reduce
+    (average_gradients semantics).  The training step augments like the reference's (unsupervised_loss(augment=True),
+    train.py:160,170); `augment=False` switches that off."""
+
+    ENGINE_KEYS = ('flownet', 'train_all', 'full_res', 'pyramid_loss', 'border_mask', 'mask_occlusion')
+
+    def __init__(self, batch_size, height, width, params, device=None, seed=0, augment=True, use_graph=True):
         self.params = dict(params)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        loss_params = {k: v for k, v in params.items()
-                       if k.endswith('_weight') or k in ('flownet', 'pyramid_loss', 'border_mask', 'mask_occlusion')}
-        self.engine = FlowNetCEngine(batch_size, height, width, params=loss_params or None, device=device, seed=seed)
-        self.reducer = GradAllReducer(self.engine.G, self.world) if self.world > 1 else None
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        eng_params = {k: v for k, v in params.items() if k.endswith('_weight') or k in self.ENGINE_KEYS}
+        self.engine = FlowNetEngine(batch_size, height, width, params=eng_params or None, device=device, seed=seed)
+        self.runner = StepRunner(self.engine, self.world, use_graph=use_graph)
+        self.augment = augment
+        self.generator = torch.Generator().manual_seed(1000003 * (seed + 1) + self.rank)   # per-rank augmentation draws
         self.iteration = 0
 
-    def train_step(self, im1, im2):
-        """sess.run([train_op, loss_]) (train.py:247-251): returns the loss tensor (device, no sync)."""
-        lr = learning_rate_at(self.params, self.iteration) if 'decay_interval' in self.params else self.params['learning_rate']
-        loss = self.engine.fwd_bwd(im1, im2)
-        if self.reducer is not None:
-            self.reducer.all_reduce()
-        self.engine.adam_step(lr, grad_scale=1.0 / self.world)
+    def train_step(self, im1, im2, augment=None):
+        """sess.run([train_op, loss_]) (train.py:247-251): returns the loss tensor (device, no sync).  `augment`: None = the
+        trainer's setting (random draws per step), False = off, or a dict of draws to replay."""
+        lr = learning_rate_at(self.params, self.iteration)
+        aug = self.augment if augment is None else augment
+        if aug is True:
+            from .augment import draw_training_augmentation
+            aug = draw_training_augmentation(self.engine.B, self.generator)
+        loss = self.runner.step(im1, im2, lr, augment=aug or None)
         self.iteration += 1
         return loss

@@ -18,7 +18,7 @@ def unsupervised_loss(batch, params, normalization=None, augment=True, return_fl
             raise NotImplementedError("custom channel means")
     im1, im2 = batch
     B, H, W, _ = im1.shape
-    eng = engine or get_engine(B, H, W, params=params, device=im1.device)
+    eng = engine or get_engine(B, H, W, params=params, device=im1.device)     # flownet / full_res / train_all / loss keys
     if augment is True:
         from .augment import draw_training_augmentation
         augment = draw_training_augmentation(B, generator)

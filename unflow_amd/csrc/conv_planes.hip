@@ -859,9 +859,8 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
 }
 
 // ------------------------------------------------------------------------------------------------ plane producers
-// fp32 [npix][ldx] (C channels used) -> planes [npix][ldp] with channels C .. Cp-1 zero-filled (Cp = round-up-8 of C, <= ldp)
-__global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, long npix, int C, PlaneOut o) {
-  const int Cp = (C + 7) & ~7;
+// fp32 [npix][ldx] (C channels used) -> planes [npix][ldp] with channels C .. Cp-1 zero-filled (Cp a multiple of 4, >= C)
+__global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, long npix, int C, int Cp, PlaneOut o) {
   const int nq = Cp >> 2;
   const long total = npix * nq;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -1213,13 +1212,15 @@ int unflow_conv2d_transpose_bwd_data_po(const float* dz, int lddz, const float* 
                                         unflow_stream_t stream);
 
 // ===================================================================== C ABI
-UNFLOW_API int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, const unflow_planes* out,
+UNFLOW_API int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, int C_fill, const unflow_planes* out,
                                       unflow_stream_t stream) {
   if (!x || !out || !out->base) return UNFLOW_ERR_NULL;
   if (npix <= 0 || C <= 0) return UNFLOW_OK;
-  if (!planes_ok(out, C) || ldx < C) return UNFLOW_ERR_UNSUPPORTED;
-  const int Cp = (C + 7) & ~7;
-  planes_from_f32_kernel<<<stream_grid(npix * (Cp / 4)), 256, 0, as_stream(stream)>>>(x, ldx, npix, C, plane_out(out, 0, Cp));
+  const int Cp = (C_fill + 3) & ~3;
+  if ((out->n_planes != 1 && out->n_planes != 3) || out->ld % 4 != 0 || (reinterpret_cast<uintptr_t>(out->base) & 7) != 0 ||
+      ldx < C || Cp < C || Cp > ((C + 7) & ~7) || out->ld < Cp)
+    return UNFLOW_ERR_UNSUPPORTED;
+  planes_from_f32_kernel<<<stream_grid(npix * (Cp / 4)), 256, 0, as_stream(stream)>>>(x, ldx, npix, C, Cp, plane_out(out, 0, Cp));
   return launch_status();
 }
 
