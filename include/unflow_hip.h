@@ -351,6 +351,14 @@ typedef struct unflow_planes {
   int n_planes;
 } unflow_planes;
 
+/* unflow_correlation_nhwc_fwd with the features' operand planes (n_planes == 3, kernel_size 1, stride_1 1, C % 16 == 0):
+ * the products run on the bf16 matrix cores (six terms, fp32 accumulation).  Falls back to the fp32 entry point when the
+ * planes are NULL / unusable (then in0 / in1 must be given). */
+int unflow_correlation_nhwc_fwd_pl(const float* in0, const float* in1, int ld_in, const unflow_planes* in0_pl,
+                                   const unflow_planes* in1_pl, int pair_shift, float* out, int ld_out, int B, int C,
+                                   int H, int W, int kernel_size, int max_displacement, int pad, int stride_1,
+                                   int stride_2, unflow_stream_t stream);
+
 /* fp32 [npix][ldx] (C channels) -> planes; plane channels C .. C_fill-1 are zero-filled (C <= C_fill <= round_up_8(C),
  * C_fill a multiple of 4: a slice that ends the buffer row before the next multiple of 8 passes the row's end). */
 int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, int C_fill, const unflow_planes* out,

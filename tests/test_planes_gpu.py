@@ -236,3 +236,36 @@ def test_planes_kernels_match_inline_split_bitwise_close(dev):
     y_in = torch.zeros(B, H, W, Cout, device=dev)
     L.conv2d_fwd(X.t, wd, None, y_in, 1, False)
     assert rel_err(y_pl, y_in) < 2e-6
+
+
+CORR_PL_CASES = [
+    # N (directed batch), C, H, W, attrs
+    (8, 256, 48, 64, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),   # the step's shape
+    (4, 96, 16, 24, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),    # 3/8-width features
+    (2, 64, 12, 40, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),      # 81 channels, 2 site tiles
+    (2, 32, 9, 11, dict(kernel_size=1, max_displacement=3, pad=5, stride_1=1, stride_2=1)),       # pad > displacement
+]
+
+
+@pytest.mark.parametrize("case", CORR_PL_CASES)
+def test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib):
+    """unflow_correlation_nhwc_fwd_pl (bf16 matrix cores, six-term split) vs the scalar C oracle of CorrelateData
+    (ops/correlation_op.cu.cc:51-117), paired like the training step (sample n with (n + N/2) % N)."""
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, ptr, stream
+    N, C, H, W, attrs = case
+    B = N // 2
+    rs = np.random.RandomState(zlib.crc32(str(case).encode()))
+    feat = torch.from_numpy(rs.randn(N, H, W, C).astype(np.float32))
+    F = make_pt(feat, dev, 3, extra=8)
+    oc, oh, ow = oracle_lib.correlation_out_shape(H, W, **attrs)
+    out = torch.zeros(N, oh, ow, oc + 3, device=dev)
+    a = attrs
+    check(_lib.lib().unflow_correlation_nhwc_fwd_pl(ptr(F.t), ptr(F.t), F.t.stride(2), _lib.planes_of(F.pl), _lib.planes_of(F.pl),
+                                                    B, ptr(out), oc + 3, N, C, H, W, a['kernel_size'], a['max_displacement'],
+                                                    a['pad'], a['stride_1'], a['stride_2'], stream()), "correlation_pl")
+    x = np.ascontiguousarray(feat.numpy().transpose(0, 3, 1, 2))
+    ref = oracle_lib.correlation(x, np.ascontiguousarray(np.roll(x, -B, axis=0)), **attrs)
+    got = out[..., :oc].permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert out[..., oc:].abs().max().item() == 0

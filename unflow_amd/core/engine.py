@@ -338,9 +338,10 @@ class _Stage:
                 c3, out = self.pt(op.src), self.pt(op.dst)
                 C = op.src[2] - op.src[1]
                 h8, w8 = e.H // 8, e.W // 8
-                check(_lib.lib().unflow_correlation_nhwc_fwd(ptr(c3.t), ptr(c3.t), c3.t.stride(2), B, ptr(out.t),
-                                                             out.t.stride(2), N, C, h8, w8, 1, 20, 20, 1, 2, e.stream()),
-                      "correlation")
+                c3pl = _lib.planes_of(c3.pl if e.n_planes == 3 else None)     # bf16 planes: the matrix-core path
+                check(_lib.lib().unflow_correlation_nhwc_fwd_pl(ptr(c3.t), ptr(c3.t), c3.t.stride(2), c3pl, c3pl, B,
+                                                                ptr(out.t), out.t.stride(2), N, C, h8, w8, 1, 20, 20, 1, 2,
+                                                                e.stream()), "correlation")
                 if out.pl is not None:       # operand planes of the cost volume for conv3_1 (pad channels zeroed)
                     L.planes_from_f32(out.t, out.pl)
                 continue

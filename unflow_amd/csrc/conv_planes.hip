@@ -254,12 +254,14 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   auto piece_a = [&](int i) {
     const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
     const bool inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-    const int voff = inb ? a_lin[i] + a_tile : OOB_MARK;
+    int voff = inb ? a_lin[i] + a_tile : OOB_MARK;
+    if (p.dbg & 4) voff = tid * 16 + i * 4096;      // ablation: perfectly coalesced (wrong) addresses, same load count
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
   };
   auto piece_b = [&](int i) {
-    const int voff = b_row[i] + w_tile;
+    int voff = b_row[i] + w_tile;
+    if (p.dbg & 4) voff = tid * 16 + i * 4096;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
   };
@@ -730,13 +732,15 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
     const int yg = (int)(q - bb * (unsigned)p.Hg);
     const int yb = yg * p.sm, xb = xg * p.sm;
     const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
-    const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
+    int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
+    if (p.dbg & 4) voff = tid * 16 + i * 4096;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
   };
   auto piece_b = [&](int i, int kt) {
     const int sidx = kt * BK + bk + BKS * i;
-    const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
+    int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
+    if (p.dbg & 4) voff = tid * 16 + i * 4096;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(dst_rs[pl], voff);
   };

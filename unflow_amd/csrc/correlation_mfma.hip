@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma_kernel(const CorrMfmaParams
   // f0 fragment source (clamped; masked by a select): it is RE-READ from L1/L2 in NCH chunks per Gram instead of
   // living in C/2 registers for the whole kernel — 244 VGPRs allowed only 2 waves per SIMD, i.e. 1.5 rounds for the
   // 3072 waves of the FlowNetC shape.
-  constexpr int NCH = C >= 128 ? 2 : 1;        // channel chunks per Gram
-  constexpr int CQ = C / 8 / NCH;              // float4 loads per chunk
+  // C == 0: channel count at run time (any multiple of 32), chunks of 32 channels
+  constexpr int NCH_C = C >= 128 ? 2 : 1;      // channel chunks per Gram
+  constexpr int CQ = C == 0 ? 4 : C / 8 / NCH_C;   // float4 loads per chunk
+  const int NCH = C == 0 ? p.C / 32 : NCH_C;
   const float* asrc;
   bool aok;
   {
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma_kernel(const CorrMfmaParams
     aok = ox < p.ow && (unsigned)x0 < (unsigned)p.W && (unsigned)y0 < (unsigned)p.H;
     asrc = p.in0 + (((size_t)n * p.H + (aok ? y0 : 0)) * p.W + (aok ? x0 : 0)) * p.ld_in + 4 * h;
   }
-  const float cf = (float)C;
+  const float cf = (float)(C == 0 ? p.C : C);
   const int per = (p.gw + 3) >> 2;
   // the short last share (gw = 21: 6,6,6,3) rotates over the waves — wave w of every block sits on SIMD w, a fixed
   // assignment would leave one SIMD of each CU with half the work
@@ -224,7 +226,7 @@ CorrMfmaParams base_params(int B, int C, int H, int W, const CorrGeom& g) {
 
 int corr_mfma_supported(const CorrGeom& g, int C, int ld_in) {
   if (g.k != 1 || g.s1 != 1) return 0;
-  if (!(C == 64 || C == 128 || C == 256)) return 0;
+  if (C % 32 != 0 || C < 32 || C > 512) return 0;     // 3/8-width FlowNetC: C = 96 (flownet.py:22-23)
   if (ld_in % 4 != 0) return 0;
   if (g.md - g.pad > 0) return 0;  // never valid for the reference geometry (output would be empty) — keep it simple
   return 1;
@@ -235,9 +237,14 @@ int corr_mfma_fwd(const float* in0, const float* in1, int ld_in, int shift, floa
   CorrMfmaParams p = base_params(B, C, H, W, g);
   p.in0 = in0; p.in1 = in1; p.out = out; p.ld_in = ld_in; p.ld_out = ld_out; p.shift = shift;
   const int blocks = B * p.nA * g.s2 * g.oh;
-  if (C == 256) corr_fwd_mfma_kernel<256><<<blocks, 256, 0, st>>>(p);
-  else if (C == 128) corr_fwd_mfma_kernel<128><<<blocks, 256, 0, st>>>(p);
-  else corr_fwd_mfma_kernel<64><<<blocks, 256, 0, st>>>(p);
+  switch (C) {
+    case 256: corr_fwd_mfma_kernel<256><<<blocks, 256, 0, st>>>(p); break;
+    case 128: corr_fwd_mfma_kernel<128><<<blocks, 256, 0, st>>>(p); break;
+    case 64: corr_fwd_mfma_kernel<64><<<blocks, 256, 0, st>>>(p); break;
+    case 96: corr_fwd_mfma_kernel<96><<<blocks, 256, 0, st>>>(p); break;
+    case 32: corr_fwd_mfma_kernel<32><<<blocks, 256, 0, st>>>(p); break;
+    default: corr_fwd_mfma_kernel<0><<<blocks, 256, 0, st>>>(p); break;     // any other multiple of 32: runtime channel loop
+  }
   return launch_status();
 }
 
@@ -246,9 +253,10 @@ int corr_mfma_bwd(const float* dout, int ld_dout, const float* in0, const float*
   CorrMfmaParams p = base_params(B, C, H, W, g);
   p.in0 = in0; p.in1 = in1; p.dout = dout; p.g0 = g0; p.g1 = g1;
   p.ld_in = ld_in; p.ld_dout = ld_dout; p.ld_g = ld_g; p.shift = shift; p.fuse = fuse;
-  constexpr int CT = 2;
+  const int CT = C % 64 == 0 ? 2 : 1;
   const long jobs = (long)(C / (32 * CT)) * B * p.nA * g.s2 * H;
   dim3 grid((unsigned)((jobs + 3) / 4), fuse ? 1 : 2);
-  corr_bwd_mfma_kernel<CT><<<grid, 256, 0, st>>>(p);
+  if (CT == 2) corr_bwd_mfma_kernel<2><<<grid, 256, 0, st>>>(p);
+  else corr_bwd_mfma_kernel<1><<<grid, 256, 0, st>>>(p);
   return launch_status();
 }

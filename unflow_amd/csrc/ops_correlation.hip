@@ -150,6 +150,11 @@ int corr_mfma_fwd(const float* in0, const float* in1, int ld_in, int shift, floa
 int corr_mfma_bwd(const float* dout, int ld_dout, const float* in0, const float* in1, int ld_in, int shift, float* g0,
                   float* g1, int ld_g, int fuse, int B, int C, int H, int W, const CorrGeom& g, hipStream_t st);
 
+// operand-plane forward (correlation_planes.hip)
+int corr_pl_supported(const CorrGeom& g, int C, const unflow_planes* a, const unflow_planes* b);
+int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, float* out, int ld_out, int B, int C, int H,
+                int W, const CorrGeom& g, hipStream_t st);
+
 static int corr_status(int H, int W, int k, int md, int pad, int s1, int s2, CorrGeom* g) {
   if (k <= 0 || s1 <= 0 || s2 <= 0 || md < 0 || pad < 0) return UNFLOW_ERR_SHAPE;
   if (k % 2 == 0) return UNFLOW_ERR_EVEN_KERNEL;
@@ -185,6 +190,22 @@ UNFLOW_API int unflow_correlation_nhwc_fwd(const float* in0, const float* in1, i
   dim3 grid(g.ow, g.oh, B);
   corr_fwd_generic_kernel<<<grid, 256, smem, as_stream(stream)>>>(in0, in1, ld_in, pair_shift, out, ld_out, B, C, H, W, g);
   return launch_status();
+}
+
+UNFLOW_API int unflow_correlation_nhwc_fwd_pl(const float* in0, const float* in1, int ld_in, const unflow_planes* in0_pl,
+                                              const unflow_planes* in1_pl, int pair_shift, float* out, int ld_out, int B,
+                                              int C, int H, int W, int kernel_size, int max_displacement, int pad,
+                                              int stride_1, int stride_2, unflow_stream_t stream) {
+  if (!out) return UNFLOW_ERR_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return UNFLOW_ERR_SHAPE;
+  CorrGeom g;
+  const int st = corr_status(H, W, kernel_size, max_displacement, pad, stride_1, stride_2, &g);
+  if (st != UNFLOW_OK) return st;
+  if (ld_out < g.oc) return UNFLOW_ERR_SHAPE;
+  if (corr_pl_supported(g, C, in0_pl, in1_pl))
+    return corr_pl_fwd(in0_pl, in1_pl, pair_shift, out, ld_out, B, C, H, W, g, as_stream(stream));
+  return unflow_correlation_nhwc_fwd(in0, in1, ld_in, pair_shift, out, ld_out, B, C, H, W, kernel_size, max_displacement,
+                                     pad, stride_1, stride_2, stream);
 }
 
 UNFLOW_API int unflow_correlation_nhwc_bwd(const float* dout, int ld_dout, const float* in0, const float* in1,
