@@ -173,6 +173,54 @@ def test_conv_planes_vs_fp64(case, P, dev):
     assert rel_err(dw, wr.grad) < (3e-5 if P == 3 else TOL[P])
 
 
+@pytest.mark.parametrize("P", [3, 1])
+@pytest.mark.parametrize("case", [(2, 24, 32, 64), (1, 17, 70, 24), (3, 64, 128, 64)])
+def test_conv1_two_pixel_granules(case, P, dev):
+    """FlowNetC's first layer in the two-pixel-granule form (rgb4_form of csrc/conv_planes.hip): input planes with row
+    length 4, weight planes of W[7,7,4,Cout] read as [7][28][Cout]; forward and filter gradient vs fp64, including the image
+    borders (granule pairs at x = -2,-1 and W, W+1 ... must read zeros) and an odd height."""
+    import ctypes
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, stream
+    from unflow_amd.core import layers as L
+    from oracle import model_ref as M
+    B, H, W, Cout = case
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = torch.randn(B, H, W, 4, generator=g)
+    x[..., 3] = 0
+    w = torch.randn(7, 7, 4, Cout, generator=g) * (1.0 / np.sqrt(147))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr, wr, br = x.double(), w.double().requires_grad_(), b.double()
+    y_ref = M.conv2d(xr.permute(0, 3, 1, 2), wr, br, 2, act=True).permute(0, 2, 3, 1)
+    gy = torch.randn(y_ref.shape, generator=g).double()
+    dz_ref = gy * torch.where(y_ref.detach() > 0, 1.0, 0.1)
+    y_ref.backward(gy)
+
+    X = L.PT(x.to(dev), torch.zeros(P, B, H, W, 4, dtype=torch.int16, device=dev))
+    L.planes_from_f32(X.t, X.pl, C=4)
+    wd = w.to(dev).contiguous()
+    w_dir = torch.zeros(P, 7, 28, Cout, dtype=torch.int16, device=dev)
+    w_tr = torch.zeros(P, 7, Cout, 32, dtype=torch.int16, device=dev)
+    check(_lib.lib().unflow_weight_planes_batched(1, (ctypes.c_void_p * 1)(wd.data_ptr()), (ctypes.c_int * 1)(7),
+                                                  (ctypes.c_int * 1)(28), (ctypes.c_int * 1)(Cout),
+                                                  (ctypes.c_void_p * 1)(w_dir.data_ptr()),
+                                                  (ctypes.c_void_p * 1)(w_tr.data_ptr()), P, stream()), "weight_planes")
+    Ho, Wo = L.out_hw(H, W, 2)
+    Y = L.PT.alloc((B, Ho, Wo, Cout), dev, P)
+    L.conv_fwd(X, wd, w_tr, b.to(dev), Y, 2, True)
+    assert rel_err(Y.t, y_ref) < TOL[P]
+    DZ = make_pt(dz_ref.float(), dev, P)
+    dw = torch.full((7, 7, 4, Cout), 9.0, device=dev)
+    L.conv_bwd_filter(X, DZ, dw, 2)
+    assert rel_err(dw, wr.grad) < (3e-5 if P == 3 else TOL[P])
+    # same numbers as the one-pixel-granule form
+    X8 = make_pt(x, dev, P)
+    _, _, w_tr8 = weight_planes(w, dev, P)
+    Y8 = L.PT.alloc((B, Ho, Wo, Cout), dev, P)
+    L.conv_fwd(X8, wd, w_tr8, b.to(dev), Y8, 2, True)
+    assert rel_err(Y.t, Y8.t) < 1e-5
+
+
 # (B, H, W, Cin, Cout)   H,W = INPUT size; output is 2H x 2W
 DECONV_CASES = [
     (8, 6, 8, 1024, 512),     # deconv5

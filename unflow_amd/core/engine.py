@@ -65,6 +65,9 @@ def conv_math_mode():
     return m
 
 
+RGB4_FORM = os.environ.get('UNFLOW_RGB4', '1') != '0'     # A/B knob: two-pixel K granules for FlowNetC's first layer
+
+
 class Layer:
     """One conv / conv_transpose variable pair.  in_map: [(physical lo, tf lo, n)] — where the reference's input channels
     live in the (padded, segment-aligned) physical input of the layer; cout_p >= cout is the physical output width
@@ -88,6 +91,13 @@ class Layer:
 
     def tf_wshape(self):
         return (self.k, self.k, self.cin, self.cout) if self.kind == 'conv' else (self.k, self.k, self.cout, self.cin)
+
+    def wplane_view(self):
+        """(taps, R, Cc) the weight planes are built from.  FlowNetC's first layer (7x7 stride 2 over RGB0) is read as
+        [7 tap rows][28 = 7 kx * 4 channels][Cout]: the two-pixel-granule form of csrc/conv_planes.hip (rgb4_form)."""
+        if self.kind == 'conv' and self.k == 7 and self.stride == 2 and self.cin_p == 4 and RGB4_FORM:
+            return (7, 28, self.cout_p)
+        return (self.k * self.k, self.wshape()[2], self.wshape()[3])
 
     def uses_planes(self):
         return self.cout > 4 and self.cin_p >= 4
@@ -476,12 +486,12 @@ class FlowNetEngine:
             users = [l for l in self.layers if l.uses_planes()]
             tot = 0
             for l in users:
-                taps, R, Cc = l.k * l.k, l.wshape()[2], l.wshape()[3]
+                taps, R, Cc = l.wplane_view()
                 tot += P * (taps * R * round8(Cc) + taps * Cc * round8(R))
             self.WP = torch.zeros(tot, dtype=torch.int16, device=self.dev)
             off = 0
             for l in users:
-                taps, R, Cc = l.k * l.k, l.wshape()[2], l.wshape()[3]
+                taps, R, Cc = l.wplane_view()
                 n = P * taps * R * round8(Cc)
                 l.wpl_d = self.WP[off:off + n].view(P, taps, R, round8(Cc))
                 off += n
@@ -492,9 +502,9 @@ class FlowNetEngine:
             n = len(users)
             self._wp_table = (n,
                               (ctypes.c_void_p * n)(*[l.w.data_ptr() for l in users]),
-                              (ctypes.c_int * n)(*[l.k * l.k for l in users]),
-                              (ctypes.c_int * n)(*[l.wshape()[2] for l in users]),
-                              (ctypes.c_int * n)(*[l.wshape()[3] for l in users]),
+                              (ctypes.c_int * n)(*[l.wplane_view()[0] for l in users]),
+                              (ctypes.c_int * n)(*[l.wplane_view()[1] for l in users]),
+                              (ctypes.c_int * n)(*[l.wplane_view()[2] for l in users]),
                               (ctypes.c_void_p * n)(*[l.wpl_d.data_ptr() for l in users]),
                               (ctypes.c_void_p * n)(*[l.wpl_t.data_ptr() for l in users]))
 
@@ -564,8 +574,9 @@ class FlowNetEngine:
     def _alloc_activations(self):
         N, H, W, dev = self.N, self.H, self.W, self.dev
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        # mean-subtracted network input (4th channel zero) + its operand planes (8 channels: conv1 walks K in groups of 8)
-        self.X0 = L.PT(z(N, H, W, 4), torch.zeros(self.n_planes, N, H, W, 8, dtype=torch.int16, device=dev)
+        # mean-subtracted network input (4th channel zero) + its operand planes.  Row length 4 when W is even: a 16-byte
+        # K granule of conv1 is then two pixels (rgb4_form of csrc/conv_planes.hip), else 8 (one zero-padded pixel)
+        self.X0 = L.PT(z(N, H, W, 4), torch.zeros(self.n_planes, N, H, W, 4 if (W % 2 == 0 and RGB4_FORM) else 8, dtype=torch.int16, device=dev)
                        if self.n_planes else None)
         self.x0 = self.X0.t
         self.im01 = z(N, H, W, 3)     # images in [0,1] for the losses

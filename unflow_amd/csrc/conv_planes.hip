@@ -47,6 +47,8 @@ struct PlGatherParams : GatherGeom {
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
   int dbg;                     // ablation switches (UNFLOW_DBG env; 0 in production): 1 no loads in the loop, 2 no LDS stores
+  int xcd;                     // XCD-contiguous tile order (xcd_remap)
+  int gpx;                     // pixels per K granule along x (0: a granule is 8 channels of ONE pixel; 2: conv1 form, below)
   PlaneOut pl;
 };
 
@@ -55,6 +57,16 @@ struct PlGatherParams : GatherGeom {
 constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
   const int tiles = npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4;
   return tiles > stage ? tiles : stage;
+}
+
+// Workgroups are handed to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), so neighbouring tiles — which share
+// source rows (the vertical taps) — sit on different L2s.  This bijective remap of blockIdx.x gives every XCD a contiguous
+// run of tiles instead: its L2 then fetches each source row once, not once per XCD that holds one of the row's consumers.
+__device__ __forceinline__ int xcd_remap(int b, int n, int on) {
+  if (!on || n < 16) return b;
+  const int xcd = b & 7, idx = b >> 3;
+  const int q = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 template <int NPL, bool F16>
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   const int cls_id = blockIdx.z % p.ncls, split = blockIdx.z / p.ncls;
   const TapClass tc = p.cls[cls_id];
   const int M = p.B * p.Hg * p.Wg;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = xcd_remap(blockIdx.x, gridDim.x, p.xcd) * BM, n0 = blockIdx.y * BN;
   const int ntaps = tc.nty * tc.ntx;
   const int Cg = p.Cs >> 3;                      // granules per tap
   const int Kg = ntaps * Cg;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
   for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Cs)) * 2);
     w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
   }
 
@@ -245,9 +257,11 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
     const int ty = (int)(((unsigned)q_tap * ntx_magic) >> 16), tx = q_tap - ty * tc.ntx;
     const bool kvalid = live && q_tap < ntaps;
     dy = tc.dy0 + ty * p.dstep;
-    dx = tc.dx0 + tx * p.dstep;
+    // two-pixel granules (rgb4_form, row length 4): granule q_cg of a tap row starts gpx * q_cg pixels to the right, which
+    // is also its address (gpx * lds2 = 16 bytes) — the bounds check of piece_a then covers each granule separately
+    dx = tc.dx0 + tx * p.dstep + p.gpx * q_cg;
     const int cofs = q_cg * 16;
-    a_tile = kvalid ? (dy * p.Ws + dx) * lds2 + cofs : OOB_MARK;
+    a_tile = kvalid ? (dy * p.Ws + dx) * lds2 + (p.gpx ? 0 : cofs) : OOB_MARK;
     const int widx = (tc.ky0 + ty * p.kstep) * p.KW + tc.kx0 + tx * p.kstep;
     w_tile = kvalid ? widx * p.N * p.Cs * 2 + cofs : OOB_MARK;
   };
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   const int kt0 = split * ch_per * ntaps, kt1 = min(nchunk, (split + 1) * ch_per) * ntaps;
 
   // tile -> (image, tile row, tile column)
-  int t = blockIdx.x;
+  int t = xcd_remap(blockIdx.x, gridDim.x, p.xcd);
   const int txi = t % p.tiles_x; t /= p.tiles_x;
   const int tyi = t % p.tiles_y;
   const int b = t / p.tiles_y;
@@ -658,6 +672,7 @@ struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multi
   int Ca_out;                  // rows per tap of dW (the weight tensor's own channel padding, <= Ca)
   int nsplit;
   int dbg;
+  int gpx;                     // conv1 form: granule ag of a tap row starts gpx * ag pixels to the right
   unsigned cag_magic;          // ceil(2^32 / (Ca/8))
 };
 
@@ -701,7 +716,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
   __amdgpu_buffer_rsrc_t src_rs[NPL], dst_rs[NPL];
 #pragma unroll
   for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Ca) * 2);
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
     dst_rs[pl] = make_rsrc(p.dst + pl * p.dst_ps, (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
   }
 
@@ -712,9 +727,9 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
   const unsigned tap = p.cag_magic ? fast_div((unsigned)mg, p.cag_magic) : (unsigned)mg;   // magic 0: Ca == 8, one granule per tap
   const int ag = mg - (int)tap * Cag;
   const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
-  const int dy = p.dy0 + ky, dx = p.dx0 + kx;
+  const int dy = p.dy0 + ky, dx = p.dx0 + kx + p.gpx * ag;
   const int lds2 = p.lds * 2;
-  const int a_lane_off = (dy * p.Ws + dx) * lds2 + ag * 16;   // may be negative; added to the site's base offset
+  const int a_lane_off = (dy * p.Ws + (p.dx0 + kx)) * lds2 + ag * 16;   // may be negative; added to the site's base offset
   // dense operand: this thread's column granule
   const int bj = tid % BJ, bk = tid / BJ;
   const int nbq = (n0 >> 3) + bj;
@@ -989,7 +1004,8 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
   const int KT = (maxtaps * (p.Cs >> 3) + 3) >> 2;
   static const int min_kt = getenv("UNFLOW_GATHER_MIN_KT") ? max(1, atoi(getenv("UNFLOW_GATHER_MIN_KT"))) : 8;   // tuning knob
-  const int max_by_k = min(16, KT / min_kt > 0 ? KT / min_kt : 1);
+  static const int max_split = getenv("UNFLOW_GATHER_MAX_SPLIT") ? max(1, atoi(getenv("UNFLOW_GATHER_MAX_SPLIT"))) : 16;
+  const int max_by_k = min(max_split, KT / min_kt > 0 ? KT / min_kt : 1);
   if (pl.cfg == 0) {
     const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
     if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
@@ -1077,6 +1093,10 @@ inline int pl_dbg() {
 
 int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStream_t st) {
   p.dbg = pl_dbg();
+  {
+    static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
+    p.xcd = xcd;
+  }
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
   PlPlan pl = plan_pl_gather(p, npl);
@@ -1281,6 +1301,12 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
   WgradGeom wg{};
   build_conv_wgrad(wg, B, H, W, Ci8, Cout, k, stride);
   need = max(need, pl_wgrad_partial_bytes(wg, Cin, plan_pl_wgrad(wg, n_planes)));
+  if (Cin == 4 && k == 7 && stride == 2 && W % 2 == 0) {   // the two-pixel-granule form of FlowNetC's first layer (rgb4_form)
+    g.Cs = 32; g.KW = 1; g.wtaps = 7; g.cls[0].ntx = 1;
+    need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
+    wg.Ca = 32; wg.KW = 1;
+    need = max(need, pl_wgrad_partial_bytes(wg, 28, plan_pl_wgrad(wg, n_planes)));
+  }
   if (k == 4 && stride == 2 && H % 2 == 0 && W % 2 == 0) {
     GatherGeom tf{};
     build_deconv_fwd(tf, B, H / 2, W / 2, Ci8, Cout);
@@ -1295,6 +1321,17 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
   return need + 1024;
 }
 
+// The first layer of a FlowNetC (7x7 stride 2 over RGB0, flownet.py:204): with 8-channel K granules half of every granule
+// is padding (49 taps x 8 = 392 K slots for 147 weights).  Stored with row length 4, a 16-byte granule of the input planes is
+// TWO neighbouring pixels, and because the SAME padding on the left is even (2) and W is even, the pairs a tap row needs —
+// pixels (2xg-2, 2xg-1) .. (2xg+4, 2xg+5) — never straddle the image border: the layer becomes a 7x1 convolution over
+// "pixels" of 32 channels (4 granules, the last pixel of the last one meets a zero weight row): K = 7 x 32 = 224 slots.
+// The weight tensor [7][7][4][Cout] read as [7 taps][28 rows][Cout] gives the matching planes (rows 28..31 zero).
+static bool rgb4_form(const unflow_planes* x_pl, int W, int Cin, int k, int stride) {
+  return x_pl && x_pl->base && Cin == 4 && k == 7 && stride == 2 && x_pl->ld == 4 && W % 2 == 0 &&
+         (x_pl->n_planes == 1 || x_pl->n_planes == 3) && (reinterpret_cast<uintptr_t>(x_pl->base) & 7) == 0;
+}
+
 static bool use_planes(const unflow_planes* a, int ca, const unflow_planes* b, int cb, int Cout_or_n) {
   return Cout_or_n > 4 && planes_ok(a, ca) && planes_ok(b, cb) && a->n_planes == b->n_planes;
 }
@@ -1306,12 +1343,18 @@ UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes
   if (!y || (!x && !x_pl)) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
   const int Ci8 = (Cin + 7) & ~7;
-  if (!use_planes(x_pl, Cin, w_pl, Cin, Cout) || w_pl->ld != Ci8)
+  const bool rgb4 = rgb4_form(x_pl, W, Cin, k, stride) && Cout > 4 && planes_ok(w_pl, 28) && w_pl->ld == 32 &&
+                    w_pl->n_planes == x_pl->n_planes;
+  if (!rgb4 && (!use_planes(x_pl, Cin, w_pl, Cin, Cout) || w_pl->ld != Ci8))
     return unflow_conv2d_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, k, stride, leaky, plane_out(y_pl, 0, Cout), workspace,
                                 workspace_bytes, stream);
   if (ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   build_conv_fwd(p, B, H, W, Ci8, Cout, k, stride);
+  if (rgb4) {
+    p.Cs = 32; p.KW = 1; p.wtaps = 7; p.gpx = 2;
+    p.cls[0].ntx = 1;
+  }
   p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
   p.bias = bias; p.dst = y; p.ldd = ldy; p.act_src = nullptr; p.leaky = leaky; p.accumulate = 0;
@@ -1349,13 +1392,16 @@ UNFLOW_API int unflow_conv2d_bwd_filter_pl(const float* x, int ldx, const unflow
                                            unflow_stream_t stream) {
   if (!dw || (!x && !x_pl) || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
-  if (!use_planes(x_pl, Cin, dz_pl, Cout, Cout) || Cout % 4 != 0)
+  const bool rgb4 = rgb4_form(x_pl, W, Cin, k, stride) && planes_ok(dz_pl, Cout) && dz_pl->n_planes == x_pl->n_planes &&
+                    Cout > 4 && Cout % 4 == 0;
+  if (!rgb4 && (!use_planes(x_pl, Cin, dz_pl, Cout, Cout) || Cout % 4 != 0))
     return unflow_conv2d_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, stream);
   PlWgradParams p{};
   build_conv_wgrad(p, B, H, W, (Cin + 7) & ~7, Cout, k, stride);
+  if (rgb4) { p.Ca = 32; p.KW = 1; p.gpx = 2; }
   p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
   p.dst = reinterpret_cast<const unsigned short*>(dz_pl->base); p.dst_ps = dz_pl->plane_stride; p.ldd = dz_pl->ld;
-  p.out = dw; p.Ca_out = Cin;
+  p.out = dw; p.Ca_out = rgb4 ? 28 : Cin;
   size_t used = 0;
   return run_pl_wgrad(p, x_pl->n_planes, workspace, workspace_bytes, &used, as_stream(stream));
 }
