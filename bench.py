@@ -287,7 +287,8 @@ def measure_roofline(eng, args):
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "peak_note": "FLOP-weighted: 2/3 of the class at %.1f (gather kernels), 1/3 at %.1f TFLOP/s (filter gradients); "
-                         "bf16x3 peak = 2500 / 6 product terms" % (g_peak, w_peak),
+                         "%s" % (g_peak, w_peak, "fp16 operands: one product term, the dense 16-bit MFMA peak" if f16 else
+                                 "bf16x3 peak = 2500 / 6 product terms"),
             **(_pmc_traffic() if (eng.B, eng.H, eng.W, eng.spec) == (4, 384, 512, 'C') else {"traffic": None}),
             "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
 

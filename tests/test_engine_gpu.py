@@ -430,3 +430,43 @@ def test_fused_loss_pyramid_equals_per_level_path(dev):
     assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.equal(a, b)
+
+
+def test_filter_gradients_on_second_stream_bit_identical(dev):
+    """The filter gradients of a step run in groups on a second stream beside the data-gradient chain (engine
+    _Stage.backward).  Same kernels, same split counts, own scratch: every gradient must equal the single-stream schedule's
+    bit for bit — eagerly and over repeated replays of the captured two-branch hipGraphs, for several group sizes."""
+    from parity_util import graph_step, images
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 2, 384, 512
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
+    eng.init_params(seed=5)
+    im1, im2 = images(B, H, W, 77)
+    im1, im2 = im1.to(dev), im2.to(dev)
+    side = torch.cuda.Stream(dev)
+
+    def run(group, graph):
+        eng.wgrad_group, eng.wgrad_stream = group, (side if group > 0 else None)
+        if graph:
+            graph_step(eng, im1, im2)
+        else:
+            eng.set_input(im1, im2)
+            eng.G.zero_()
+            eng.forward_net()
+            eng.forward_loss(with_grad=True)
+            eng.backward_net()
+            torch.cuda.synchronize()
+        return eng.G.clone()
+
+    ref = run(0, False)
+    assert torch.equal(run(0, True), ref)
+    for group, graph, reps in ((6, False, 2), (6, True, 6), (3, True, 4), (1, True, 2), (100, True, 2)):
+        for _ in range(reps):
+            got = run(group, graph)
+            bad = []
+            for l in eng.layers:
+                lo = (l.dw.data_ptr() - eng.G.data_ptr()) // 4
+                if not torch.equal(got[lo:lo + l.dw.numel()], ref[lo:lo + l.dw.numel()]):
+                    bad.append(l.name)
+            assert not bad, (group, graph, bad)
+    assert torch.equal(got[eng.n_weights:], ref[eng.n_weights:])         # bias gradients too

@@ -373,6 +373,33 @@ class _Stage:
         e = self.eng
         lo, hi = (0, len(self.bwd)) if part is None else (self.part_bounds[part], self.part_bounds[part + 1])
         B, N = e.B, e.N
+        # Filter gradients leave the critical path: a layer's dW depends only on its (final) dz and its input, and nothing
+        # reads it before the optimizer, so groups of them run on a second stream beside the data-gradient chain (own
+        # split-K scratch, ws_slot 3); the part joins before it returns.  The small deep layers, whose kernels cannot fill
+        # the chip alone, are where this pays (+2.9 % on the benchmarked step).  The Cout = 2 layers (flow heads, 2 -> 2
+        # flow upsamplers) stay on the main stream: measured on MI355X / ROCm 7.2, the tiny_deconv_wgrad_kernel of a
+        # replayed two-branch hipGraph returned 2-3 of its 64 sums off by ~1e-3 whenever it ran beside a main-branch
+        # kernel (never eagerly, never with a join after each group, never with the gradients deferred to the end of the
+        # part: tools/debug/wgstream_diff.py; cause not found) — tests/test_engine_gpu.py asserts bit-identity of the two
+        # schedules over repeated replays.
+        side = e.wgrad_stream
+        main = torch.cuda.current_stream(e.dev)
+        pending = []
+        counter = [100 * (part or 0)]
+
+        def flush():
+            if not pending:
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for fn, a in pending:
+                    with L.ws_slot(3 + (counter[0] if e.wgrad_unique_ws else 0)):
+                        fn(*a)
+                    counter[0] += 1
+            pending.clear()
+            if e.wgrad_sync_each:
+                main.wait_stream(side)
+
         for op, first, act_lo, act_hi in self.bwd[lo:hi]:
             if op.kind == 'corr':
                 c3, g3, gout = self.pt(op.src), self.pt(op.src, True), self.pt(op.dst, True)
@@ -389,10 +416,13 @@ class _Stage:
                 dz = L.PT(dz.t.as_strided(dz.t.shape[:3] + (l.cout_p,), dz.t.stride(), dz.t.storage_offset()), dz.pl)
             if e._bias_plan is None:
                 e._bias_jobs.append((dz.t, l))       # bias gradients: one batched column-sum launch at the end
-            if l.kind == 'conv':
-                L.conv_bwd_filter(x, dz, l.dw, l.stride)
+            wg = (L.conv_bwd_filter, (x, dz, l.dw, l.stride)) if l.kind == 'conv' else (L.deconv_bwd_filter, (x, dz, l.dw))
+            if side is None or (e.wgrad_inline_tiny and l.cout <= 2):
+                wg[0](*wg[1])
             else:
-                L.deconv_bwd_filter(x, dz, l.dw)
+                pending.append(wg)
+                if len(pending) >= e.wgrad_group:
+                    flush()
             sb = op.src[0]
             is_input = sb == 'x0' or (sb == self.bin and op.src[1] == 0 and op.src[2] == pad4(self.in_ch)
                                       and op.l.name.endswith('conv1'))
@@ -406,6 +436,9 @@ class _Stage:
                 L.conv_bwd_data(dz, l.w, l.wpl_d, dx, l.stride, accumulate, act_src, act_lo, act_hi)
             else:
                 L.deconv_bwd_data(dz, l.w, l.wpl_t, dx, accumulate, act_src, act_lo, act_hi)
+        if side is not None:
+            flush()
+            main.wait_stream(side)
 
 
 class FlowNetEngine:
@@ -435,6 +468,12 @@ class FlowNetEngine:
         self.N = 2 * batch
         self.dev = torch.device('cuda:0') if device is None else torch.device(device)
         self.math = conv_math_mode()
+        # filter gradients on a second stream, in groups of wgrad_group layers (UNFLOW_WGRAD_GROUP=0: inline)
+        self.wgrad_group = int(os.environ.get('UNFLOW_WGRAD_GROUP', '6'))
+        self.wgrad_stream = None
+        self.wgrad_sync_each = False      # debug: join after every group (no concurrency, still two graph branches)
+        self.wgrad_unique_ws = False      # debug: one scratch buffer per deferred filter gradient
+        self.wgrad_inline_tiny = True     # the Cout = 2 layers' filter gradients stay on the main stream (see backward())
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
         if layout_only:
             self.n_planes = 0
@@ -448,6 +487,8 @@ class FlowNetEngine:
             self._alloc_params()
             if not layout_only:
                 self._alloc_activations()
+                if self.wgrad_group > 0 and self.dev.type == 'cuda':
+                    self.wgrad_stream = torch.cuda.Stream(self.dev)
                 self._build_masks()
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
