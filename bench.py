@@ -52,15 +52,22 @@ def conv_family_gflop(eng):
     res = {'conv1': 2, 'conv2': 4, 'conv3': 8, 'conv_redir': 8, 'conv3_1': 8, 'conv4': 16, 'conv4_1': 16, 'conv5': 32,
            'conv5_1': 32, 'conv6': 64, 'conv6_1': 64, 'flow6': 64, 'deconv5': 32, 'flow6_up5': 32, 'flow5': 32,
            'deconv4': 16, 'flow5_up4': 16, 'flow4': 16, 'deconv3': 8, 'flow4_up3': 8, 'flow3': 8, 'deconv2': 4,
-           'flow3_up2': 4, 'flow2': 4}
-    for l in eng.layers:
-        nm = l.name.split('/')[-1]
-        d = res[nm]
-        opix = N * (H // d) * (W // d)
-        taps = l.k * l.k if l.kind == 'conv' else 4      # conv_transpose k4 s2: 4 taps reach each output pixel
-        f = 2.0 * opix * taps * l.cin * l.cout / 1e9
-        sizes[nm] = f
-        tot += f * (2 if nm == 'conv1' else 3)          # fwd + wgrad (+ dgrad except for the first layer)
+           'flow3_up2': 4, 'flow2': 4, 'deconv1': 2, 'flow2_up1': 2, 'flow1': 2, 'deconv0': 1, 'flow1_up0': 1, 'flow0': 1}
+    for st in eng.stages:
+        for l in st.layers:
+            nm = l.name.split('/')[-1]
+            d = res[nm]
+            opix = N * (H // d) * (W // d)
+            taps = l.k * l.k if l.kind == 'conv' else 4      # conv_transpose k4 s2: 4 taps reach each output pixel
+            f = 2.0 * opix * taps * l.cin * l.cout / 1e9
+            sizes[l.name] = f
+            if not st.trainable:
+                passes = 1                                   # behind stop_gradient: forward only
+            elif nm == 'conv1' and not (st.need_in_grad and not st.is_c):
+                passes = 2                                   # first layer: fwd + wgrad, its input is data
+            else:
+                passes = 3
+            tot += f * passes
     return tot, sizes
 
 
@@ -191,7 +198,7 @@ def main():
     if world > 1 or force_dist:
         out["rccl_world_size"] = dist.get_world_size()      # the rank count the RCCL communicator reports
 
-    if rank == 0 and world == 1 and not args.no_roofline and args.flownet == 'C':
+    if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = measure_roofline(eng, args)
     if rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C' and eng.math in ("bf16x3", "bf16x3_inline"):
         out["value_fp32_mfma_only"] = measure_alt_fp32(args)      # same step with every conv kernel on the fp32 MFMA

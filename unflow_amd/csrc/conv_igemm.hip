@@ -1,24 +1,25 @@
-// conv / conv_transpose stacks of FlowNetC/S (src/e2eflow/core/flownet.py:89-237) as fp32 MFMA
-// implicit GEMMs for gfx950, channels-last.
+// conv / conv_transpose stacks of FlowNetC/S (src/e2eflow/core/flownet.py:89-237) as implicit GEMMs for gfx950,
+// channels-last — the kernels that take fp32 tensors as operands.  The default path of the training step is
+// csrc/conv_planes.hip (pre-split 16-bit operand planes); this file is what runs with UNFLOW_CONV_MATH=fp32 /
+// bf16x3_inline, for operands without planes (the old C-ABI entry points, unaligned channel counts), and it holds the
+// kernels of the layers that are no GEMM at all: the Cout = 2 flow heads (head3_*), the 2 -> 2 flow upsamplers
+// (tiny_deconv_*), conv_redir's data gradient (pointwise32) and the batched bias-gradient column sums.
 //
-// One "gather GEMM" kernel covers conv fwd, conv dgrad, deconv fwd and deconv dgrad:
+// One "gather GEMM" kernel covers conv fwd, conv dgrad, deconv fwd and deconv dgrad (geometry: igemm_shared.h):
 //   D[site, n] = sum_{tap} sum_{c} SRC[b, yg*sm + dy(tap), xg*sm + dx(tap), c] * W(tap, c, n)
-// with the rows (sites) a regular grid, out-of-image taps contributing zero (TF 'SAME'), and the
-// stride-2 transposed cases split into the 4 output-parity classes (each class is a dense
-// stride-1 gather with its own tap subset) — no zero-insertion, no im2col buffer, no col2im.
-// One "wgrad" kernel covers conv and deconv filter gradients:
+// with the rows (sites) a regular grid, out-of-image taps contributing zero (TF 'SAME'), and the stride-2 transposed
+// cases split into the 4 output-parity classes (each a dense stride-1 gather with its own tap subset) — no
+// zero-insertion, no im2col buffer, no col2im.  One "wgrad" kernel covers conv and deconv filter gradients:
 //   dW[(tap,a), b] = sum_{site} SRC[gather(site, tap), a] * DST[site, b]
-// K is the flattened (tap, channel) axis walked in 16-byte quads, so Cin = 4 (the padded RGB
-// input) packs 8 taps into one K-tile instead of wasting 7/8 of it.
+// K is the flattened (tap, channel) axis walked in 16-byte quads.
 //
-// Tiling: 256 threads = 4 waves; v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles, 157 TF peak);
-// A and B tiles staged through LDS (double buffered, one barrier per K-tile of 32), layouts chosen
-// so every ds_read_b32 of an MFMA operand is bank-conflict free:
-//   K-contiguous global operand  -> LDS [row][33]   (lane i reads row i: stride 33 -> 32 banks)
-//   row-contiguous global operand-> LDS [k][rows]   (lane i reads consecutive dwords)
-// HBM side: 16-byte loads, 128 B contiguous per pixel-row of a tile (channels-last).
-// Deep layers (M = 384..6144 sites) use split-K so the launch covers the 256 CUs; partials go to a
-// caller workspace and a fixed-order reduce applies the epilogue (deterministic, no float atomics).
+// Math (template MATH): 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products, 157 TFLOP/s peak), operands in LDS as fp32
+// [row][K+4]; 1 = the 3-way bf16 split done WHILE staging (split_store: fp32 -> hi/mid/lo planes in LDS, six
+// v_mfma_f32_32x32x16_bf16 terms) — the round-1 default, superseded by the pre-split planes of conv_planes.hip, which take
+// the split and two thirds of the LDS store traffic out of the K loop.
+// Tiling: 256 threads = 4 waves, K-tiles of 32, register-staged double buffering, one barrier per K-tile; split-K for
+// the deep layers with partials in a caller workspace and a fixed-order reduce that applies the epilogue (deterministic,
+// no float atomics).
 #include "igemm_shared.h"
 
 namespace {
@@ -1644,12 +1645,9 @@ int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
   const size_t smem = (MATH ? (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short) : (size_t)(BM + BN) * LDK * sizeof(float)) +
                       BM * sizeof(int);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
+  (void)attr;
   dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
   igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF><<<grid, 256, smem, st>>>(p);
   return launch_status();
@@ -1696,12 +1694,9 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad_b3_cfg(const WgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const size_t smem = (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_b3_kernel<BM, BN, WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_b3_kernel<BM, BN, WM, WN>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
+  (void)attr;
   dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
   igemm_wgrad_b3_kernel<BM, BN, WM, WN><<<grid, 256, smem, st>>>(p);
   return launch_status();
@@ -1711,12 +1706,9 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad_cfg(const WgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const size_t smem = (size_t)(BK * BM + BK * BN) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM, BN, WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM, BN, WM, WN>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
+  (void)attr;
   dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
   igemm_wgrad_kernel<BM, BN, WM, WN><<<grid, 256, smem, st>>>(p);
   return launch_status();
