@@ -15,10 +15,13 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None, force=False):
+    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None, force=False, local_overlap=False):
         self.g = flat_grad
         self.world = world_size
         self.force = force      # issue the collectives even for world_size 1 (exercises the stream logic on one GPU)
+        # one rank, no process group: reduce_then() still moves fn() to the side stream, so the bucketed optimizer update
+        # runs beside the rest of the backward pass exactly as it does behind an exchange
+        self.local_overlap = local_overlap and world_size <= 1 and not force
         self.group = group
         n = flat_grad.numel()
         per = max(1, bucket_bytes // 4)
@@ -70,7 +73,12 @@ class GradAllReducer:
         exchange and running concurrently with whatever the compute stream does next (the bucketed optimizer update:
         train.py StepRunner).  Returns immediately; finish() joins."""
         if self.world <= 1 and not self.force:
-            fn()
+            if self.local_overlap and self.cuda:
+                self.stream.wait_stream(torch.cuda.current_stream(self.g.device))
+                with torch.cuda.stream(self.stream):
+                    fn()
+            else:
+                fn()
             return
         if not self.cuda:
             for lo, hi in ranges:
@@ -89,6 +97,8 @@ class GradAllReducer:
 
     def finish(self):
         if self.world <= 1 and not self.force:
+            if self.local_overlap and self.cuda:
+                torch.cuda.current_stream(self.g.device).wait_stream(self.stream)
             return
         if self.cuda:
             with torch.cuda.stream(self.stream):

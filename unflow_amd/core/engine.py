@@ -471,6 +471,7 @@ class FlowNetEngine:
         # filter gradients on a second stream, in groups of wgrad_group layers (UNFLOW_WGRAD_GROUP=0: inline)
         self.wgrad_group = int(os.environ.get('UNFLOW_WGRAD_GROUP', '4'))
         self.wgrad_stream = None
+        self.planes_external = False      # True: the captured forward does not re-split the weights (StepRunner does, per bucket)
         self.wgrad_sync_each = False      # debug: join after every group (no concurrency, still two graph branches)
         self.wgrad_unique_ws = False      # debug: one scratch buffer per deferred filter gradient
         self.wgrad_inline_tiny = True     # the Cout = 2 layers' filter gradients stay on the main stream (see backward())
@@ -539,15 +540,21 @@ class FlowNetEngine:
                 n = P * taps * Cc * round8(R)
                 l.wpl_t = self.WP[off:off + n].view(P, taps, Cc, round8(R))
                 off += n
-            import ctypes
-            n = len(users)
-            self._wp_table = (n,
-                              (ctypes.c_void_p * n)(*[l.w.data_ptr() for l in users]),
-                              (ctypes.c_int * n)(*[l.wplane_view()[0] for l in users]),
-                              (ctypes.c_int * n)(*[l.wplane_view()[1] for l in users]),
-                              (ctypes.c_int * n)(*[l.wplane_view()[2] for l in users]),
-                              (ctypes.c_void_p * n)(*[l.wpl_d.data_ptr() for l in users]),
-                              (ctypes.c_void_p * n)(*[l.wpl_t.data_ptr() for l in users]))
+            self._wp_users = users
+            self._wp_table = self._wp_table_of(users)
+            self._wp_range_tables = {}
+
+    @staticmethod
+    def _wp_table_of(users):
+        import ctypes
+        n = len(users)
+        return (n,
+                (ctypes.c_void_p * n)(*[l.w.data_ptr() for l in users]),
+                (ctypes.c_int * n)(*[l.wplane_view()[0] for l in users]),
+                (ctypes.c_int * n)(*[l.wplane_view()[1] for l in users]),
+                (ctypes.c_int * n)(*[l.wplane_view()[2] for l in users]),
+                (ctypes.c_void_p * n)(*[l.wpl_d.data_ptr() for l in users]),
+                (ctypes.c_void_p * n)(*[l.wpl_t.data_ptr() for l in users]))
 
     def refresh_weight_planes(self, force=False):
         """Re-split the parameters into their operand planes.  Needed whenever P changed: adam_step marks it; in-place
@@ -556,11 +563,31 @@ class FlowNetEngine:
         if self._wp_table is None:
             return
         capturing = torch.cuda.is_current_stream_capturing()
+        if self.planes_external and capturing and not force:
+            return        # the step runner re-splits each bucket right after its optimizer update, outside the graphs
         if not (force or capturing or self._wplanes_version != self.P._version):
             return
         n, w, taps, R, Cc, d, t = self._wp_table
         check(_lib.lib().unflow_weight_planes_batched(n, w, taps, R, Cc, d, t, self.n_planes, self.stream()), "weight_planes")
         self._wplanes_version = self.P._version
+
+    def refresh_weight_planes_ranges(self, ranges):
+        """Re-split the weight tensors that lie in the flat parameter ranges [(lo, hi), ...] on the current stream (the
+        bucketed form of refresh_weight_planes: train.py StepRunner calls it after each bucket's optimizer update)."""
+        if self._wp_table is None:
+            return
+        key = tuple(ranges)
+        tab = self._wp_range_tables.get(key)
+        if tab is None:
+            base = self.P.data_ptr()
+            users = [l for l in self._wp_users
+                     if any(lo <= (l.w.data_ptr() - base) // 4 < hi for lo, hi in ranges)]
+            tab = self._wp_table_of(users) if users else (0,)
+            self._wp_range_tables[key] = tab
+        if tab[0] == 0:
+            return
+        n, w, taps, R, Cc, d, t = tab
+        check(_lib.lib().unflow_weight_planes_batched(n, w, taps, R, Cc, d, t, self.n_planes, self.stream()), "weight_planes")
 
     def init_params(self, seed=0):
         """layers.variance_scaling_initializer() (flownet.py:177): truncated normal, stddev sqrt(1.3*2/fan_in);

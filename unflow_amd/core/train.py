@@ -12,8 +12,14 @@ One process per GPU.  A training step is
     join
 
 so the optimizer update of a bucket overlaps the exchange and the backward pass of the earlier layers (a layer's weights are
-only read by its own forward / data-gradient launches, which are complete when its bucket is released).  With one rank
-there is no exchange: one graph, one Adam launch."""
+only read by its own forward / data-gradient launches, which are complete when its bucket is released).  The re-split of
+the updated weights into their operand planes (csrc/conv_planes.hip) follows each bucket's update on the same stream
+instead of opening the next forward pass.  With one rank there is no exchange: one graph, one Adam launch.  (Keeping the cut
+on one rank — UNFLOW_OVERLAP_ADAM=1: the HBM-bound Adam + re-split of the deep layers beside the backward pass of the shallow
+ones — measured 2.7 % SLOWER on MI355X, 544 vs 559 pairs/s: the streaming blocks take CU slots from conv launches that are
+sized to fill the chip in exactly one round.)"""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -54,14 +60,17 @@ class StepRunner:
                  bucket_bytes=64 << 20, group=None):
         self.eng = engine
         self.world = world
-        self.dist = world > 1 or force_reducer
-        self.reducer = GradAllReducer(engine.G, world, bucket_bytes=bucket_bytes, group=group, force=force_reducer) \
-            if self.dist else None
+        local = (world == 1 and not force_reducer and engine.dev.type == 'cuda'
+                 and os.environ.get('UNFLOW_OVERLAP_ADAM', '0') != '0')
+        self.dist = world > 1 or force_reducer or local
+        self.reducer = GradAllReducer(engine.G, world, bucket_bytes=bucket_bytes, group=group, force=force_reducer,
+                                      local_overlap=local) if self.dist else None
         self.nparts = engine.set_backward_parts(bucket_cuts if (self.dist and not engine.train_all) else ())
         self.buckets = engine.part_buckets()
         self.frozen = engine.frozen_ranges()
         self.use_graph = use_graph
         self.graphs = None
+        self._captured = False
         engine.defer_l2 = True      # the L2 term of the loss rides on the pass Adam makes over the parameters
 
     # ---- the pieces of a step
@@ -75,6 +84,8 @@ class StepRunner:
     def capture(self):
         """One eager pass (grows the workspaces), then one hipGraph per backward part."""
         e = self.eng
+        e.refresh_weight_planes(force=True)
+        e.planes_external = self.reducer is not None     # from here on: re-split per bucket, after its update (_update)
         for k in range(self.nparts):
             self._part(k)
         torch.cuda.synchronize(e.dev)
@@ -99,15 +110,25 @@ class StepRunner:
         """One optimisation step on the minibatch (im1, im2) [B,H,W,3] in [0,255]; returns the loss tensor [1] (complete
         when the stream has drained)."""
         e = self.eng
-        if self.graphs is None and self.use_graph:
+        if not self._captured:
             e.set_input(im1, im2, augment=augment)
             self.capture()
+            self._captured = True
         e.set_input(im1, im2, augment=augment)
+        if e.planes_external and e._wplanes_version != e.P._version:
+            e.refresh_weight_planes(force=True)          # the parameters were written behind the runner's back (a restore)
         lr_t = e.adam_begin(lr)
         scale = 1.0 / self.world
+
+        def update(ranges):
+            for lo, hi in ranges:
+                e.adam_range(lo, hi, lr_t, scale)
+            if e.planes_external:
+                e.refresh_weight_planes_ranges(ranges)
+
         if self.reducer is not None and self.frozen:
             # frozen networks: zero data gradient everywhere, nothing to exchange; their L2 update runs on the side stream
-            self.reducer.reduce_then([], lambda: [e.adam_range(lo, hi, lr_t, scale) for lo, hi in self.frozen])
+            self.reducer.reduce_then([], lambda: update(self.frozen))
         for k in range(self.nparts):
             if self.graphs is not None:
                 self.graphs[k].replay()
@@ -115,11 +136,13 @@ class StepRunner:
                 self._part(k)
             if self.reducer is not None:
                 ranges = self.buckets[k]
-                self.reducer.reduce_then(ranges, lambda r=ranges: [e.adam_range(lo, hi, lr_t, scale) for lo, hi in r])
+                self.reducer.reduce_then(ranges, lambda r=ranges: update(r))
         if self.reducer is not None:
             self.reducer.finish()
         else:
             e.adam_range(0, e.n_params, lr_t, scale)
+        if e.planes_external:
+            e._wplanes_version = e.P._version
         return e.loss_acc
 
 
