@@ -4,6 +4,7 @@
 # rocprofv3 aborts and then hangs in its finaliser for some counter combinations (TA_* together with TCP_* did).
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p $out
 i=0
 for c in "$@"; do
   i=$((i+1))
