@@ -88,8 +88,8 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / args.reps
         tot_us += us
         tot_gf += gf
-        print("%-18s %-22s %-22s %5d %9.1f %8.1f" % (n, "x".join(map(str, si)), "x".join(map(str, so)), kk, us, gf / us * 1e-3 if us else 0))
-    print("total %.1f us  %.1f GFLOP -> %.1f TFLOP/s (%d calls)" % (tot_us, tot_gf, tot_gf / tot_us * 1e-3, len(calls)))
+        print("%-18s %-22s %-22s %5d %9.1f %8.1f" % (n, "x".join(map(str, si)), "x".join(map(str, so)), kk, us, gf / us * 1e3 if us else 0))
+    print("total %.1f us  %.1f GFLOP -> %.1f TFLOP/s (%d calls)" % (tot_us, tot_gf, tot_gf / tot_us * 1e3, len(calls)))
 
 
 if __name__ == "__main__":

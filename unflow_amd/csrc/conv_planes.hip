@@ -47,7 +47,10 @@ struct PlGatherParams : GatherGeom {
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
   int dbg;                     // ablation switches (UNFLOW_DBG env; 0 in production): 1 no loads in the loop, 2 no LDS stores
-  int xcd;                     // XCD-contiguous tile order (xcd_remap)
+  int xcd;                     // XCD-contiguous work order (xcd_remap + work_decode)
+  int mt, nt;                  // M tiles, N tiles of the launch (the grid is 1-D: mt * nt * ncls * nsplit workgroups)
+  int order;                   // work order (work_decode): 0 N tile fastest .. M tile slowest; 1 M tile fastest; 2 M groups
+  int mgroup;                  // order 2: M tiles per group (one group per XCD)
   int gpx;                     // pixels per K granule along x (0: a granule is 8 channels of ONE pixel; 2: conv1 form, below)
   PlaneOut pl;
 };
@@ -67,6 +70,41 @@ __device__ __forceinline__ int xcd_remap(int b, int n, int on) {
   const int xcd = b & 7, idx = b >> 3;
   const int q = n >> 3, r = n & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// The launch is a 1-D grid; the linear workgroup id is first made XCD-contiguous (xcd_remap: the workgroups one XCD runs
+// are a contiguous run of the work order) and then decoded so that the workgroups resident together on an XCD share
+// operands in its L2.  Orders (run_pl_gather picks one per layer):
+//   0  N tile fastest, then parity class, K split, M tile: the consumers of one M tile's source pixels are adjacent;
+//   1  M tile fastest, then N tile, class, split: the M tiles of one weight slice are adjacent and an XCD touches 1/8 of the
+//      weights (deep layers: 28-56 MB of weight planes against 5 MB of activations; with the (x, y, z) grid dealt
+//      round-robin the forward / data-gradient kernels of conv5..conv6_1 moved 210-345 MB each);
+//   2  the M tiles are cut into 8 groups (one per XCD: neighbouring tiles share the vertical taps' rows); inside a group the
+//      M tile runs fastest, then N tile, class, split: every weight slice is streamed once per XCD by all its M tiles in
+//      step.  The grid is padded to whole groups; surplus workgroups return at once (m = -1).
+__device__ __forceinline__ void work_decode(int v, int mt, int nt, int ncls, int nsplit, int order, int mgroup, int& m, int& n,
+                                            int& c, int& s) {
+  if (order == 0) {
+    n = v % nt; v /= nt;
+    c = v % ncls; v /= ncls;
+    s = v % nsplit;
+    m = v / nsplit;
+    return;
+  }
+  if (order == 2) {
+    const int per = mgroup * nt * ncls * nsplit;
+    const int g = v / per;
+    v -= g * per;
+    const int mi = v % mgroup;
+    v /= mgroup;
+    m = g * mgroup + mi;
+    if (m >= mt) m = -1;
+  } else {
+    m = v % mt; v /= mt;
+  }
+  n = v % nt; v /= nt;
+  c = v % ncls;
+  s = v / ncls;
 }
 
 template <int NPL, bool F16>
@@ -186,10 +224,12 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int cls_id = blockIdx.z % p.ncls, split = blockIdx.z / p.ncls;
+  int mtile, ntile, cls_id, split;
+  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, mtile, ntile, cls_id, split);
+  if (mtile < 0) return;
   const TapClass tc = p.cls[cls_id];
   const int M = p.B * p.Hg * p.Wg;
-  const int m0 = xcd_remap(blockIdx.x, gridDim.x, p.xcd) * BM, n0 = blockIdx.y * BN;
+  const int m0 = mtile * BM, n0 = ntile * BN;
   const int ntaps = tc.nty * tc.ntx;
   const int Cg = p.Cs >> 3;                      // granules per tap
   const int Kg = ntaps * Cg;
@@ -401,9 +441,11 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int cls_id = blockIdx.z % p.ncls, split = blockIdx.z / p.ncls;
+  int t, ntile, cls_id, split;
+  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id, split);
+  if (t < 0) return;
   const TapClass tc = p.cls[cls_id];
-  const int n0 = blockIdx.y * BN;
+  const int n0 = ntile * BN;
   const int ntaps = tc.nty * tc.ntx;
   const int Cg = p.Cs >> 3;
   const int nchunk = (Cg + 3) >> 2;
@@ -411,7 +453,6 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   const int kt0 = split * ch_per * ntaps, kt1 = min(nchunk, (split + 1) * ch_per) * ntaps;
 
   // tile -> (image, tile row, tile column)
-  int t = xcd_remap(blockIdx.x, gridDim.x, p.xcd);
   const int txi = t % p.tiles_x; t /= p.tiles_x;
   const int tyi = t % p.tiles_y;
   const int b = t / p.tiles_y;
@@ -674,6 +715,7 @@ struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multi
   int dbg;
   int gpx;                     // conv1 form: granule ag of a tap row starts gpx * ag pixels to the right
   unsigned cag_magic;          // ceil(2^32 / (Ca/8))
+  int mt, nt, xcd;             // 1-D grid of mt * nt * nsplit workgroups, XCD-contiguous in (split, N tile, M tile) order
 };
 
 // LDS image of one operand plane: [k = 32 sites][ROWS channels], rows of ROWS*2 bytes; 32-byte pairs of granules
@@ -707,11 +749,19 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
   const int taps = p.KH * p.KW;
   const int Cag = p.Ca >> 3;
   const int Mg = taps * Cag;                     // row granules of the (padded) problem
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // Work order: all (M tile, N tile) blocks of one K split are adjacent and an XCD runs a contiguous run of that order, so
+  // the blocks that read the same range of sites (every tap / channel chunk of the gathered operand, every column tile
+  // of the dense one) share one L2.  With the (x, y, z) grid dealt round-robin to the XCDs they did not: the filter
+  // gradients of conv2 / conv3 / conv3_1 moved 1.6-1.9 GB each (6-7 TB/s from the Infinity Cache) for 0.25 GB of operands.
+  int v = xcd_remap(blockIdx.x, gridDim.x, p.xcd);
+  const int mtile = v % p.mt; v /= p.mt;
+  const int ntile = v % p.nt;
+  const int split = v / p.nt;
+  const int m0 = mtile * BM, n0 = ntile * BN;
   const int S = p.B * p.Hg * p.Wg;               // reduction length (sites)
   const int KT = (S + BK - 1) / BK;
   const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
-  const int kt0 = blockIdx.z * kt_per, kt1 = min(KT, kt0 + kt_per);
+  const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
 
   __amdgpu_buffer_rsrc_t src_rs[NPL], dst_rs[NPL];
 #pragma unroll
@@ -856,7 +906,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
     __syncthreads();
   }
 
-  float* o = p.nsplit > 1 ? p.partial + (size_t)blockIdx.z * taps * p.Ca_out * p.Cb : p.out;
+  float* o = p.nsplit > 1 ? p.partial + (size_t)split * taps * p.Ca_out * p.Cb : p.out;
   const int lh5 = lane >> 5;
 #pragma unroll
   for (int i = 0; i < TM; i++)
@@ -1021,6 +1071,16 @@ inline size_t pl_gather_partial_bytes(const GatherGeom& p, int nsplit) {
   return nsplit > 1 ? (size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
 }
 
+// workgroups of a launch (q.mt, q.nt set): order 2 pads the M tiles to whole groups
+inline int pl_grid(PlGatherParams& q) {
+  int mt = q.mt;
+  if (q.order == 2) {
+    q.mgroup = q.mt >= 16 ? cdiv(q.mt, 8) : q.mt;
+    mt = cdiv(q.mt, q.mgroup) * q.mgroup;
+  }
+  return mt * q.nt * q.ncls * q.nsplit;
+}
+
 template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
@@ -1028,8 +1088,9 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
-  dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
-  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(p);
+  PlGatherParams q = p;
+  q.mt = cdiv(M, BM); q.nt = cdiv(p.N, BN);
+  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<pl_grid(q), 256, smem, st>>>(q);
   return launch_status();
 }
 
@@ -1081,8 +1142,9 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     smem_set = smem;
   }
-  dim3 grid(p.B * p.tiles_y * p.tiles_x, cdiv(p.N, BN), p.ncls * p.nsplit);
-  igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<grid, 256, smem, st>>>(p, hp);
+  PlGatherParams q = p;
+  q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
+  igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<pl_grid(q), 256, smem, st>>>(q, hp);
   return launch_status();
 }
 
@@ -1095,7 +1157,11 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   p.dbg = pl_dbg();
   {
     static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
+    static const int ord = getenv("UNFLOW_XCD_ORDER") ? atoi(getenv("UNFLOW_XCD_ORDER")) : -1;     // A/B knob: force 0 / 1
     p.xcd = xcd;
+    // order 2 (M groups per XCD, M tile fastest inside) measured best or tied on every layer of FlowNetC 384x512 B=4 against
+    // 0 and 1 (profiles/r02_xcd_order_per_layer.txt)
+    p.order = ord >= 0 ? ord : 2;
   }
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
@@ -1164,8 +1230,11 @@ int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
-  dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
-  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE><<<grid, 256, smem, st>>>(p);
+  PlWgradParams q = p;
+  q.mt = cdiv(Mp, BM); q.nt = cdiv(p.Cb, BN);
+  static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
+  q.xcd = xcd;
+  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
   return launch_status();
 }
 
