@@ -1,0 +1,7 @@
+set -x
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02m; mkdir -p $O
+for d in 17 16 0; do
+UNFLOW_DBG=$d timeout 200 python tools/per_layer_bench.py > $O/per_layer_dbg$d.txt 2>$O/err_dbg$d.txt
+done

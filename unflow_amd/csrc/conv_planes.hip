@@ -51,6 +51,8 @@ struct PlGatherParams : GatherGeom {
   int mt, nt;                  // M tiles, N tiles of the launch (the grid is 1-D: mt * nt * ncls * nsplit workgroups)
   int order;                   // work order (work_decode): 0 N tile fastest .. M tile slowest; 1 M tile fastest; 2 M groups
   int mgroup;                  // order 2: M tiles per group (one group per XCD)
+  int tw_log;                  // gather kernel: 0 = an M tile is BM consecutive sites of the linear (b, y, x) order; else the
+                               // tile is (BM >> tw_log) rows x (1 << tw_log) sites of one image (tiles_x, tiles_y per image)
   int gpx;                     // pixels per K granule along x (0: a granule is 8 channels of ONE pixel; 2: conv1 form, below)
   PlaneOut pl;
 };
@@ -247,13 +249,32 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 
   const int kq = tid & 3;
   const int lds2 = p.lds * 2;
+  // row r of the tile -> site (b, yg, xg); valid: the site exists
+  auto site_of = [&](int r, int& b, int& yg, int& xg) -> bool {
+    if (p.tw_log) {
+      // 2-D tiles: (BM / TW) rows x TW sites.  With a source stride of 2 a 4 x 32 tile of a 5x5 conv touches 11 x 67 source
+      // pixels, a 1 x 128 tile 5 x 259: 43 % fewer bytes through L2 for the layers whose source does not stay in L2
+      // between taps (conv2 forward moved 1.5 GB at 5.9 TB/s, the Infinity-Cache rate).
+      int t = mtile;
+      const int txi = t % p.tiles_x; t /= p.tiles_x;
+      const int tyi = t % p.tiles_y;
+      b = t / p.tiles_y;
+      yg = tyi * (BM >> p.tw_log) + (r >> p.tw_log);
+      xg = (txi << p.tw_log) + (r & ((1 << p.tw_log) - 1));
+      return true;
+    }
+    const int m = m0 + r;
+    xg = m % p.Wg;
+    const int t = m / p.Wg;
+    yg = t % p.Hg;
+    b = t / p.Hg;
+    return m < M;
+  };
   int a_yx[AR], a_lin[AR];     // (y << 16 | x) of the site's source origin; byte offset of that pixel (or the OOB mark)
 #pragma unroll
   for (int i = 0; i < AR; i++) {
-    const int m = m0 + (tid >> 2) + 64 * i;
-    if (m < M) {
-      const int xg = m % p.Wg, t = m / p.Wg;
-      const int yg = t % p.Hg, b = t / p.Hg;
+    int b, yg, xg;
+    if (site_of((tid >> 2) + 64 * i, b, yg, xg)) {
       const int y = yg * p.sm, x = xg * p.sm;
       a_yx[i] = (y << 16) | x;
       a_lin[i] = (b * p.Hs * p.Ws + y * p.Ws + x) * lds2;
@@ -263,13 +284,8 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
     }
   }
   if (tid < BM) {
-    const int m = m0 + tid;
-    int v = -1;
-    if (m < M) {
-      const int xg = m % p.Wg, t = m / p.Wg;
-      const int yg = t % p.Hg, b = t / p.Hg;
-      v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
-    }
+    int b, yg, xg, v = -1;
+    if (site_of(tid, b, yg, xg)) v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
     pix[tid] = v;
   }
   int b_row[NB];
@@ -927,6 +943,189 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
     }
 }
 
+// ------------------------------------------------------------------------------------------------ filter gradient, LDS-DMA form
+// Same product, tiles, LDS image and MFMA loop as igemm_pl_wgrad_kernel (3 planes), different staging: the operand rows
+// ([site][channels], 256 contiguous bytes per site and plane) go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds, no
+// staging registers, no ds_write pass), in stages of 16 sites, double-buffered: the six loads of stage s+1 are in flight
+// while the 24 MFMAs of stage s run, and ONE barrier per stage publishes them (the register-staged kernel needs two per 32
+// sites around its ds_write pass, and its loads could only start once the previous tile's registers were stored).  A wave
+// instruction writes lane-linear: 64 lanes x 16 bytes = 4 site rows x 16 granule slots, so the XOR swizzle of the
+// transposing-read image is applied on the SOURCE side — lane (row, slot) fetches the granule that belongs in that slot.
+// Out-of-range rows (image border taps, the tail of the site range, channel padding) are buffer offsets >= num_records:
+// the hardware writes zeros.  48 KB of LDS and <= 168 registers: three blocks per CU, as before.
+template <int BN, int WN>
+__global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
+  constexpr int BM = 128, WM = 64, NPL = 3, NT = 6, KS = 16;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  static_assert(BN == 128 || BN == 64, "swizzle forms");
+  constexpr int A_PLANE = KS * BM, B_PLANE = KS * BN;            // elements
+  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  constexpr int B_RPI = 512 / BN;                                // site rows per wave instruction: 4 (256-byte rows) / 8
+  constexpr int B_NI = KS / B_RPI;                               // wave instructions per plane and stage: 4 / 2
+  constexpr int B_SLOTS = BN / 8;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int taps = p.KH * p.KW;
+  const int Cag = p.Ca >> 3;
+  const int Mg = taps * Cag;
+  int v = xcd_remap(blockIdx.x, gridDim.x, p.xcd);               // work order: see igemm_pl_wgrad_kernel
+  const int mtile = v % p.mt; v /= p.mt;
+  const int ntile = v % p.nt;
+  const int split = v / p.nt;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int S = p.B * p.Hg * p.Wg;
+  const int KT = (S + KS - 1) / KS;
+  const int kt_per = (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;   // whole 32-site tiles per split, as the planner counts them
+  const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
+
+  // buffer descriptors as plain dwords (the LDS-DMA loads are inline asm: hipcc would otherwise wait vmcnt(0) in front of
+  // every ds_read that follows a load into the same LDS array, i.e. drain the stage in flight)
+  u32x4 src_rs[NPL], dst_rs[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = raw_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
+    dst_rs[pl] = raw_rsrc(p.dst + pl * p.dst_ps, (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
+  }
+
+  // gathered operand: lane -> (site row 4*wid + lane/16 of the stage, slot lane%16); the granule stored in that slot
+  const int a_k = 4 * wid + (lane >> 4);
+  const int a_slot = lane & 15;
+  const int a_g = ((((a_slot >> 1) ^ ((a_k & 3) << 1)) << 1) | (a_slot & 1));
+  const int mg = (m0 >> 3) + a_g;
+  const bool m_ok = mg < Mg;
+  const unsigned tap = p.cag_magic ? fast_div((unsigned)mg, p.cag_magic) : (unsigned)mg;
+  const int ag = mg - (int)tap * Cag;
+  const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
+  const int dy = p.dy0 + ky, dx = p.dx0 + kx + p.gpx * ag;
+  const int lds2 = p.lds * 2;
+  const int a_lane_off = (dy * p.Ws + (p.dx0 + kx)) * lds2 + ag * 16;
+  // dense operand
+  const int b_k = B_RPI * wid + lane / B_SLOTS;                  // (waves >= B_NI issue no B load)
+  const int b_slot = lane % B_SLOTS;
+  const int b_sw = BN == 128 ? ((b_k & 3) << 1) : (((b_k >> 1) & 1) << 1);
+  const int b_g = ((((b_slot >> 1) ^ b_sw) << 1) | (b_slot & 1));
+  const int nbq = (n0 >> 3) + b_g;
+  const bool b_ok = nbq * 8 < p.Cb;
+  const int b_lane_off = nbq * 16;
+  const int ldd2 = p.ldd * 2;
+  const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
+
+  const unsigned lds0 = lds_addr(smem16);
+  auto issue = [&](int kt, int buf) {
+    const unsigned st = lds0 + (unsigned)(buf * STAGE * 2);      // byte address of the stage in LDS
+    {
+      const unsigned sidx = (unsigned)(kt * KS + a_k);
+      const unsigned q = fast_div(sidx, magW);
+      const int xg = (int)(sidx - q * (unsigned)p.Wg);
+      const unsigned bb = fast_div(q, magH);
+      const int yg = (int)(q - bb * (unsigned)p.Hg);
+      const int yb = yg * p.sm, xb = xg * p.sm;
+      const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
+      const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
+      const unsigned d = st + (unsigned)(4 * wid * BM * 2);
+      dma3(voff, src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
+    }
+    if (wid < B_NI) {
+      const int sidx = kt * KS + b_k;
+      const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
+      const unsigned d = st + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
+      dma3(voff, dst_rs[0], dst_rs[1], dst_rs[2], d, d + B_PLANE * 2, d + 2 * B_PLANE * 2);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int i16 = lane & 15, grp = lane >> 4, lh = grp >> 1;
+  const int krow = 8 * lh + (i16 >> 2);
+  int a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const int c = wm * WM + i * 32 + 16 * (grp & 1) + 4 * (i16 & 3);
+    a_rd[i] = tr_swz<BM>(krow, c >> 3) + (c & 7);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int c = wn * WN + j * 32 + 16 * (grp & 1) + 4 * (i16 & 3);
+    b_rd[j] = NPL * A_PLANE + tr_swz<BN>(krow, c >> 3) + (c & 7);
+  }
+
+  if (kt0 < kt1) issue(kt0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int cur = (kt - kt0) & 1;
+    // stage kt+1 -> the other buffer (every wave passed the barrier after its reads of that buffer); past the last stage the
+    // loads are all out of range (zeros into a buffer nobody reads)
+    if (!(p.dbg & 1)) issue(kt + 1 < kt1 ? kt + 1 : KT + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned short* st = smem16 + ((p.dbg & 32) ? 0 : cur * STAGE);   // ablation 32: always the same buffer
+    s16x8 av[TM][NPL], bv[TN][NPL];
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) {
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const unsigned short* b0 = st + pl * A_PLANE + a_rd[i];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BM));
+        av[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const unsigned short* b0 = st + pl * B_PLANE + b_rd[j];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BN));
+        bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+    // own loads landed + own LDS reads retired, then the barrier: stage kt+1 is complete and buffer `cur` is free (the
+    // scheduling fences keep the MFMAs above and the next stage's loads below it)
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.dbg & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ablation: do not wait for the loads (wrong results)
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();                       // ablation 16: no barrier (wrong results)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  float* o = p.nsplit > 1 ? p.partial + (size_t)split * taps * p.Ca_out * p.Cb : p.out;
+  const int lh5 = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh5;
+      const int mgr = m >> 3;
+      if (mgr >= Mg) continue;
+      const unsigned tp = p.cag_magic ? fast_div((unsigned)mgr, p.cag_magic) : (unsigned)mgr;
+      const int a = (mgr - (int)tp * Cag) * 8 + (m & 7);
+      if (a >= p.Ca_out) continue;
+      float* orow = o + ((size_t)tp * p.Ca_out + a) * p.Cb;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        if (n < p.Cb) orow[n] = acc[i][j][r];
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ plane producers
 // fp32 [npix][ldx] (C channels used) -> planes [npix][ldp] with channels C .. Cp-1 zero-filled (Cp a multiple of 4, >= C)
 __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, long npix, int C, int Cp, PlaneOut o) {
@@ -1090,6 +1289,19 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   (void)attr;
   PlGatherParams q = p;
   q.mt = cdiv(M, BM); q.nt = cdiv(p.N, BN);
+  {
+    // 2-D tiles when they divide the site grid exactly (TW = min(32, Wg) sites wide)
+    static const int tiles2d = getenv("UNFLOW_GATHER_TILE2D") ? atoi(getenv("UNFLOW_GATHER_TILE2D")) : 1;   // A/B knob
+    int twl = 0;
+    while ((2 << twl) <= p.Wg && (2 << twl) <= 32) twl++;
+    const int tw = 1 << twl, th = BM >> twl;
+    q.tw_log = 0;
+    if (tiles2d && twl >= 3 && th >= 2 && p.Wg % tw == 0 && p.Hg % th == 0 && th * tw == BM) {
+      q.tw_log = twl;
+      q.tiles_x = p.Wg / tw;
+      q.tiles_y = p.Hg / th;
+    }
+  }
   igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<pl_grid(q), 256, smem, st>>>(q);
   return launch_status();
 }
@@ -1238,6 +1450,26 @@ int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   return launch_status();
 }
 
+template <int BN, int WN>
+int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int smem = 2 * 3 * (128 + BN) * 16 * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)attr;
+  PlWgradParams q = p;
+  q.mt = cdiv(Mp, 128); q.nt = cdiv(p.Cb, BN);
+  static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
+  q.xcd = xcd;
+  igemm_pl_wgrad_dma_kernel<BN, WN><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
+  return launch_status();
+}
+
+inline bool pl_wgrad_dma() {    // UNFLOW_WGRAD_DMA=0: the register-staged kernel (A/B knob)
+  static const bool on = !(getenv("UNFLOW_WGRAD_DMA") && atoi(getenv("UNFLOW_WGRAD_DMA")) == 0);
+  return on;
+}
+
 inline bool pl_wgrad_pipe() {   // UNFLOW_WGRAD_PIPE=1: both slabs' fragments in flight, two waves per SIMD (A/B knob)
   static const bool on = getenv("UNFLOW_WGRAD_PIPE") && atoi(getenv("UNFLOW_WGRAD_PIPE")) != 0;
   return on;
@@ -1257,7 +1489,8 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
   *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
   const int cfg = pl_wgrad_cfg(p);
   int code;
-  if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st)
+  if (npl == 3 && pl_wgrad_dma()) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32>(p, st) : launch_pl_wgrad_dma<128, 64>(p, st);
+  else if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st)
                      : pl_wgrad_pipe() ? launch_pl_wgrad<128, 128, 64, 64, 3, false, true>(p, st)
                                        : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);

@@ -68,6 +68,38 @@ __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
+// ---- LDS-DMA (buffer_load ... lds) as inline asm --------------------------------------------------------------------------
+// hipcc counts a __builtin_amdgcn_raw_ptr_buffer_load_lds as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the
+// next ds_read of the same array — which drains the stage a double-buffered loop wants in flight.  As inline asm the loads
+// are invisible to that bookkeeping; the kernel waits for them itself (s_waitcnt vmcnt(0) + s_barrier before the stage is
+// read).  M0 = LDS byte address of the wave's 1 KB destination (lane i lands at M0 + 16 i); M0 is compiler-reserved, so it
+// is saved and restored inside the statement.  Out-of-range offsets (>= num_records) write zeros.
+__device__ __forceinline__ u32x4 raw_rsrc(const void* p, size_t bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  u32x4 r;
+  r.x = (unsigned)a;
+  r.y = (unsigned)(a >> 32) & 0xffffu;
+  r.z = (unsigned)(bytes > 0x3fffffffu ? 0x3fffffffu : bytes);
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+// three 16-byte-per-lane loads (one per plane) with the same per-lane offset into three descriptors / LDS destinations
+__device__ __forceinline__ void dma3(int voff, u32x4 r0, u32x4 r1, u32x4 r2, unsigned d0, unsigned d1, unsigned d2) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r0], 0 offen lds\n\t"
+      "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r1], 0 offen lds\n\t"
+      "s_mov_b32 m0, %[d2]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r2], 0 offen lds\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [v] "v"(voff), [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [d0] "s"(d0), [d1] "s"(d1), [d2] "s"(d2)
+      : "memory");
+}
+
 // ---- fp32 -> 16-bit operand planes -------------------------------------------------------------------------------------
 // x = hi + mid + lo with three bf16 values (3 x 8 significand bits = the 24 of fp32, same exponent range); a*b is summed
 // from the six terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 (fp32 accumulation); the
