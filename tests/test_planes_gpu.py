@@ -317,3 +317,59 @@ def test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib):
     got = out[..., :oc].permute(0, 3, 1, 2).cpu().numpy()
     assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     assert out[..., oc:].abs().max().item() == 0
+
+
+# (B, H, W, Cin, Cout, k, stride): shapes whose forward / data gradient split K (few output tiles, deep K)
+SPLITK_CASES = [
+    (8, 96, 128, 128, 256, 5, 2),    # conv3: gather kernel forward with 2 slices per tile (fused), halo data gradient
+    (8, 48, 64, 256, 256, 3, 1),     # conv3_1-like: halo kernel, 4 slices over channel chunks (fused)
+    (8, 48, 64, 256, 512, 3, 2),     # conv4: gather forward 4 slices (fused), 4-class data gradient
+    (8, 12, 16, 512, 512, 3, 1),     # conv5_1: 16 slices -> the reduce kernel
+]
+
+
+def _splitk_outputs(case, dev, reps):
+    """Forward + data gradient of one layer, `reps` times into fresh buffers: list of (y, dx) CPU tensors."""
+    from unflow_amd.core import layers as L
+    B, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(k, k, Cin, Cout, generator=g) * (1.0 / np.sqrt(k * k * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = L.out_hw(H, W, stride)
+    dz = torch.randn(B, Ho, Wo, Cout, generator=g)
+    X, DZ = make_pt(x, dev, 3), make_pt(dz, dev, 3)
+    wd, w_dir, w_tr = weight_planes(w, dev, 3)
+    outs = []
+    for _ in range(reps):
+        Y = L.PT.alloc((B, Ho, Wo, Cout), dev, 3)
+        DX = L.PT.alloc((B, H, W, Cin), dev, 3)
+        L.conv_fwd(X, wd, w_tr, b.to(dev), Y, stride, True)
+        L.conv_bwd_data(DZ, wd, w_dir, DX, stride, accumulate=False)
+        # a second, dependent launch right behind (the hand-off must also hold with the consumer hot on the producer's heels)
+        L.conv_bwd_data(DZ, wd, w_dir, DX, stride, accumulate=True)
+        outs.append((Y.t.cpu(), DX.t.cpu(), Y.pl.cpu()))
+    return outs
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_fused_splitk_bit_identical_to_reduce_kernel(case, dev, tmp_path):
+    """The optional in-kernel split-K reduction (UNFLOW_FUSED_SPLITK=n: the last-arriving block of a tile sums the partial
+    tiles in slice order; write-through partial stores, relaxed agent-scope ticket, sc1 loads) is bit-identical to the default
+    fixed-order reduce kernel and stable over 20 back-to-back launches whatever the arrival order.  The knob is read once
+    per process, so the fused run is a sub-process."""
+    import os
+    import subprocess
+    import sys
+    ref = _splitk_outputs(case, dev, 1)[0]
+    f = str(tmp_path / "fused.pt")
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_planes_gpu as T; "
+            "o = T._splitk_outputs(%r, torch.device('cuda:0'), 20); "
+            "assert all(torch.equal(a, b) for q in o[1:] for a, b in zip(q, o[0])), 'fused split-K not stable run to run'; "
+            "torch.save(o[0], %r)"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), case, f))
+    env = dict(os.environ, UNFLOW_FUSED_SPLITK="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    y0, dx0, pl0 = torch.load(f)
+    assert torch.equal(y0, ref[0]) and torch.equal(dx0, ref[1]) and torch.equal(pl0, ref[2])

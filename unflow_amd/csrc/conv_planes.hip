@@ -44,6 +44,8 @@ struct PlGatherParams : GatherGeom {
   int lds, ldd, ld_act, act_lo, act_hi;
   int nsplit;
   int leaky, accumulate;
+  int* counters;               // fused split-K: one arrival counter per (class, M tile, N tile), zeroed before the launch
+  int fused_splitk;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
   int dbg;                     // ablation switches (UNFLOW_DBG env; 0 in production): 1 no loads in the loop, 2 no LDS stores
@@ -122,6 +124,85 @@ __device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (
   }
 }
 
+// bias / leaky-ReLU / accumulate / leaky derivative of four consecutive output channels, fp32 store + output planes
+__device__ __forceinline__ void epi_store4(const PlGatherParams& p, size_t px, int n, float4 v) {
+  if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
+  if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
+  float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
+  if (p.accumulate) {
+    const float4 e = *d;
+    v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+  }
+  if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
+    const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
+    if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
+    if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
+    if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
+    if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
+  }
+  *d = v;
+  store_planes4(p.pl, px, n, v);
+}
+
+// Split-K without a second kernel (tiles with few slices): after its partial tile is stored, a block takes a ticket on its
+// tile's counter; the block that draws nsplit - 1 (every slice of the tile is then in memory) sums the nsplit partial tiles
+// in slice order — the result does not depend on which block arrives last, and equals the separate reduce kernel's bit for
+// bit — and applies the epilogue.  Hand-off (cdna_hip_programming.md §5 / §6 G16, write-through form): partial tiles are
+// stored with sc1 (write-through) 16-byte buffer stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 relaxed
+// agent-scope ticket; the last arriver reads the slabs with sc1 loads (served by L2 / fabric, never a stale L1 line).
+// No cache-wide fence: a release fence per block (buffer_wbl2) made every split launch ~40 us slower than the separate
+// reduce pass it was meant to replace.  Correct for any placement of a tile's slices over CUs / XCDs.  The counters are
+// zeroed by a memset node ahead of the launch.  Returns true in the block that has to reduce (all threads, after a barrier).
+__device__ __forceinline__ bool splitk_last_arriver(const PlGatherParams& p, int tile_id, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return *flag == p.nsplit - 1;
+}
+
+constexpr int AUX_SC1 = 16;    // cache-policy bits of the raw buffer intrinsics: sc1 = write-through store / L1-bypassing load
+
+// the last arriver's pass over its BM x BN tile: fixed-order sum of the partials + epilogue; EU float4 per thread in flight
+// per slice (a single block has to keep >= 8-16 loads per lane outstanding to read the slabs at a useful rate)
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_tile_reduce(const PlGatherParams& p, const int* pix, int n0) {
+  constexpr int QPR = BN / 4;
+  constexpr int PER = BM * QPR / 256;              // float4 per thread: 16 / 8 / 4
+  constexpr int EU = PER < 4 ? PER : 4;
+  const size_t slab_f = (size_t)p.B * p.Hd * p.Wd * p.N;      // floats per split
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.partial, slab_f * 4 * (size_t)p.nsplit);
+  const int slab_b = (int)(slab_f * 4);
+#pragma unroll 1
+  for (int e0 = 0; e0 < PER; e0 += EU) {
+    int off[EU], px[EU], nn[EU];
+    float4 v[EU];
+#pragma unroll
+    for (int u = 0; u < EU; u++) {
+      const int e = threadIdx.x + 256 * (e0 + u);
+      const int row = e / QPR;
+      nn[u] = n0 + 4 * (e % QPR);
+      px[u] = pix[row];
+      const bool ok = px[u] >= 0 && nn[u] < p.N;
+      off[u] = ok ? (px[u] * p.N + nn[u]) * 4 : OOB_MARK;       // out of range: zeros, and the store below is skipped
+      if (!ok) px[u] = -1;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll 4
+    for (int s2 = 0; s2 < p.nsplit; s2++) {
+#pragma unroll
+      for (int u = 0; u < EU; u++) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], s2 * slab_b, AUX_SC1);
+        v[u].x += __uint_as_float(t.x); v[u].y += __uint_as_float(t.y);
+        v[u].z += __uint_as_float(t.z); v[u].w += __uint_as_float(t.w);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; u++)
+      if (px[u] >= 0) epi_store4(p, (size_t)px[u], nn[u], v[u]);
+  }
+}
+
 // Epilogue shared by the gather kernels: bias / leaky-ReLU / accumulate / leaky derivative, fp32 result + output planes, or
 // the split-K partial.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int WM, int WN>
@@ -141,6 +222,7 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
     constexpr int QPR = WN / 4, RPI = 64 / QPR;
     float* stg = reinterpret_cast<float*>(smem16) + wid * (32 * EP);
     const size_t npix_d = (size_t)p.B * p.Hd * p.Wd;
+    const __amdgpu_buffer_rsrc_t part_rs = make_rsrc(p.partial, to_partial ? npix_d * p.N * 4 * (size_t)p.nsplit : 0);
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -155,25 +237,17 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
         const int n = n0 + wn * WN + 4 * q;
         if (px < 0 || n >= p.N) continue;
         if (to_partial) {
-          *reinterpret_cast<float4*>(p.partial + ((size_t)split * npix_d + px) * p.N + n) = v;
+          float* dp = p.partial + ((size_t)split * npix_d + px) * p.N + n;
+          if (p.fused_splitk) {   // write-through: the last arriver of the tile reads it from L2 / fabric (splitk_last_arriver)
+            u32x4 t;
+            t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+            __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (int)(((size_t)px * p.N + n) * 4), split * (int)(npix_d * p.N * 4), AUX_SC1);
+          } else {
+            *reinterpret_cast<float4*>(dp) = v;
+          }
           continue;
         }
-        if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
-        if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
-        float4* d = reinterpret_cast<float4*>(p.dst + (size_t)px * p.ldd + n);
-        if (p.accumulate) {
-          const float4 e = *d;
-          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
-        }
-        if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
-          const float4 a = *reinterpret_cast<const float4*>(p.act_src + (size_t)px * p.ld_act + n);
-          if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
-          if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
-          if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
-          if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
-        }
-        *d = v;
-        store_planes4(p.pl, (size_t)px, n, v);
+        epi_store4(p, (size_t)px, n, v);
       }
     }
     return;
@@ -416,6 +490,10 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   }
 
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
+  if (p.fused_splitk) {
+    if (!splitk_last_arriver(p, (cls_id * p.mt + mtile) * p.nt + ntile, pix + BM)) return;
+    splitk_tile_reduce<BM, BN>(p, pix, n0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ halo gather kernel
@@ -460,6 +538,7 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   int t, ntile, cls_id, split;
   work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id, split);
   if (t < 0) return;
+  const int mtile_id = t;
   const TapClass tc = p.cls[cls_id];
   const int n0 = ntile * BN;
   const int ntaps = tc.nty * tc.ntx;
@@ -664,6 +743,10 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
     ld_advance(kk + 1);
   }
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
+  if (p.fused_splitk) {
+    if (!splitk_last_arriver(p, (cls_id * p.mt + mtile_id) * p.nt + ntile, pix + BM)) return;
+    splitk_tile_reduce<BM, BN>(p, pix, n0);
+  }
 }
 
 // Fixed-order sum of the split-K partials + the epilogue (+ the output planes).  One float4 per thread.
@@ -683,22 +766,7 @@ __global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec
         const float4 t = src[(size_t)s * totq];
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
-      if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
-      if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
-      float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
-      if (p.accumulate) {
-        const float4 e = *d;
-        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
-      }
-      if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
-        const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
-        if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
-        if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
-        if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
-        if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
-      }
-      *d = v;
-      store_planes4(p.pl, px, n, v);
+      epi_store4(p, px, n, v);
     }
     return;
   }
@@ -1234,7 +1302,7 @@ struct PlPlan {
   int nsplit;
 };
 
-inline int pl_smem_gather(int bm, int bn, int npl) { return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl) + bm * 4; }
+inline int pl_smem_gather(int bm, int bn, int npl) { return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl) + bm * 4 + 16; }   // + the pixel table + the split-K flag
 
 // blocks per CU by LDS (160 KB) and registers (<= 168: 3 waves per SIMD)
 inline int pl_blocks_per_cu(int bm, int bn, int npl) {
@@ -1266,8 +1334,16 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   return pl;
 }
 
+inline size_t pl_gather_counter_bytes(const GatherGeom& p) {      // arrival counters of the fused split-K (64 x 64 tiles at worst)
+  const size_t M = (size_t)p.B * p.Hg * p.Wg;
+  const size_t halo_tiles = (size_t)p.B * (p.Hg / 4 + 1) * (p.Wg / 32 + 1);     // 4 x 32-site tiles, ragged edges included
+  return ((((M + 63) / 64 + 8) + halo_tiles) * ((p.N + 63) / 64) * p.ncls * sizeof(int) + 255) & ~(size_t)255;
+}
+inline size_t pl_gather_slab_bytes(const GatherGeom& p, int nsplit) {
+  return (((size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float)) + 255) & ~(size_t)255;
+}
 inline size_t pl_gather_partial_bytes(const GatherGeom& p, int nsplit) {
-  return nsplit > 1 ? (size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
+  return nsplit > 1 ? pl_gather_slab_bytes(p, nsplit) + pl_gather_counter_bytes(p) : 0;
 }
 
 // workgroups of a launch (q.mt, q.nt set): order 2 pads the M tiles to whole groups
@@ -1302,7 +1378,9 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
       q.tiles_y = p.Hg / th;
     }
   }
-  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<pl_grid(q), 256, smem, st>>>(q);
+  const int grid = pl_grid(q);
+  if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q);
   return launch_status();
 }
 
@@ -1329,7 +1407,7 @@ inline int pl_halo_pixels(const GatherGeom& p) {
   return hp;
 }
 inline int pl_halo_smem(const GatherGeom& p, int bn, int npl) {
-  return pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, npl, pl_halo_pixels(p)) + 128 * 4;
+  return pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, npl, pl_halo_pixels(p)) + 128 * 4 + 16;
 }
 inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
   const int bn = p.N <= 64 ? 64 : 128;
@@ -1347,7 +1425,7 @@ inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
 template <int BN, int WN, int NPL, bool F16>
 int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   const int hp = pl_halo_pixels(p);
-  const int smem = pl_halo_main_bytes(BN, WN, NPL, hp) + 128 * 4;
+  const int smem = pl_halo_main_bytes(BN, WN, NPL, hp) + 128 * 4 + 16;
   static int smem_set = 0;      // grow-only (the halo size depends on the layer): benign race, idempotent
   if (smem > smem_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, 64, WN, NPL, F16>),
@@ -1356,7 +1434,9 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   }
   PlGatherParams q = p;
   q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
-  igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<pl_grid(q), 256, smem, st>>>(q, hp);
+  const int grid = pl_grid(q);
+  if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<grid, 256, smem, st>>>(q, hp);
   return launch_status();
 }
 
@@ -1395,6 +1475,16 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     p.vec_epi = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0 &&
                 (!p.pl.n_planes || p.pl.ld % 4 == 0);
   }
+  {
+    // UNFLOW_FUSED_SPLITK=n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
+    // chip-wide reduce kernel: measured on MI355X (FlowNetC 384x512 B=4) the fused form is bit-identical but not faster —
+    // n = 4: 597 vs 599 image-pairs/s, n = 16 with release/acquire fences: 521 vs 590 — although the reduce launches cost
+    // 0.69 ms of the step (no-reduce ablation, UNFLOW_DBG=128): what they cost is the second pass over the partials, which
+    // one block per tile does no faster than 256 CUs.  Kept as a tested alternative.
+    static const int fused = getenv("UNFLOW_FUSED_SPLITK") ? atoi(getenv("UNFLOW_FUSED_SPLITK")) : 0;
+    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu;
+    p.counters = p.fused_splitk ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pl_gather_slab_bytes(p, p.nsplit)) : nullptr;
+  }
   int code;
   if (halo) {
     if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
@@ -1403,7 +1493,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   }
   if (code != UNFLOW_OK) return code;
-  if (p.nsplit > 1) {
+  if (p.nsplit > 1 && !p.fused_splitk && !(p.dbg & 128)) {     // 128: timing experiment (no reduce: wrong results)
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
     const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
                          reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0);
@@ -1495,7 +1585,7 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
                                        : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
   if (code != UNFLOW_OK) return code;
-  if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);
+  if (ns > 1 && !(p.dbg & 64)) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);   // 64: timing experiment
   return UNFLOW_OK;
 }
 
