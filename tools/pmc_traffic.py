@@ -1,7 +1,7 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only, as MI355X_MICROARCH.md prescribes)
 of `bench.py --no-graph` into per-step HBM traffic of the conv-kernel family.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE STEPS+WARMUP > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py <FETCH_SIZE pass dir> <WRITE_SIZE pass dir> [n_params] > profiles/rNN_pmc_traffic.json
 
 Units / corrections: rocprofv3 reports both counters in KiB-like units of 1024 B ("KB"); on gfx950 FETCH_SIZE tallies
 128-byte requests at 64 B, so wide coalesced reads show exactly half their bytes (guide, HBM section) -> x2.  Both
@@ -16,9 +16,13 @@ from collections import defaultdict
 
 
 def load(d):
+    """Counter sums and dispatch counts per kernel over ONE training step: the dispatches between the last two Adam launches."""
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
+    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+    rows = rows[adam[-2] + 1: adam[-1] + 1]
     tot, cnt = defaultdict(float), defaultdict(int)
-    for r in csv.DictReader(open(f)):
+    for r in rows:
         k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0]
         tot[k] += float(r['Counter_Value'])
         cnt[k] += 1
@@ -26,8 +30,9 @@ def load(d):
 
 
 def main():
-    fd, wd, nsteps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    n_params = 39175298 if len(sys.argv) < 5 else int(sys.argv[4])
+    fd, wd = sys.argv[1], sys.argv[2]
+    nsteps = 1          # load() keeps exactly one step
+    n_params = 39175298 if len(sys.argv) < 4 else int(sys.argv[3])
     f, fc = load(fd)
     w, wc = load(wd)
     adam = [k for k in f if 'adam' in k][0]
