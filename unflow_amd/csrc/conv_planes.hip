@@ -283,6 +283,10 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
 // 256 threads = 4 waves.  Loads: thread (kq = tid & 3, r = tid >> 2) fetches granule kq (8 consecutive k) of rows r, r + 64
 // of each operand and plane: a wave instruction covers 16 rows x 64 contiguous bytes.  The loads of tile t+1 sit between
 // the MFMA groups of tile t (sched_barrier fences); single LDS stage, 3 blocks per CU resident and out of phase.
+// (Tried and dropped: the LDS-DMA form that pays for the filter gradients — K16 stages, double-buffered, one barrier per
+// stage, 118 registers.  A K16 stage of a gathered operand is 32 bytes per row: conv2 / conv3 forward 261 -> 326 us,
+// 251 -> 329 us, stride-2 data gradients 142 -> 173 us, the step 598 -> 570 image-pairs/s.  The 64-byte row pieces of a
+// K32 tile are the smallest unit the L1 / TA path moves efficiently; two K32 stages are 96 KB of LDS, one block per CU.)
 template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_gather_kernel(const PlGatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -1356,6 +1360,21 @@ inline int pl_grid(PlGatherParams& q) {
   return mt * q.nt * q.ncls * q.nsplit;
 }
 
+// 2-D site tiles of the plain gather kernels when they divide the site grid exactly (TW = min(32, Wg) sites wide)
+template <int BM>
+inline void pl_gather_tiles2d(PlGatherParams& q) {
+  static const int tiles2d = getenv("UNFLOW_GATHER_TILE2D") ? atoi(getenv("UNFLOW_GATHER_TILE2D")) : 1;   // A/B knob
+  int twl = 0;
+  while ((2 << twl) <= q.Wg && (2 << twl) <= 32) twl++;
+  const int tw = 1 << twl, th = BM >> twl;
+  q.tw_log = 0;
+  if (tiles2d && twl >= 3 && th >= 2 && q.Wg % tw == 0 && q.Hg % th == 0 && th * tw == BM) {
+    q.tw_log = twl;
+    q.tiles_x = q.Wg / tw;
+    q.tiles_y = q.Hg / th;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
@@ -1365,19 +1384,7 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   (void)attr;
   PlGatherParams q = p;
   q.mt = cdiv(M, BM); q.nt = cdiv(p.N, BN);
-  {
-    // 2-D tiles when they divide the site grid exactly (TW = min(32, Wg) sites wide)
-    static const int tiles2d = getenv("UNFLOW_GATHER_TILE2D") ? atoi(getenv("UNFLOW_GATHER_TILE2D")) : 1;   // A/B knob
-    int twl = 0;
-    while ((2 << twl) <= p.Wg && (2 << twl) <= 32) twl++;
-    const int tw = 1 << twl, th = BM >> twl;
-    q.tw_log = 0;
-    if (tiles2d && twl >= 3 && th >= 2 && p.Wg % tw == 0 && p.Hg % th == 0 && th * tw == BM) {
-      q.tw_log = twl;
-      q.tiles_x = p.Wg / tw;
-      q.tiles_y = p.Hg / th;
-    }
-  }
+  pl_gather_tiles2d<BM>(q);
   const int grid = pl_grid(q);
   if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
   igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q);
