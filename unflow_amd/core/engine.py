@@ -377,11 +377,12 @@ class _Stage:
         # reads it before the optimizer, so groups of them run on a second stream beside the data-gradient chain (own
         # split-K scratch, ws_slot 3); the part joins before it returns.  The small deep layers, whose kernels cannot fill
         # the chip alone, are where this pays (+2.9 % on the benchmarked step).  The Cout = 2 layers (flow heads, 2 -> 2
-        # flow upsamplers) stay on the main stream: measured on MI355X / ROCm 7.2, the tiny_deconv_wgrad_kernel of a
-        # replayed two-branch hipGraph returned 2-3 of its 64 sums off by ~1e-3 whenever it ran beside a main-branch
-        # kernel (never eagerly, never with a join after each group, never with the gradients deferred to the end of the
-        # part: tools/debug/wgstream_diff.py; cause not found) — tests/test_engine_gpu.py asserts bit-identity of the two
-        # schedules over repeated replays.
+        # flow upsamplers) stay on the main stream (wgrad_inline_tiny; they are too small to matter).  History: the 2 -> 2
+        # filter gradient of a replayed two-branch graph used to return one wrong sum in ~10 % of the replays whenever a
+        # kernel of the other branch shared its SIMD; root cause: a compiler-formed v_pk_mul_f32 whose destination pair
+        # overlaps an op_sel-selected source (unflow_amd/build.py: the library is now built with -fno-slp-vectorize;
+        # tools/debug/wgstream_flake.py reproduces it with the old flags).  tests/test_engine_gpu.py asserts bit-identity of
+        # the two schedules over repeated replays.
         side = e.wgrad_stream
         main = torch.cuda.current_stream(e.dev)
         pending = []

@@ -15,10 +15,10 @@
 // No LDS, no barriers; zero padding is a bounds check (the reference materialises two padded copies).
 // Work decomposition: sample index fastest in the block id, so block b runs on XCD b % 8 = its
 // sample when B == 8 and the rows of one sample stay in one XCD's L2.
-#include "common.h"
+#include "igemm_shared.h"
 #include "correlation_geom.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -209,6 +209,126 @@ __global__ __launch_bounds__(256) void corr_bwd_mfma_kernel(const CorrMfmaParams
   }
 }
 
+// eight fp32 values (consecutive k of one MFMA operand row) -> their three bf16 planes (x = hi + mid + lo exactly, igemm_shared.h)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned hh = igemm::cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hh << 16), rb = b - __uint_as_float(hh & 0xffff0000u);
+    const unsigned mm = igemm::cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
+    hi[i] = hh; mid[i] = mm; lo[i] = igemm::cvt_pk_bf16(sa, sb);
+  }
+}
+
+// The backward banded product on the bf16 matrix cores: the same decomposition, loads and masks as corr_bwd_mfma_kernel,
+// but a lane holds 8 CONSECUTIVE contracted sites (the K layout of v_mfma_f32_32x32x16_bf16) and every operand value is
+// split into its three bf16 planes in registers (v_cvt_pk_bf16_f32); six product terms per K16 slab, fp32 accumulation —
+// the arithmetic class of the conv kernels (§4.1b of DESIGN.md).  32 fp32 MFMAs of 64 cycles per iteration become 24 bf16
+// MFMAs of 32 cycles; the ~220 split instructions run on the vector ALU beside them.
+template <int CT>
+__global__ __launch_bounds__(256) void corr_bwd_b3_kernel(const CorrMfmaParams p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int ncg = p.C / (32 * CT);
+  long job = (long)blockIdx.x * 4 + wid;
+  const int cg = (int)(job % ncg); job /= ncg;
+  const int s = (int)(job % p.B); job /= p.B;
+  const int ia = (int)(job % p.nA); job /= p.nA;
+  const int q = (int)(job % p.s2); job /= p.s2;
+  const int y = (int)job;
+  if (y >= p.H) return;
+  const int i0 = ia * 32, c0 = cg * 32 * CT;
+  const int role_lo = p.fuse ? 0 : (int)blockIdx.y, role_hi = p.fuse ? 1 : (int)blockIdx.y;
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r_ = 0; r_ < 16; r_++) acc[c][r_] = 0.f;
+
+  // operands of one iteration: av[slab][e], bvv[slab][e][c] for contracted site k = k0 + 16*slab + 8*h + e
+  auto load_operands = [&](int role, int pi, int t, float (&av)[2][8], float (&bvv)[2][8][CT]) -> bool {
+    const int nd = role == 0 ? s : ((s - p.shift) % p.B + p.B) % p.B;  // sample whose dOut is read
+    const int ns = role == 0 ? (s + p.shift) % p.B : nd;              // sample whose features are the B operand
+    const float* srcbase = role == 0 ? p.in1 : p.in0;
+    const int dyp = p.s2 * (pi - p.r);
+    const int ysrc = role == 0 ? y + dyp : y - dyp;
+    const int oy = (role == 0 ? y : y - dyp) - p.off;
+    if ((unsigned)ysrc >= (unsigned)p.H || (unsigned)oy >= (unsigned)p.oh) return false;
+    const int k0 = i0 + 32 * t;
+    const int xk_lo = q + p.off + p.s2 * k0, xk_hi = q + p.off + p.s2 * (k0 + 31);
+    if (xk_hi < 0 || xk_lo >= p.W) return false;
+    const float* drow = p.dout + ((size_t)nd * p.oh + oy) * p.ow * p.ld_dout + pi * p.gw + p.r;
+    const float* srow = srcbase + ((size_t)ns * p.H + ysrc) * p.W * p.ld_in + c0 + l31;
+    const int own = i0 + l31;
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = k0 + 16 * sl + 8 * h + e;
+        const int site = role == 0 ? own : k;
+        const int o = role == 0 ? k - own : own - k;
+        const int ox = q + p.s2 * site;
+        const bool ok = o >= -p.r && o <= p.r && (unsigned)ox < (unsigned)p.ow;
+        const float v = drow[(size_t)(ok ? ox : 0) * p.ld_dout + (ok ? o : 0)];
+        av[sl][e] = ok ? v : 0.f;
+      }
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int xs = q + p.off + p.s2 * (k0 + 16 * sl + 8 * h + e);
+        const bool ok = (unsigned)xs < (unsigned)p.W;
+        const float* sp = srow + (size_t)(ok ? xs : 0) * p.ld_in;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          const float tv = sp[32 * c];
+          bvv[sl][e][c] = ok ? tv : 0.f;
+        }
+      }
+    return true;
+  };
+
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_planes.hip mfma_terms)
+  for (int role = role_lo; role <= role_hi; role++)
+    for (int pi = 0; pi < p.gw; pi++)
+      for (int t = -p.T; t <= p.T; t++) {
+        float av[2][8], bvv[2][8][CT];
+        if (!load_operands(role, pi, t, av, bvv)) continue;
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+          u32x4 ap[3], bp[CT][3];
+          split8(av[sl], ap[0], ap[1], ap[2]);
+#pragma unroll
+          for (int c = 0; c < CT; c++) {
+            float col[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) col[e] = bvv[sl][e][c];
+            split8(col, bp[c][0], bp[c][1], bp[c][2]);
+          }
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+            for (int c = 0; c < CT; c++)
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[ta[tt]]), __builtin_bit_cast(bf16x8, bp[c][tb[tt]]),
+                                                               acc[c], 0, 0, 0);
+        }
+      }
+  float* gout = (p.fuse || blockIdx.y == 0) ? p.g0 : p.g1;
+  const float cf = (float)p.C;
+#pragma unroll
+  for (int r_ = 0; r_ < 16; r_++) {
+    const int i = i0 + (r_ & 3) + 8 * (r_ >> 2) + 4 * h;
+    const int x = q + p.off + p.s2 * i;
+    if ((unsigned)x >= (unsigned)p.W) continue;
+    float* d = gout + (((size_t)s * p.H + y) * p.W + x) * p.ld_g + c0 + l31;
+#pragma unroll
+    for (int c = 0; c < CT; c++) d[32 * c] = acc[c][r_] / cf;
+  }
+}
+
 CorrMfmaParams base_params(int B, int C, int H, int W, const CorrGeom& g) {
   CorrMfmaParams p{};
   p.B = B; p.C = C; p.H = H; p.W = W;
@@ -256,6 +376,14 @@ int corr_mfma_bwd(const float* dout, int ld_dout, const float* in0, const float*
   const int CT = C % 64 == 0 ? 2 : 1;
   const long jobs = (long)(C / (32 * CT)) * B * p.nA * g.s2 * H;
   dim3 grid((unsigned)((jobs + 3) / 4), fuse ? 1 : 2);
+  // default: fp32-equivalent products on the bf16 matrix cores (UNFLOW_CORR_MATH=fp32 / UNFLOW_CONV_MATH=fp32: v_mfma_f32_32x32x2_f32)
+  static const bool b3 = !((getenv("UNFLOW_CORR_MATH") && !strcmp(getenv("UNFLOW_CORR_MATH"), "fp32")) ||
+                           (getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32")));
+  if (b3) {
+    if (CT == 2) corr_bwd_b3_kernel<2><<<grid, 256, 0, st>>>(p);
+    else corr_bwd_b3_kernel<1><<<grid, 256, 0, st>>>(p);
+    return launch_status();
+  }
   if (CT == 2) corr_bwd_mfma_kernel<2><<<grid, 256, 0, st>>>(p);
   else corr_bwd_mfma_kernel<1><<<grid, 256, 0, st>>>(p);
   return launch_status();
