@@ -25,6 +25,29 @@ __device__ __forceinline__ BwTaps bw_sample(int px, int py, float u, float v) {
   return t;
 }
 
+// Streamed-once operands (the flow field in, the warped image / flow gradient out) bypass the cache hierarchy's retention
+// (nt): the gathers of the warps are the only accesses with reuse, and they keep the L2 for themselves.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float2 ld_nt2(const float* p) {
+  const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_nt2(float* p, float a, float b) {
+  f32x2 v; v.x = a; v.y = b;
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(p));
+}
+template <int CT>
+__device__ __forceinline__ void st_nt_px(float* p, const float (&s)[CT ? CT : 1]) {
+  if constexpr (CT == 3) {
+    f32x3 v; v.x = s[0]; v.y = s[1]; v.z = s[2];
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x3*>(p));
+  } else {
+#pragma unroll
+    for (int c = 0; c < CT; c++) __builtin_nontemporal_store(s[c], p + c);
+  }
+}
+
 template <int CT>
 __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
                                          float* __restrict__ out, int B, int H, int W, int C) {
@@ -33,7 +56,7 @@ __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const fl
     const Pix pp = decode_pix(i, W, H);
     const int px = pp.x, py = pp.y;
     const long b = pp.n;
-    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const float2 f = ld_nt2(flow + 2 * (size_t)i);
     const BwTaps t = bw_sample(px, py, f.x, f.y);
     const float* base = img + b * H * W * C;
     const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 >= -1 && t.x0 < W - 1;
@@ -49,15 +72,29 @@ __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const fl
     const float* p_br = base + (size_t)(yc * W + xb) * CC;
     const bool m_tl = xl && yt, m_tr = xr && yt, m_bl = xl && yb, m_br = xr && yb;
     const float w_tl = t.wl * t.wt, w_tr = t.wr * t.wt, w_bl = t.wl * t.wb, w_br = t.wr * t.wb;
+    if constexpr (CT != 0) {
+      float r[CT ? CT : 1];
 #pragma unroll
-    for (int c = 0; c < CC; c++) {
-      const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
-      float s = 0.f;
-      s += m_tl ? w_tl * v_tl : 0.f;
-      s += m_tr ? w_tr * v_tr : 0.f;
-      s += m_bl ? w_bl * v_bl : 0.f;
-      s += m_br ? w_br * v_br : 0.f;
-      out[(size_t)i * CC + c] = s;
+      for (int c = 0; c < CT; c++) {
+        const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
+        float s = 0.f;
+        s += m_tl ? w_tl * v_tl : 0.f;
+        s += m_tr ? w_tr * v_tr : 0.f;
+        s += m_bl ? w_bl * v_bl : 0.f;
+        s += m_br ? w_br * v_br : 0.f;
+        r[c] = s;
+      }
+      st_nt_px<CT>(out + (size_t)i * CT, r);
+    } else {
+      for (int c = 0; c < CC; c++) {
+        const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
+        float s = 0.f;
+        s += m_tl ? w_tl * v_tl : 0.f;
+        s += m_tr ? w_tr * v_tr : 0.f;
+        s += m_bl ? w_bl * v_bl : 0.f;
+        s += m_br ? w_br * v_br : 0.f;
+        out[(size_t)i * CC + c] = s;
+      }
     }
   }
 }
@@ -71,7 +108,7 @@ __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const f
     const Pix pp = decode_pix(i, W, H);
     const int px = pp.x, py = pp.y;
     const long b = pp.n;
-    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const float2 f = ld_nt2(flow + 2 * (size_t)i);
     const BwTaps t = bw_sample(px, py, f.x, f.y);
     const float* base = img + b * H * W * C;
     const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 >= -1 && t.x0 < W - 1;
@@ -87,7 +124,7 @@ __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const f
     float du = 0.f, dv = 0.f;
 #pragma unroll 4
     for (int c = 0; c < CC; c++) {
-      const float din = dout[(size_t)i * CC + c];
+      const float din = __builtin_nontemporal_load(dout + (size_t)i * CC + c);
       const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
       const float q_tl = m_tl ? v_tl * din : 0.f, q_tr = m_tr ? v_tr * din : 0.f;
       const float q_bl = m_bl ? v_bl * din : 0.f, q_br = m_br ? v_br * din : 0.f;
@@ -96,7 +133,7 @@ __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const f
       du -= t.wb * q_bl; dv += t.wl * q_bl;
       du += t.wb * q_br; dv += t.wr * q_br;
     }
-    reinterpret_cast<float2*>(dflow)[i] = make_float2(du, dv);
+    st_nt2(dflow + 2 * (size_t)i, du, dv);
   }
 }
 
@@ -183,7 +220,7 @@ __global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, c
     const Pix pp = decode_pix(i, W, H);
     const int px = pp.x, py = pp.y, b = pp.n;
     const int bs = (b + shift) % B;
-    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const float2 f = ld_nt2(flow + 2 * (size_t)i);
     const IwTaps t = iw_sample(px, py, f.x * fscale, f.y * fscale, H, W);
     const long sbase = (long)bs * H * W;
     if (idx4) {
@@ -194,10 +231,16 @@ __global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, c
     const float* pb = im + (sbase + t.ib) * ld_im;
     const float* pc = im + (sbase + t.ic) * ld_im;
     const float* pd = im + (sbase + t.id) * ld_im;
-    const int CC = CT ? CT : C;
+    if constexpr (CT != 0) {
+      float r[CT ? CT : 1];
+#pragma unroll
+      for (int c = 0; c < CT; c++) r[c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
+      st_nt_px<CT>(out + (size_t)i * CT, r);
+    } else {
 #pragma unroll 4
-    for (int c = 0; c < CC; c++)
-      out[(size_t)i * C + c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
+      for (int c = 0; c < C; c++)
+        out[(size_t)i * C + c] = ((t.wa * pa[c] + t.wb * pb[c]) + t.wc * pc[c]) + t.wd * pd[c];
+    }
   }
 }
 
