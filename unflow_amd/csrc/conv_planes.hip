@@ -1101,9 +1101,9 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
       const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
       const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
       const unsigned d = st + (unsigned)(4 * wid * BM * 2);
-      dma3(voff, src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
+      if (!(p.dbg & 512)) dma3(voff, src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);   // 512 / 256: ablations
     }
-    if (wid < B_NI) {
+    if (wid < B_NI && !(p.dbg & 256)) {
       const int sidx = kt * KS + b_k;
       const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
       const unsigned d = st + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
