@@ -12,6 +12,7 @@ im1, im2 = im1.to(dev), im2.to(dev)
 side = torch.cuda.Stream(dev)
 def run(group, graph):
     eng.wgrad_group, eng.wgrad_stream = group, (side if group > 0 else None)
+    eng.wgrad_inline_tiny = os.environ.get('UNFLOW_WGRAD_INLINE_TINY', '0') != '0'
     if graph:
         graph_step(eng, im1, im2)
     else:
@@ -19,8 +20,8 @@ def run(group, graph):
         eng.forward_net(); eng.forward_loss(with_grad=True); eng.backward_net(); torch.cuda.synchronize()
     return eng.G.clone()
 ref = run(0, False)
-for rep in range(100):
-    for group in (3,):
+for rep in range(40):
+    for group in (3, 4, 6):
         got = run(group, True)
         for l in eng.layers:
             lo = (l.dw.data_ptr() - eng.G.data_ptr()) // 4

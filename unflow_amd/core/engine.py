@@ -376,13 +376,14 @@ class _Stage:
         # Filter gradients leave the critical path: a layer's dW depends only on its (final) dz and its input, and nothing
         # reads it before the optimizer, so groups of them run on a second stream beside the data-gradient chain (own
         # split-K scratch, ws_slot 3); the part joins before it returns.  The small deep layers, whose kernels cannot fill
-        # the chip alone, are where this pays (+2.9 % on the benchmarked step).  The Cout = 2 layers (flow heads, 2 -> 2
-        # flow upsamplers) stay on the main stream (wgrad_inline_tiny; they are too small to matter).  History: the 2 -> 2
-        # filter gradient of a replayed two-branch graph used to return one wrong sum in ~10 % of the replays whenever a
-        # kernel of the other branch shared its SIMD; root cause: a compiler-formed v_pk_mul_f32 whose destination pair
-        # overlaps an op_sel-selected source (unflow_amd/build.py: the library is now built with -fno-slp-vectorize;
-        # tools/debug/wgstream_flake.py reproduces it with the old flags).  tests/test_engine_gpu.py asserts bit-identity of
-        # the two schedules over repeated replays.
+        # the chip alone, are where this pays (+2.9 % on the benchmarked step; +0.5 % more with the Cout = 2 layers — flow
+        # heads, 2 -> 2 flow upsamplers — in the groups too, wgrad_inline_tiny = False).  History: those layers used to stay
+        # on the main stream because the 2 -> 2 filter gradient of a replayed two-branch graph returned one wrong sum in
+        # ~10 % of the replays whenever a kernel of the other branch shared its SIMD; root cause: a compiler-formed
+        # v_pk_mul_f32 whose destination pair overlaps an op_sel-selected source (unflow_amd/build.py: the library is now
+        # built with -fno-slp-vectorize; tools/debug/wgstream_flake.py reproduces it with the old flags: 0 wrong sums in 120
+        # replays now, with every filter gradient on the second stream).  tests/test_engine_gpu.py asserts bit-identity of the
+        # schedules over repeated replays.
         side = e.wgrad_stream
         main = torch.cuda.current_stream(e.dev)
         pending = []
@@ -475,7 +476,9 @@ class FlowNetEngine:
         self.planes_external = False      # True: the captured forward does not re-split the weights (StepRunner does, per bucket)
         self.wgrad_sync_each = False      # debug: join after every group (no concurrency, still two graph branches)
         self.wgrad_unique_ws = False      # debug: one scratch buffer per deferred filter gradient
-        self.wgrad_inline_tiny = True     # the Cout = 2 layers' filter gradients stay on the main stream (see backward())
+        # True: the Cout = 2 layers' filter gradients (flow heads, 2 -> 2 upsamplers: small latency-bound kernels) stay on the main
+        # stream; False (default): they join the groups on the second stream like every other filter gradient
+        self.wgrad_inline_tiny = os.environ.get('UNFLOW_WGRAD_INLINE_TINY', '0') != '0'
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
         if layout_only:
             self.n_planes = 0
