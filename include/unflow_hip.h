@@ -374,6 +374,11 @@ int unflow_weight_planes_batched(int n, const float* const* w, const int* taps, 
 
 size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes);
 
+/* Test hook (host only, no GPU): the (M tile, N tile, parity class, K split) each workgroup of a gather / halo launch decodes from
+ * its linear id — XCD-contiguous remap + work order 0 / 1 / 2 of csrc/conv_planes.hip — 4 ints per workgroup, M tile = -1 for
+ * the padding workgroups of order 2.  Returns the grid size (out == NULL: query only). */
+int unflow_debug_work_order(int mt, int nt, int ncls, int nsplit, int order, int xcd, int* out, int out_blocks);
+
 /* w_pl: the `transposed` planes of w (ld = round_up_8(Cin)). */
 int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* w, const unflow_planes* w_pl,
                          const float* bias, float* y, int ldy, const unflow_planes* y_pl, int B, int H, int W, int Cin,

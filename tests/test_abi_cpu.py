@@ -86,3 +86,32 @@ def test_pyr_level_struct_layout_matches_the_library():
     from unflow_amd import _lib
     assert ctypes.sizeof(_lib.PyrLevel) == _lib.lib().unflow_sizeof_pyr_level()
     assert _lib.PyrLevel.H.offset == 7 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_work_order_of_the_plane_kernels_is_a_bijection(lib):
+    """Every (M tile, N tile, parity class, K split) of a gather / halo launch is decoded by exactly one workgroup, for the
+    three work orders, with and without the XCD-contiguous remap, including M-tile counts that are not multiples of 8
+    (order 2 pads the grid; the padding workgroups decode M tile -1 and exit); with the remap on, the workgroups of one XCD
+    (linear id mod 8) own a contiguous run of the order."""
+    import itertools
+    shapes = [(768, 1, 1, 1), (192, 2, 1, 2), (48, 4, 1, 8), (3, 8, 1, 16), (30, 3, 4, 2), (17, 1, 4, 5), (7, 5, 1, 3), (1, 1, 1, 1)]
+    for (mt, nt, ncls, ns), order, xcd in itertools.product(shapes, (0, 1, 2), (0, 1)):
+        grid = lib.unflow_debug_work_order(mt, nt, ncls, ns, order, xcd, None, 0)
+        assert grid >= mt * nt * ncls * ns
+        buf = (ctypes.c_int * (4 * grid))()
+        assert lib.unflow_debug_work_order(mt, nt, ncls, ns, order, xcd, buf, grid) == grid
+        seen = set()
+        for b in range(grid):
+            m, n, c, s = buf[4 * b:4 * b + 4]
+            if m < 0:
+                assert order == 2
+                continue
+            assert 0 <= m < mt and 0 <= n < nt and 0 <= c < ncls and 0 <= s < ns
+            assert (m, n, c, s) not in seen
+            seen.add((m, n, c, s))
+        assert len(seen) == mt * nt * ncls * ns, (mt, nt, ncls, ns, order, xcd)
+        if xcd and order == 2 and mt >= 16 and mt % 8 == 0:
+            # one M group per XCD: the M tiles of XCD x are the x-th run of mt / 8 tiles
+            for b in range(grid):
+                m = buf[4 * b]
+                assert m // (mt // 8) == b % 8

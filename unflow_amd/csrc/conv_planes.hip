@@ -69,7 +69,7 @@ constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
 // Workgroups are handed to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), so neighbouring tiles — which share
 // source rows (the vertical taps) — sit on different L2s.  This bijective remap of blockIdx.x gives every XCD a contiguous
 // run of tiles instead: its L2 then fetches each source row once, not once per XCD that holds one of the row's consumers.
-__device__ __forceinline__ int xcd_remap(int b, int n, int on) {
+__host__ __device__ __forceinline__ int xcd_remap(int b, int n, int on) {
   if (!on || n < 16) return b;
   const int xcd = b & 7, idx = b >> 3;
   const int q = n >> 3, r = n & 7;
@@ -86,7 +86,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n, int on) {
 //   2  the M tiles are cut into 8 groups (one per XCD: neighbouring tiles share the vertical taps' rows); inside a group the
 //      M tile runs fastest, then N tile, class, split: every weight slice is streamed once per XCD by all its M tiles in
 //      step.  The grid is padded to whole groups; surplus workgroups return at once (m = -1).
-__device__ __forceinline__ void work_decode(int v, int mt, int nt, int ncls, int nsplit, int order, int mgroup, int& m, int& n,
+__host__ __device__ __forceinline__ void work_decode(int v, int mt, int nt, int ncls, int nsplit, int order, int mgroup, int& m, int& n,
                                             int& c, int& s) {
   if (order == 0) {
     n = v % nt; v /= nt;
@@ -1635,6 +1635,24 @@ int unflow_conv2d_transpose_bwd_data_po(const float* dz, int lddz, const float* 
                                         unflow_stream_t stream);
 
 // ===================================================================== C ABI
+// Host-side replay of the work order of the gather / halo kernels (xcd_remap + work_decode, the same functions the kernels
+// run): out[4 * b .. 4 * b + 3] = (M tile, N tile, class, split) of workgroup b, M tile = -1 for the padding blocks of order 2.
+// Returns the grid size; out may be NULL to query it.  For tests: every (M tile, N tile, class, split) exactly once.
+UNFLOW_API int unflow_debug_work_order(int mt, int nt, int ncls, int nsplit, int order, int xcd, int* out, int out_blocks) {
+  if (mt <= 0 || nt <= 0 || ncls <= 0 || nsplit <= 0 || order < 0 || order > 2) return UNFLOW_ERR_SHAPE;
+  PlGatherParams q{};
+  q.mt = mt; q.nt = nt; q.ncls = ncls; q.nsplit = nsplit; q.order = order;
+  const int grid = pl_grid(q);
+  if (!out) return grid;
+  if (out_blocks < grid) return UNFLOW_ERR_WORKSPACE;
+  for (int b = 0; b < grid; b++) {
+    int m, n, c, sp;
+    work_decode(xcd_remap(b, grid, xcd), mt, nt, ncls, nsplit, order, q.mgroup, m, n, c, sp);
+    out[4 * b] = m; out[4 * b + 1] = n; out[4 * b + 2] = c; out[4 * b + 3] = sp;
+  }
+  return grid;
+}
+
 UNFLOW_API int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, int C_fill, const unflow_planes* out,
                                       unflow_stream_t stream) {
   if (!x || !out || !out->base) return UNFLOW_ERR_NULL;
