@@ -471,7 +471,7 @@ class FlowNetEngine:
         self.dev = torch.device('cuda:0') if device is None else torch.device(device)
         self.math = conv_math_mode()
         # filter gradients on a second stream, in groups of wgrad_group layers (UNFLOW_WGRAD_GROUP=0: inline)
-        self.wgrad_group = int(os.environ.get('UNFLOW_WGRAD_GROUP', '4'))
+        self.wgrad_group = int(os.environ.get('UNFLOW_WGRAD_GROUP', '6'))
         self.wgrad_stream = None
         self.planes_external = False      # True: the captured forward does not re-split the weights (StepRunner does, per bucket)
         self.wgrad_sync_each = False      # debug: join after every group (no concurrency, still two graph branches)
