@@ -229,3 +229,19 @@ def test_empty_batch_is_a_no_op(dev):
     assert lib.unflow_downsample_fwd(ptr(one), ptr(one), 0, 8, 12, 3, 2, stream()) == 0
     assert lib.unflow_adam_step(ptr(one), ptr(one), ptr(one), ptr(one), _lib.cl(0), _lib.cl(0), _lib.cf(1.0),
                                 _lib.cf(0.0), _lib.cf(1e-3), _lib.cf(0.9), _lib.cf(0.999), _lib.cf(1e-8), stream()) == 0
+
+
+def test_correlation_backward_both_math_modes(dev):
+    """The correlation backward defaults to fp32-equivalent products on the bf16 matrix cores (corr_bwd_b3_kernel: 3-way bf16
+    split in registers, six terms, fp32 accumulation); UNFLOW_CORR_MATH=fp32 keeps v_mfma_f32_32x32x2_f32.  The knob is read
+    once per process, so the other mode runs the correlation tests of this file in a sub-process, at the same tolerances."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("UNFLOW_CORR_MATH_SUBTEST"):
+        pytest.skip("already inside the sub-process")
+    other = "bf16x3" if os.environ.get("UNFLOW_CORR_MATH", "bf16x3") == "fp32" else "fp32"
+    env = dict(os.environ, UNFLOW_CORR_MATH=other, UNFLOW_CORR_MATH_SUBTEST="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", "correlation"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
