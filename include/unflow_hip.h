@@ -359,6 +359,15 @@ int unflow_correlation_nhwc_fwd_pl(const float* in0, const float* in1, int ld_in
                                    int H, int W, int kernel_size, int max_displacement, int pad, int stride_1,
                                    int stride_2, unflow_stream_t stream);
 
+/* unflow_correlation_nhwc_bwd with the features' operand planes (n_planes == 3, kernel_size 1, stride_1 1, C % 64 == 0): the
+ * feature operand of the banded products comes from the planes (LDS-DMA + transposing reads), the band operand is split in
+ * registers; six terms on the bf16 matrix cores, fp32 accumulation.  Falls back to the fp32 entry point otherwise. */
+int unflow_correlation_nhwc_bwd_pl(const float* dout, int ld_dout, const float* in0, const float* in1, int ld_in,
+                                   const unflow_planes* in0_pl, const unflow_planes* in1_pl, int pair_shift, float* grad0,
+                                   float* grad1, int ld_grad, int accumulate_g1_into_g0, int B, int C, int H, int W,
+                                   int kernel_size, int max_displacement, int pad, int stride_1, int stride_2,
+                                   unflow_stream_t stream);
+
 /* fp32 [npix][ldx] (C channels) -> planes; plane channels C .. C_fill-1 are zero-filled (C <= C_fill <= round_up_8(C),
  * C_fill a multiple of 4: a slice that ends the buffer row before the next multiple of 8 passes the row's end). */
 int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, int C_fill, const unflow_planes* out,

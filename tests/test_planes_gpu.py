@@ -373,3 +373,33 @@ def test_fused_splitk_bit_identical_to_reduce_kernel(case, dev, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     y0, dx0, pl0 = torch.load(f)
     assert torch.equal(y0, ref[0]) and torch.equal(dx0, ref[1]) and torch.equal(pl0, ref[2])
+
+
+@pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1)])
+def test_correlation_planes_bwd_vs_fp32_kernel(case, dev):
+    """unflow_correlation_nhwc_bwd_pl (feature operand from the bf16 planes through LDS-DMA + transposing reads, band operand
+    split in registers, six terms on the bf16 matrix cores) vs the fp32-MFMA backward of the same library (itself checked
+    against the scalar C oracle in tests/test_ops_gpu.py), fused g0 + g1 with the training step's pairing."""
+    import os
+    import subprocess
+    import sys
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, ptr, stream
+    B, C, H, W, md, s2 = case
+    N = 2 * B
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = torch.randn(N, H, W, C, generator=g)
+    F = make_pt(x, dev, 3)
+    import ctypes
+    o3 = (ctypes.c_int * 3)()
+    assert _lib.lib().unflow_correlation_out_shape(H, W, 1, md, md, 1, s2, o3) == 0
+    oc, oh, ow = tuple(o3)
+    dout = torch.randn(N, oh, ow, oc, generator=g).to(dev)
+    g_pl = torch.zeros(N, H, W, C, device=dev)
+    g_ref = torch.zeros(N, H, W, C, device=dev)
+    check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(dout), oc, ptr(F.t), ptr(F.t), F.t.stride(2), _lib.planes_of(F.pl),
+                                                    _lib.planes_of(F.pl), B, ptr(g_pl), ptr(None), C, 1, N, C, H, W, 1, md, md, 1, s2,
+                                                    stream()), "correlation_bwd_pl")
+    check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(dout), oc, ptr(F.t), ptr(F.t), F.t.stride(2), None, None, B, ptr(g_ref),
+                                                    ptr(None), C, 1, N, C, H, W, 1, md, md, 1, s2, stream()), "correlation_bwd")
+    assert rel_err(g_pl, g_ref) < 2e-5

@@ -408,9 +408,11 @@ class _Stage:
                 C = op.src[2] - op.src[1]
                 h8, w8 = e.H // 8, e.W // 8
                 assert first
-                check(_lib.lib().unflow_correlation_nhwc_bwd(ptr(gout.t), gout.t.stride(2), ptr(c3.t), ptr(c3.t),
-                                                             c3.t.stride(2), B, ptr(g3.t), ptr(None), g3.t.stride(2), 1, N,
-                                                             C, h8, w8, 1, 20, 20, 1, 2, e.stream()), "correlation_grad")
+                c3pl = _lib.planes_of(c3.pl if e.n_planes == 3 else None)     # bf16 planes: feature operand by LDS-DMA
+                check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(gout.t), gout.t.stride(2), ptr(c3.t), ptr(c3.t),
+                                                                c3.t.stride(2), c3pl, c3pl, B, ptr(g3.t), ptr(None),
+                                                                g3.t.stride(2), 1, N, C, h8, w8, 1, 20, 20, 1, 2, e.stream()),
+                      "correlation_grad")
                 continue
             l = op.l
             x, dz = self.pt(op.src), self.pt(op.dst, True)

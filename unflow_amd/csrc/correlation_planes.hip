@@ -17,6 +17,7 @@ using namespace igemm;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct CorrPlParams {
   const unsigned short* f0;   // planes of in0, channel 0 of the feature slice; [pixel][ld] per plane
@@ -145,6 +146,204 @@ __global__ __launch_bounds__(256) void corr_fwd_pl_kernel(const CorrPlParams p) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward from planes
+// out[site][c] += Band(dOut)[site][k] * F[k][c] (correlation_mfma.hip: corr_bwd_b3_kernel) with the FEATURE operand taken from
+// its bf16 planes instead of being split in registers: per iteration a wave's 32 contracted sites x 64 channels x 3 planes
+// (12 KB) go HBM/L2 -> a wave-private LDS tile by LDS-DMA (no staging registers, no conversion work), and the MFMA B
+// fragments — 8 consecutive SITES of one channel — come out through ds_read_b64_tr_b16, exactly like the filter-gradient
+// kernels of conv_planes.hip.  The band operand (scattered dOut values) is still gathered as fp32 and split in registers.
+// Wave-private tiles: no barriers; the tile of the next iteration is requested as soon as this iteration's fragments are in
+// registers, and lands under its MFMAs.
+struct CorrBwdPlParams {
+  const unsigned short* f0;
+  const unsigned short* f1;
+  long ps;
+  int ld;
+  const float* dout;
+  float* g0;
+  float* g1;
+  int ld_dout, ld_g, shift, fuse;
+  int B, C, H, W;
+  int oh, ow, r, gw, s2;
+  int off, nA, T;
+};
+
+__device__ __forceinline__ int corr_tr_swz64(int k, int granule) {      // conv_planes.hip tr_swz<64>
+  const int pair = granule >> 1;
+  const int sw = ((k >> 1) & 1) << 1;
+  return k * 64 + (((pair ^ sw) << 1) | (granule & 1)) * 8;
+}
+
+__device__ __forceinline__ void corr_split8(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned hh = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hh << 16), rb = b - __uint_as_float(hh & 0xffff0000u);
+    const unsigned mm = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
+    hi[i] = hh; mid[i] = mm; lo[i] = cvt_pk_bf16(sa, sb);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int TILE = 3 * 32 * 64;                 // elements per wave: 3 planes x 32 sites x 64 channels
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l31 = lane & 31, h = lane >> 5;
+  const int ncg = p.C >> 6;
+  long job = (long)blockIdx.x * 4 + wid;
+  const int cg = (int)(job % ncg); job /= ncg;
+  const int s = (int)(job % p.B); job /= p.B;
+  const int ia = (int)(job % p.nA); job /= p.nA;
+  const int q = (int)(job % p.s2); job /= p.s2;
+  const int y = (int)job;
+  if (y >= p.H) return;
+  const int i0 = ia * 32, c0 = cg * 64;
+  const int role_lo = p.fuse ? 0 : (int)blockIdx.y, role_hi = p.fuse ? 1 : (int)blockIdx.y;
+  unsigned short* tile = lds + wid * TILE;
+  const unsigned tile_addr = lds_addr(tile);
+
+  const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
+  u32x4 f0_rs[3], f1_rs[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    f0_rs[pl] = raw_rsrc(p.f0 + pl * p.ps, recs);
+    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
+  }
+  const int ld2 = p.ld * 2;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
+
+  // fragment addresses (transposing reads): lane -> 4 consecutive channels (i16 & 3) of site row (i16 >> 2) of its half
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int krow = 8 * (grp >> 1) + (i16 >> 2);
+  int b_rd[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const int ch = 32 * c + 16 * (grp & 1) + 4 * (i16 & 3);
+    b_rd[c] = corr_tr_swz64(krow, ch >> 3) + (ch & 7);
+  }
+  // DMA lane mapping: instruction j covers sites 8j .. 8j+7, lane -> (site 8j + lane/8, slot lane%8 -> granule)
+  const int d_site = lane >> 3, d_slot = lane & 7;
+
+  // iteration state
+  int it_role = role_lo, it_pi = -1, it_t = p.T;      // advanced before use
+  int nd = 0, ns = 0, ysrc = 0, oy = 0, k0 = 0;
+  auto next_item = [&]() -> bool {
+    for (;;) {
+      if (++it_t > p.T) { it_t = -p.T; if (++it_pi >= p.gw) { it_pi = 0; if (++it_role > role_hi) return false; } }
+      const int role = it_role;
+      nd = role == 0 ? s : ((s - p.shift) % p.B + p.B) % p.B;
+      ns = role == 0 ? (s + p.shift) % p.B : nd;
+      const int dyp = p.s2 * (it_pi - p.r);
+      ysrc = role == 0 ? y + dyp : y - dyp;
+      oy = (role == 0 ? y : y - dyp) - p.off;
+      if ((unsigned)ysrc >= (unsigned)p.H || (unsigned)oy >= (unsigned)p.oh) continue;
+      k0 = i0 + 32 * it_t;
+      const int xk_lo = q + p.off + p.s2 * k0, xk_hi = q + p.off + p.s2 * (k0 + 31);
+      if (xk_hi < 0 || xk_lo >= p.W) continue;
+      return true;
+    }
+  };
+  // the feature tile of the current item -> LDS (role 0 multiplies in1, role 1 in0)
+  auto issue_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int site = 8 * j + d_site;
+      const int g = ((((d_slot >> 1) ^ (((site >> 1) & 1) << 1)) << 1) | (d_slot & 1));
+      const int xs = q + p.off + p.s2 * (k0 + site);
+      const bool ok = (unsigned)xs < (unsigned)p.W;
+      const int voff = ok ? ((ns * p.H + ysrc) * p.W + xs) * ld2 + (c0 + g * 8) * 2 : OOB_MARK;
+      const unsigned d = tile_addr + (unsigned)(j * 1024);
+      if (it_role == 0) dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+      else dma3(voff, f0_rs[0], f0_rs[1], f0_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+    }
+  };
+  // the band operand of the current item: av[slab][e] for contracted site k0 + 16 slab + 8 h + e (masked gathers)
+  auto load_band = [&](float (&av)[2][8]) {
+    const int role = it_role;
+    const float* drow = p.dout + ((size_t)nd * p.oh + oy) * p.ow * p.ld_dout + it_pi * p.gw + p.r;
+    const int own = i0 + l31;
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = k0 + 16 * sl + 8 * h + e;
+        const int site = role == 0 ? own : k;
+        const int o = role == 0 ? k - own : own - k;
+        const int ox = q + p.s2 * site;
+        const bool ok = o >= -p.r && o <= p.r && (unsigned)ox < (unsigned)p.ow;
+        const float v = drow[(size_t)(ok ? ox : 0) * p.ld_dout + (ok ? o : 0)];
+        av[sl][e] = ok ? v : 0.f;
+      }
+  };
+
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  float av0[2][8], av1[2][8];
+  bool have = next_item();
+  if (have) {
+    issue_tile();
+    load_band(av0);
+  }
+  int par = 0;
+  while (have) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this item's tile (and band values) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    s16x8 bv[2][2][3];
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const unsigned short* b0 = tile + pl * (32 * 64) + b_rd[c] + sl * 16 * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * 64));
+          bv[sl][c][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: the tile may be overwritten
+    __builtin_amdgcn_sched_barrier(0);
+    // request the next item (tile by DMA, band values by plain loads into the other register set)
+    const bool more = next_item();
+    if (more) {
+      issue_tile();
+      if (par == 0) load_band(av1); else load_band(av0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+      u32x4 ap[3];
+      if (par == 0) corr_split8(av0[sl], ap[0], ap[1], ap[2]); else corr_split8(av1[sl], ap[0], ap[1], ap[2]);
+#pragma unroll
+      for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[ta[tt]]),
+                                                           __builtin_bit_cast(bf16x8, bv[sl][c][tb[tt]]), acc[c], 0, 0, 0);
+    }
+    par ^= 1;
+    have = more;
+  }
+  float* gout = (p.fuse || blockIdx.y == 0) ? p.g0 : p.g1;
+  const float cf = (float)p.C;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int x = q + p.off + p.s2 * i;
+    if ((unsigned)x >= (unsigned)p.W) continue;
+    float* d = gout + (((size_t)s * p.H + y) * p.W + x) * p.ld_g + c0 + l31;
+#pragma unroll
+    for (int c = 0; c < 2; c++) d[32 * c] = acc[c][e] / cf;
+  }
+}
+
 }  // namespace
 
 int corr_pl_supported(const CorrGeom& g, int C, const unflow_planes* a, const unflow_planes* b) {
@@ -179,5 +378,29 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   }
   const int blocks = B * p.nA * g.s2 * g.oh;
   corr_fwd_pl_kernel<<<blocks, 256, smem, st>>>(p);
+  return launch_status();
+}
+
+int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const unflow_planes* in1, int shift, float* g0, float* g1,
+                int ld_g, int fuse, int B, int C, int H, int W, const CorrGeom& g, hipStream_t st) {
+  CorrBwdPlParams p{};
+  p.f0 = reinterpret_cast<const unsigned short*>(in0->base);
+  p.f1 = reinterpret_cast<const unsigned short*>(in1->base);
+  p.ps = in0->plane_stride; p.ld = in0->ld;
+  p.dout = dout; p.g0 = g0; p.g1 = g1; p.ld_dout = ld_dout; p.ld_g = ld_g; p.shift = shift; p.fuse = fuse;
+  p.B = B; p.C = C; p.H = H; p.W = W;
+  p.oh = g.oh; p.ow = g.ow; p.r = g.r; p.gw = g.gw; p.s2 = g.s2;
+  p.off = g.md - g.pad;
+  const int span = max(g.ow, W - p.off);
+  const int nq = (span + g.s2 - 1) / g.s2;
+  p.nA = (nq + 31) / 32;
+  p.T = (g.r + 31) / 32;
+  const int smem = 4 * 3 * 32 * 64 * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)attr;
+  const long jobs = (long)(C / 64) * B * p.nA * g.s2 * H;
+  dim3 grid((unsigned)((jobs + 3) / 4), fuse ? 1 : 2);
+  corr_bwd_pl_kernel<<<grid, 256, smem, st>>>(p);
   return launch_status();
 }

@@ -6,6 +6,8 @@
 //   generic kernels : any (kernel_size, max_displacement, pad, stride_1, stride_2)
 //   MFMA kernels    : kernel_size == 1, stride_1 == 1 (the FlowNetC configuration, flownet.py:221-222)
 //                     — see correlation_mfma.hip
+#include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "correlation_geom.h"
 
@@ -154,6 +156,8 @@ int corr_mfma_bwd(const float* dout, int ld_dout, const float* in0, const float*
 int corr_pl_supported(const CorrGeom& g, int C, const unflow_planes* a, const unflow_planes* b);
 int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, float* out, int ld_out, int B, int C, int H,
                 int W, const CorrGeom& g, hipStream_t st);
+int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const unflow_planes* in1, int shift, float* g0, float* g1,
+                int ld_g, int fuse, int B, int C, int H, int W, const CorrGeom& g, hipStream_t st);
 
 static int corr_status(int H, int W, int k, int md, int pad, int s1, int s2, CorrGeom* g) {
   if (k <= 0 || s1 <= 0 || s2 <= 0 || md < 0 || pad < 0) return UNFLOW_ERR_SHAPE;
@@ -225,6 +229,27 @@ UNFLOW_API int unflow_correlation_nhwc_bwd(const float* dout, int ld_dout, const
   corr_bwd_generic_kernel<<<stream_grid((long)B * H * W * C), 256, 0, as_stream(stream)>>>(
       dout, ld_dout, in0, in1, ld_in, pair_shift, grad0, grad1, ld_grad, accumulate_g1_into_g0, B, C, H, W, g);
   return launch_status();
+}
+
+UNFLOW_API int unflow_correlation_nhwc_bwd_pl(const float* dout, int ld_dout, const float* in0, const float* in1, int ld_in,
+                                              const unflow_planes* in0_pl, const unflow_planes* in1_pl, int pair_shift,
+                                              float* grad0, float* grad1, int ld_grad, int accumulate_g1_into_g0, int B, int C,
+                                              int H, int W, int kernel_size, int max_displacement, int pad, int stride_1,
+                                              int stride_2, unflow_stream_t stream) {
+  if (!dout || !grad0 || (!grad1 && !accumulate_g1_into_g0)) return UNFLOW_ERR_NULL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_grad < C) return UNFLOW_ERR_SHAPE;
+  CorrGeom g;
+  const int st = corr_status(H, W, kernel_size, max_displacement, pad, stride_1, stride_2, &g);
+  if (st != UNFLOW_OK) return st;
+  if (ld_dout < g.oc) return UNFLOW_ERR_SHAPE;
+  static const bool pl_on = !(getenv("UNFLOW_CORR_BWD_PLANES") && atoi(getenv("UNFLOW_CORR_BWD_PLANES")) == 0) &&
+                            !(getenv("UNFLOW_CORR_MATH") && !strcmp(getenv("UNFLOW_CORR_MATH"), "fp32")) &&
+                            !(getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32"));
+  if (pl_on && C % 64 == 0 && corr_pl_supported(g, C, in0_pl, in1_pl))
+    return corr_pl_bwd(dout, ld_dout, in0_pl, in1_pl, pair_shift, grad0, grad1, ld_grad, accumulate_g1_into_g0, B, C, H, W, g,
+                       as_stream(stream));
+  return unflow_correlation_nhwc_bwd(dout, ld_dout, in0, in1, ld_in, pair_shift, grad0, grad1, ld_grad, accumulate_g1_into_g0, B,
+                                     C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, stream);
 }
 
 UNFLOW_API size_t unflow_correlation_workspace_bytes(int B, int C, int H, int W, int kernel_size,
