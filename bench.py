@@ -222,9 +222,9 @@ def main():
 
 
 def measure_roofline(eng, args):
-    """Dominant kernel class = the conv / conv_transpose layers (fp32-MFMA implicit GEMM igemm_gather_kernel /
-    igemm_wgrad_kernel + their split-K reduces + the Cout=2 flow-head kernels): algorithmic FLOPs of those layers per
-    step / the GPU time of exactly those launches.  The launches of one step are recorded, captured alone into a
+    """Dominant kernel class = the conv / conv_transpose layers (implicit-GEMM kernels of csrc/conv_planes.hip — gather, halo,
+    LDS-DMA filter gradients — or of csrc/conv_igemm.hip with UNFLOW_CONV_MATH=fp32, + their split-K reduces + the Cout=2
+    flow-head kernels): algorithmic FLOPs of those layers per step / the GPU time of exactly those launches.  The launches of one step are recorded, captured alone into a
     hipGraph (so the measurement has the same back-to-back dispatch as the benchmarked step, no Python launch gaps)
     and its replay is timed live with HIP events on the replay stream."""
     import torch
@@ -285,7 +285,7 @@ def measure_roofline(eng, args):
     b3name, f32name = "fp32-equivalent 3xbf16 split, 6 terms on v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32"
     if f16:
         b3name = "fp16 operands on v_mfma_f32_32x32x16_f16, fp32 accumulate"
-    kname = {"bf16x3": "igemm_pl_gather_kernel / igemm_pl_wgrad_kernel (operand planes, csrc/conv_planes.hip)",
+    kname = {"bf16x3": "igemm_pl_gather_kernel / igemm_pl_halo_kernel / igemm_pl_wgrad_dma_kernel (operand planes, csrc/conv_planes.hip)",
              "f16": "igemm_pl_gather_kernel / igemm_pl_wgrad_kernel (fp16 planes, csrc/conv_planes.hip)"}.get(
                  eng.math, "igemm_gather_kernel / igemm_wgrad kernel (csrc/conv_igemm.hip)")
     return {"bound": "mfma", "kernel": "%s: gather (%s) + filter gradients (%s) incl. their split-K reduces and "
