@@ -91,28 +91,47 @@ def main():
     v.abs_()
     report("adam_step (39.2 M params, fused L2)", n * 4 * 7,
            timeit(lambda: check(lib.unflow_adam_step(ptr(p), ptr(gr), ptr(m), ptr(v), cl(n), cl(n), cf(1.0), cf(4e-4), cf(1e-4), cf(.9), cf(.999), cf(1e-8), st))))
-    # correlation, FlowNetC configuration, N=8 directed samples (compute-leaning: report both rooflines)
-    f = torch.randn(8, 48, 64, 256, generator=g).to(dev)
+    # correlation, FlowNetC configuration, N=8 directed samples (compute-leaning: report both rooflines).  The step's entry
+    # points: features with their bf16 operand planes (written by the producing convolution in the step; here by
+    # unflow_planes_from_f32 outside the timed region), six-term products on the bf16 matrix cores.
+    from unflow_amd.core import layers as L
+    from unflow_amd._lib import planes_of
+
+    def with_planes(t):
+        pt = L.PT.alloc(tuple(t.shape), dev, 3)
+        pt.t.copy_(t)
+        L.planes_from_f32(pt.t, pt.pl)
+        return pt
+    F = with_planes(torch.randn(8, 48, 64, 256, generator=g).to(dev))
+    f = F.t
     co = torch.empty(8, 48, 64, 441, device=dev)
-    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f), ptr(f), 256, 4, ptr(co), 441, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
-    report("correlation_nhwc_fwd 441ch N=8", 8 * 11.71e6, us, {"GFLOP_algorithmic": 5.55, "TFLOP/s": round(5.55e3 / us, 1)})
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd_pl(ptr(f), ptr(f), 256, planes_of(F.pl), planes_of(F.pl), 4, ptr(co), 441, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
+    report("correlation_nhwc_fwd_pl 441ch N=8", 8 * 11.71e6, us, {"GFLOP_algorithmic": 5.55, "TFLOP/s": round(5.55e3 / us, 1)})
     gco = torch.randn(8, 48, 64, 441, generator=g).to(dev)
     gf = torch.empty_like(f)
-    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco), 441, ptr(f), ptr(f), 256, 4, ptr(gf), ptr(None), 256, 1, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
-    report("correlation_nhwc_bwd 441ch N=8 (fused g0+g1)", 8 * 18.0e6, us, {"GFLOP_algorithmic": 11.1, "TFLOP/s": round(11.1e3 / us, 1)})
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd_pl(ptr(gco), 441, ptr(f), ptr(f), 256, planes_of(F.pl), planes_of(F.pl), 4, ptr(gf), ptr(None), 256, 1, 8, 256, 48, 64, 1, 20, 20, 1, 2, st)))
+    report("correlation_nhwc_bwd_pl 441ch N=8 (fused g0+g1)", 8 * 18.0e6, us, {"GFLOP_algorithmic": 11.1, "TFLOP/s": round(11.1e3 / us, 1)})
     # the north star's +-4-displacement 81-channel cost volume (HBM-bound: AI = 17.5 FLOP/B), 1/8 resolution of 768x1024
     N2, h2, w2 = 16, 96, 128
-    f2 = torch.randn(N2, h2, w2, 256, generator=g).to(dev)
+    F2 = with_planes(torch.randn(N2, h2, w2, 256, generator=g).to(dev))
+    f2 = F2.t
     co2 = torch.empty(N2, h2, w2, 84, device=dev)
     nb = N2 * h2 * w2 * (2 * 256 + 81) * 4
-    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f2), ptr(f2), 256, N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
     gfl = 2 * 81 * 256 * N2 * h2 * w2 / 1e9
-    report("correlation_nhwc_fwd 81ch (md=4, stride_2=1) N=16 96x128", nb, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f2), ptr(f2), 256, N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+    report("correlation_nhwc_fwd 81ch (md=4, stride_2=1) N=16 96x128, fp32 entry", nb, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
+    # planes entry: the features are read as 3 bf16 planes (6 B/value instead of 4)
+    nbp = N2 * h2 * w2 * (2 * 256 * 6 + 81 * 4)
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd_pl(ptr(f2), ptr(f2), 256, planes_of(F2.pl), planes_of(F2.pl), N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+    report("correlation_nhwc_fwd_pl 81ch (md=4, stride_2=1) N=16 96x128", nbp, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
     gco2 = torch.randn(N2, h2, w2, 84, generator=g).to(dev)
     gf2 = torch.empty_like(f2)
-    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco2), 84, ptr(f2), ptr(f2), 256, N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
     nbb = N2 * h2 * w2 * (81 + 2 * 256 + 256) * 4
-    report("correlation_nhwc_bwd 81ch N=16 96x128 (fused g0+g1)", nbb, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco2), 84, ptr(f2), ptr(f2), 256, N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+    report("correlation_nhwc_bwd 81ch N=16 96x128 (fused g0+g1), fp32 entry", nbb, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
+    nbbp = N2 * h2 * w2 * (81 * 4 + 2 * 256 * 6 + 256 * 4)
+    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd_pl(ptr(gco2), 84, ptr(f2), ptr(f2), 256, planes_of(F2.pl), planes_of(F2.pl), N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+    report("correlation_nhwc_bwd_pl 81ch N=16 96x128 (fused g0+g1)", nbbp, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
 
 
 if __name__ == "__main__":

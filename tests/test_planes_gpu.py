@@ -292,6 +292,16 @@ CORR_PL_CASES = [
     (4, 96, 16, 24, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),    # 3/8-width features
     (2, 64, 12, 40, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),      # 81 channels, 2 site tiles
     (2, 32, 9, 11, dict(kernel_size=1, max_displacement=3, pad=5, stride_1=1, stride_2=1)),       # pad > displacement
+    # narrow-band tiling (r <= 6 over several site tiles: 32 - 2r owned sites per tile, one Gram per displacement row)
+    (2, 64, 6, 131, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),      # 81 ch, 6 tiles, ragged
+    (2, 48, 5, 100, dict(kernel_size=1, max_displacement=6, pad=6, stride_1=1, stride_2=1)),      # r = 6: 20 owned sites
+    (2, 32, 7, 101, dict(kernel_size=1, max_displacement=8, pad=8, stride_1=1, stride_2=2)),      # r = 4 in two classes
+    (2, 32, 6, 90, dict(kernel_size=1, max_displacement=2, pad=4, stride_1=1, stride_2=1)),       # pad > displacement
+    # wide band by DMA (C % 64 == 0): row pairs, neighbour column tiles inside / outside the image, odd row counts
+    (2, 128, 11, 150, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),  # 3 tiles per class
+    (2, 128, 7, 80, dict(kernel_size=1, max_displacement=10, pad=10, stride_1=1, stride_2=1)),    # r = 10 at stride_2 = 1
+    (2, 128, 9, 40, dict(kernel_size=1, max_displacement=8, pad=12, stride_1=1, stride_2=1)),     # pad > displacement
+    (2, 192, 5, 33, dict(kernel_size=1, max_displacement=14, pad=14, stride_1=1, stride_2=2)),    # 3 waves, r = 7
 ]
 
 
@@ -308,6 +318,7 @@ def test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib):
     F = make_pt(feat, dev, 3, extra=8)
     oc, oh, ow = oracle_lib.correlation_out_shape(H, W, **attrs)
     out = torch.zeros(N, oh, ow, oc + 3, device=dev)
+    out[..., :oc] = float('nan')            # every output is written (also the all-zero Grams outside the image)
     a = attrs
     check(_lib.lib().unflow_correlation_nhwc_fwd_pl(ptr(F.t), ptr(F.t), F.t.stride(2), _lib.planes_of(F.pl), _lib.planes_of(F.pl),
                                                     B, ptr(out), oc + 3, N, C, H, W, a['kernel_size'], a['max_displacement'],
@@ -375,7 +386,9 @@ def test_fused_splitk_bit_identical_to_reduce_kernel(case, dev, tmp_path):
     assert torch.equal(y0, ref[0]) and torch.equal(dx0, ref[1]) and torch.equal(pl0, ref[2])
 
 
-@pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1)])
+@pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1),
+                                  # narrow-band tiling (correlation_planes.hip: corr_pl_tiles)
+                                  (1, 64, 6, 131, 4, 1), (2, 64, 5, 100, 6, 1), (1, 128, 7, 101, 8, 2)])
 def test_correlation_planes_bwd_vs_fp32_kernel(case, dev):
     """unflow_correlation_nhwc_bwd_pl (feature operand from the bf16 planes through LDS-DMA + transposing reads, band operand
     split in registers, six terms on the bf16 matrix cores) vs the fp32-MFMA backward of the same library (itself checked

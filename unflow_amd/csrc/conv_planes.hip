@@ -66,16 +66,7 @@ constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
   return tiles > stage ? tiles : stage;
 }
 
-// Workgroups are handed to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), so neighbouring tiles — which share
-// source rows (the vertical taps) — sit on different L2s.  This bijective remap of blockIdx.x gives every XCD a contiguous
-// run of tiles instead: its L2 then fetches each source row once, not once per XCD that holds one of the row's consumers.
-__host__ __device__ __forceinline__ int xcd_remap(int b, int n, int on) {
-  if (!on || n < 16) return b;
-  const int xcd = b & 7, idx = b >> 3;
-  const int q = n >> 3, r = n & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
+// (xcd_remap: igemm_shared.h)
 // The launch is a 1-D grid; the linear workgroup id is first made XCD-contiguous (xcd_remap: the workgroups one XCD runs
 // are a contiguous run of the work order) and then decoded so that the workgroups resident together on an XCD share
 // operands in its L2.  Orders (run_pl_gather picks one per layer):

@@ -9,6 +9,7 @@
 // 16-byte loads and serves all 2r+1 displacement rows of the block's four waves (padded rows: conflict-free b128 fragment
 // reads); the f1 fragments stream from L2 as 16-byte loads (8 consecutive channels of one pixel and plane = one MFMA operand
 // granule), four K16 slabs in flight per wave.  The forward f0 traffic drops from (2r+1) fetches per row to one.
+#include <cstdlib>
 #include "igemm_shared.h"
 #include "correlation_geom.h"
 
@@ -31,6 +32,8 @@ struct CorrPlParams {
   int off;  // input coordinate = output coordinate + off (= max_displacement - pad)
   int nA;   // 32-site tiles per residue class
   int T;    // neighbour tiles on each side that the band can reach: ceil(r / 32)
+  int vr;   // valid rows of a 32-row tile: 32, or 32 - 2r in narrow-band mode (then T = 0 and the column tile starts at i0 - r)
+  int joff; // column-tile offset: 0, or -r in narrow-band mode
 };
 
 __global__ __launch_bounds__(256) void corr_fwd_pl_kernel(const CorrPlParams p) {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void corr_fwd_pl_kernel(const CorrPlParams p) 
   const int ia = b % p.nA; b /= p.nA;
   const int q = b % p.s2; b /= p.s2;
   const int oy = b;
-  const int i0 = ia * 32;
+  const int i0 = ia * p.vr;
   const int n1 = (n + p.shift) % p.B;
   const int y0 = oy + p.off;
   const int C = p.C, Cg = C >> 3;
@@ -79,15 +82,29 @@ __global__ __launch_bounds__(256) void corr_fwd_pl_kernel(const CorrPlParams p) 
   // four slabs — of this Gram or the first group of the next one — are requested before the MFMAs of the current group
   // (two register sets; with one set every group exposed an L2 round trip: 98 us for 20 us of matrix-core work).
   int pi = pa, t = -p.T - 1, b_off = OOB_MARK, j0 = 0;
+  // band extraction: acc[r_] of lane (col j = l31, half h) is G[(r_&3) + 8*(r_>>2) + 4*h][j]
+  auto store_band = [&](int pi_c, int j0_c, const f32x16* g) {
+#pragma unroll
+    for (int r_ = 0; r_ < 16; r_++) {
+      const int i = i0 + (r_ & 3) + 8 * (r_ >> 2) + 4 * h;
+      const int o = (j0_c + l31) - i;
+      const int ox = q + p.s2 * i;
+      if (o >= -p.r && o <= p.r && ox < p.ow && i - i0 < p.vr)
+        p.out[(((size_t)n * p.oh + oy) * p.ow + ox) * p.ld_out + pi_c * p.gw + o + p.r] = g ? (*g)[r_] / cf : 0.f;
+    }
+  };
   auto next_item = [&]() -> bool {         // advance (pi, t) to the next item with a site inside the image
     for (;;) {
       if (++t > p.T) { t = -p.T; pi++; }
       if (pi >= pb) return false;
       const int y2 = y0 + p.s2 * (pi - p.r);
-      j0 = i0 + 32 * t;
+      j0 = i0 + 32 * t + p.joff;
       const int xb = q + p.off + p.s2 * (j0 + l31);
       const bool bok = (unsigned)y2 < (unsigned)p.H && (unsigned)xb < (unsigned)p.W;
-      if (!__any(bok)) continue;
+      if (!__any(bok)) {                   // no site of this Gram lies in the image: its band entries are zero
+        store_band(pi, j0, nullptr);
+        continue;
+      }
       b_off = bok ? ((n1 * p.H + y2) * p.W + xb) * ld2 + h * 16 : OOB_MARK;
       return true;
     }
@@ -133,16 +150,340 @@ __global__ __launch_bounds__(256) void corr_fwd_pl_kernel(const CorrPlParams p) 
       }
       mfma_group(b1, g2 + 1);
     }
-    // band extraction: acc[r_] of lane (col j = l31, half h) is G[(r_&3) + 8*(r_>>2) + 4*h][j]
-#pragma unroll
-    for (int r_ = 0; r_ < 16; r_++) {
-      const int i = i0 + (r_ & 3) + 8 * (r_ >> 2) + 4 * h;
-      const int o = (j0_c + l31) - i;
-      const int ox = q + p.s2 * i;
-      if (o >= -p.r && o <= p.r && ox < p.ow)
-        p.out[(((size_t)n * p.oh + oy) * p.ow + ox) * p.ld_out + pi_c * p.gw + o + p.r] = acc[r_] / cf;
-    }
+    store_band(pi_c, j0_c, &acc);
     have = more;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------- narrow-band forward
+// The +-4 cost volume of the full-resolution networks (r <= 6, several site tiles per row: corr_pl_tiles).  Streaming the
+// f1 fragments from L2 into registers (corr_fwd_pl_kernel) touches 32 cache lines per load instruction — one per site, 32
+// bytes of each — and with one Gram per displacement row there is no reuse to pay for it: the address path, not the
+// matrix cores or HBM, bounds that kernel here (481 us for 16 x 96 x 128 x 256; the matrix-core and HBM floors are ~125 us).
+// This kernel moves whole lines instead.  A block owns (sample, row, class, tile of 32 - 2r sites); wave w owns channels
+// 64 w .. 64 w + 63 (K is split over the waves) and keeps its f0 fragments in registers for all 2r+1 displacement rows.
+// The f1 rows go, one after the other, HBM/L2 -> a wave-private 12 KB LDS tile by LDS-DMA (8 full 128-byte lines per
+// instruction, source-side XOR swizzle so the b128 fragment reads are conflict-free); the next row's tile is requested as
+// soon as this row's fragments are in registers and lands under the 24 MFMAs.  The useful band of each partial Gram
+// ((32 - 2r) x (2r+1) of 1024 entries) goes to a wave-private LDS buffer; after a barrier the block sums the waves'
+// partials in a fixed order and writes each site's (2r+1)^2 contiguous outputs.
+//
+// Measured alternatives (16 x 96 x 128 x 256, r = 4): two output rows per block sharing each f1 tile,
+// with the band partials of two waves ADDED into one LDS buffer (ds_add_f32; commutative, so still reproducible) to keep
+// two blocks per CU: 505 us against 331-406 us — the 16 masked LDS atomics per Gram cost ~20 cycles each (190 us of the
+// 505; plain stores 58 us); one block per CU (larger LDS footprint): +37 %.  Ablations of this kernel: no MFMAs -27 %, no
+// f1 DMA -21 %, no band stores -10 %, none of the three: 160 us — the phases of a wave add up (two waves per SIMD, limited by
+// the 80 KB of LDS per block), which is what bounds it, not the matrix cores (floor ~125 us) or HBM (~130 us).
+__global__ __launch_bounds__(256, 2) void corr_fwd_nb_kernel(const CorrPlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int TILE = 3 * 32 * 64;                 // elements per wave: 3 planes x 32 sites x 64 channels
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  // work order: XCD-contiguous, site tiles fastest, then rows — the ~64 blocks resident together on an XCD are a few
+  // consecutive rows of one sample: neighbouring tiles share 2r f1 columns, neighbouring rows 2r of their 2r+1 f1 rows
+  int b = xcd_remap(blockIdx.x, gridDim.x, 1);
+  const int ia = b % p.nA; b /= p.nA;
+  const int oy = b % p.oh; b /= p.oh;
+  const int q = b % p.s2; b /= p.s2;
+  const int n = b;
+  const int i0 = ia * p.vr, c0 = wid * 64;
+  const int n1 = (n + p.shift) % p.B;
+  const int y0 = oy + p.off;
+  const int ld2 = p.ld * 2;
+  const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
+  u32x4 f1_rs[3];
+  __amdgpu_buffer_rsrc_t f0_rs[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    f0_rs[pl] = make_rsrc(p.f0 + pl * p.ps, recs);
+    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
+  }
+  unsigned short* tile = lds + wid * TILE;
+  const unsigned tile_addr = lds_addr(tile);
+  const int bsz = p.gw * p.vr * p.gw;               // band partials of one wave: [displacement row][site][offset]
+  float* band = reinterpret_cast<float*>(lds + nw * TILE);
+  float* myband = band + wid * bsz;
+
+  // f0 fragments, straight to registers (once per block; in flight together with the first f1 tile): slab u of lane
+  // (site l31, half h) = channels c0 + 16u + 8h .. + 7
+  s16x8 af[4][3];
+  {
+    const int xs = q + p.off + p.s2 * (i0 + l31);
+    // (the Gram rows past the owned sites are never read out: zeros, no traffic)
+    const bool ok = (unsigned)xs < (unsigned)p.W && (unsigned)y0 < (unsigned)p.H && l31 < p.vr;
+    const int voff = ok ? ((n * p.H + y0) * p.W + xs) * ld2 + (c0 + h * 8) * 2 : OOB_MARK;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) af[u][pl] = __builtin_bit_cast(s16x8, buf_ld16(f0_rs[pl], voff + u * 32));
+  }
+  // DMA lane mapping: instruction j covers sites 8j .. 8j+7 (one 128-byte line each); LDS slot lane % 8 of site 8j + lane/8
+  // receives the granule slot ^ ((site >> 1) & 7)
+  const int d_site = lane >> 3, d_slot = lane & 7;
+  const int k0 = i0 + p.joff;
+  auto issue_tile = [&](int yy) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int site = 8 * j + d_site;
+      const int g = d_slot ^ ((site >> 1) & 7);
+      const int xs = q + p.off + p.s2 * (k0 + site);
+      const bool ok = (unsigned)xs < (unsigned)p.W && (unsigned)yy < (unsigned)p.H;
+      const int voff = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + (c0 + g * 8) * 2 : OOB_MARK;
+      const unsigned d = tile_addr + (unsigned)(j * 1024);
+      dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+    }
+  };
+  // The displacement rows are visited in a rotated order: step t multiplies the f1 row R with R / s2 = t (mod 2r+1), so the
+  // 2r+1 blocks (neighbouring output rows) that need a given f1 row ask for it in the same step — one of them brings it
+  // into the XCD's L2, the others hit (measured: 2-3 %).
+  const int yq = (y0 - (p.s2 - 1) * (y0 < 0)) / p.s2;                       // floor(y0 / s2)
+  const int rot = ((p.r - yq) % p.gw + p.gw) % p.gw;
+  issue_tile(y0 + p.s2 * (rot - p.r));
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  for (int t = 0; t < p.gw; t++) {
+    const int pi = t + rot < p.gw ? t + rot : t + rot - p.gw;
+    const int pn = pi + 1 < p.gw ? pi + 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this row's tile has landed
+    __builtin_amdgcn_sched_barrier(0);
+    s16x8 bf[4][3];
+    // fragment of slab u: lane (site l31, half h) holds granule 2u + h of its site
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        bf[u][pl] = *reinterpret_cast<const s16x8*>(tile + pl * (32 * 64) + l31 * 64 + (((2 * u + h) ^ ((l31 >> 1) & 7)) << 3));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: the tile may be overwritten
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < p.gw) issue_tile(y0 + p.s2 * (pn - p.r));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int tt = 0; tt < 6; tt++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
+                                                      __builtin_bit_cast(bf16x8, bf[u][tb[tt]]), acc, 0, 0, 0);
+    // acc[e] of lane (column l31, half h) is G[li][l31], li = (e&3) + 8*(e>>2) + 4h; column j is site i0 - r + j, so the
+    // band offset index (o + r) of entry (li, j) is j - li
+    float* brow = myband + pi * p.vr * p.gw;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int li = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int oi = l31 - li;
+      if (li < p.vr && oi >= 0 && oi < p.gw) brow[li * p.gw + oi] = acc[e];
+    }
+  }
+  __syncthreads();
+  const float cf = (float)p.C;
+  const int g2 = p.gw * p.gw;
+  const float inv_g2 = 1.0f / (float)g2, inv_gw = 1.0f / (float)p.gw;
+  float* orow = p.out + ((size_t)n * p.oh + oy) * p.ow * p.ld_out;
+  for (int idx = threadIdx.x; idx < p.vr * g2; idx += blockDim.x) {
+    // idx = (li, pi, oi); the quotients are exact in fp32 at these sizes (the fractions stay >= 0.5 / 169 from an integer)
+    const int li = (int)(((float)idx + 0.5f) * inv_g2), rem = idx - li * g2;
+    const int pi = (int)(((float)rem + 0.5f) * inv_gw), oi = rem - pi * p.gw;
+    const int ox = q + p.s2 * (i0 + li);
+    if (ox >= p.ow) break;
+    const float* src = band + (pi * p.vr + li) * p.gw + oi;
+    float sum = src[0];
+    for (int w = 1; w < nw; w++) sum += src[w * bsz];
+    orow[(size_t)ox * p.ld_out + rem] = sum / cf;
+  }
+}
+
+
+// --------------------------------------------------------------------------------------- wide-band forward by DMA
+// FlowNetC's own cost volume (r = 10: the band of a 32-site tile covers most of its Gram and reaches into the neighbour
+// tiles).  corr_fwd_pl_kernel streams the f1 fragments from L2 at 32 cache lines per load instruction, ~64 cycles of the
+// CU's address path each — 3 blocks x 1008 such loads per CU are ~90 of its ~120 us at the step's shape.  Same remedy as the
+// narrow-band kernel above: K split over the waves (wave w: channels 64 w .. + 63, f0 fragments in registers), f1 tiles by
+// LDS-DMA in whole lines into a wave-private 12 KB tile, the next tile requested as soon as this one's fragments are in
+// registers.  A block owns a PAIR of output rows (oy, oy + s2): f1 row m is displacement row m of the first and m - 1 of the
+// second, so every tile feeds two Grams (48 MFMAs per DMA round trip).  The band is too large to keep per wave for the
+// whole block (2r+1 Grams x 2.7 KB), so each step's partial Grams are exchanged at once: every wave stores its 32 x 32
+// partials (LDS, 4 KB per Gram), barrier, the block sums the waves' partials in a fixed order and writes the band entries
+// of this (displacement row, column tile), barrier.  Column tiles / f1 rows outside the image are not multiplied; their
+// band entries are zero-filled up front, while the first tile is in flight.
+__global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int TILE = 3 * 32 * 64;                 // elements per wave: 3 planes x 32 sites x 64 channels
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  // work order: XCD-contiguous; row pairs fastest, samples slowest (the step's 8 samples: one per XCD)
+  int b = xcd_remap(blockIdx.x, gridDim.x, 1);
+  const int npr = ((p.oh + p.s2 - 1) / p.s2 + 1) >> 1;
+  const int pr = b % npr; b /= npr;
+  const int ry = b % p.s2; b /= p.s2;
+  const int ia = b % p.nA; b /= p.nA;
+  const int q = b % p.s2; b /= p.s2;
+  const int n = b;
+  const int oy = ry + p.s2 * 2 * pr;
+  if (oy >= p.oh) return;
+  const bool two = oy + p.s2 < p.oh;                // the pair's second row exists
+  const int i0 = ia * 32, c0 = wid * 64;
+  const int n1 = (n + p.shift) % p.B;
+  const int y0 = oy + p.off;
+  const int ld2 = p.ld * 2;
+  const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
+  u32x4 f1_rs[3];
+  __amdgpu_buffer_rsrc_t f0_rs[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    f0_rs[pl] = make_rsrc(p.f0 + pl * p.ps, recs);
+    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
+  }
+  unsigned short* tile = lds + wid * TILE;
+  const unsigned tile_addr = lds_addr(tile);
+  float* part = reinterpret_cast<float*>(lds + nw * TILE);     // [wave][output row 0/1][32 x 32]
+  float* mypart = part + wid * 2048;
+
+  // f0 fragments of the two rows, straight to registers (in flight together with the first f1 tile)
+  s16x8 af[2][4][3];
+  {
+    const int xs = q + p.off + p.s2 * (i0 + l31);
+    const bool okx = (unsigned)xs < (unsigned)p.W;
+#pragma unroll
+    for (int rw = 0; rw < 2; rw++) {
+      const int yy = y0 + rw * p.s2;
+      const bool ok = okx && (unsigned)yy < (unsigned)p.H && (rw == 0 || two);
+      const int voff = ok ? ((n * p.H + yy) * p.W + xs) * ld2 + (c0 + h * 8) * 2 : OOB_MARK;
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) af[rw][u][pl] = __builtin_bit_cast(s16x8, buf_ld16(f0_rs[pl], voff + u * 32));
+    }
+  }
+  const int d_site = lane >> 3, d_slot = lane & 7;  // DMA lane mapping: see corr_fwd_nb_kernel
+  auto issue_tile = [&](int m, int t) {
+    const int yy = y0 + p.s2 * (m - p.r), k0 = i0 + 32 * t;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int site = 8 * j + d_site;
+      const int g = d_slot ^ ((site >> 1) & 7);
+      const int xs = q + p.off + p.s2 * (k0 + site);
+      const bool ok = (unsigned)xs < (unsigned)p.W;
+      const int voff = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + (c0 + g * 8) * 2 : OOB_MARK;
+      const unsigned d = tile_addr + (unsigned)(j * 1024);
+      dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+    }
+  };
+  const int M = two ? p.gw + 1 : p.gw;              // f1 rows y0 + s2 (m - r), m = 0 .. M-1
+  auto live = [&](int m, int t) -> bool {           // has f1 row m, column tile t a site inside the image?
+    const int yy = y0 + p.s2 * (m - p.r), k0 = i0 + 32 * t;
+    return (unsigned)yy < (unsigned)p.H && q + p.off + p.s2 * k0 < p.W && q + p.off + p.s2 * (k0 + 31) >= 0;
+  };
+  auto next_live = [&](int& m, int& t) -> bool {    // advance (m, t) to the next live tile
+    for (;;) {
+      if (++t > p.T) { t = -p.T; m++; }
+      if (m >= M) return false;
+      if (live(m, t)) return true;
+    }
+  };
+  const float cf = (float)p.C, rcf = 1.0f / cf;
+  const bool pow2 = (p.C & (p.C - 1)) == 0;         // then x * (1/C) == x / C exactly
+  const float inv_gw = 1.0f / (float)p.gw;
+  // The band entries of f1 row m: those whose column lies in tile t are summed from the waves' partial Grams (t = tsum);
+  // those of DEAD column tiles (no site inside the image: nothing is multiplied) are zero-filled when `zeros` is set — by the
+  // first live tile of the row, or, for a row with no live tile at all, by the pass below (tsum = an impossible tile).
+  // a thread's band entries idx = tid + k * blockDim (li, oi) are the same in every step: partial-Gram index, column tile
+  // and output offset once (NE covers 32 x 41 entries at 256 threads; the host checks it)
+  constexpr int NE = 6;
+  int e_src[NE], e_dst[NE], e_tj[NE];
+#pragma unroll
+  for (int k = 0; k < NE; k++) {
+    const int idx = threadIdx.x + k * blockDim.x;
+    const int li = (int)(((float)idx + 0.5f) * inv_gw), oi = idx - li * p.gw;     // exact in fp32 at these sizes
+    const int jabs = li + oi - p.r;                                                // column relative to the tile's first site
+    const int ox = q + p.s2 * (i0 + li);
+    const bool ok = idx < 32 * p.gw && ox < p.ow;
+    e_src[k] = li * 32 + (jabs & 31);
+    e_tj[k] = ok ? (jabs >> 5) : 0x7ffe;                                           // (matches no tile)
+    e_dst[k] = ox * p.ld_out + oi;
+  }
+  auto write_band = [&](int m, int tsum, bool zeros) {
+#pragma unroll 1
+    for (int rw = 0; rw < 2; rw++) {
+      const int pi = m - rw;
+      if (pi < 0 || pi >= p.gw || (rw == 1 && !two)) continue;
+      float* orow = p.out + ((size_t)n * p.oh + oy + rw * p.s2) * p.ow * p.ld_out + pi * p.gw;
+#pragma unroll
+      for (int k = 0; k < NE; k++) {
+        if (k * (int)blockDim.x >= 32 * p.gw) break;
+        const int tj = e_tj[k];
+        float sum = 0.f;
+        if (tj == tsum) {
+          const float* src = part + rw * 1024 + e_src[k];
+          sum = src[0];
+          for (int w = 1; w < nw; w++) sum += src[w * 2048];
+          sum = pow2 ? sum * rcf : sum / cf;
+        } else if (tj == 0x7ffe || !zeros || live(m, tj)) {
+          continue;
+        }
+        orow[e_dst[k]] = sum;
+      }
+    }
+  };
+
+  int m = 0, t = -p.T - 1;
+  bool have = next_live(m, t);
+  if (have) issue_tile(m, t);
+  for (int dm = 0; dm < M; dm++) {                  // f1 rows outside the image: all their entries are zero
+    bool any = false;
+    for (int dt = -p.T; dt <= p.T; dt++) any = any || live(dm, dt);
+    if (!any) write_band(dm, 0x7fff, true);           // (0x7fff: no entry is summed)
+  }
+  int m_prev = -1;
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  while (have) {
+    const int mc = m, tc = t;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile has landed
+    __builtin_amdgcn_sched_barrier(0);
+    s16x8 bf[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        bf[u][pl] = *reinterpret_cast<const s16x8*>(tile + pl * (32 * 64) + l31 * 64 + (((2 * u + h) ^ ((l31 >> 1) & 7)) << 3));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: the tile may be overwritten
+    __builtin_amdgcn_sched_barrier(0);
+    have = next_live(m, t);
+    if (have) issue_tile(m, t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rw = 0; rw < 2; rw++) {
+      const int pi = mc - rw;
+      if (pi < 0 || pi >= p.gw || (rw == 1 && !two)) continue;     // (block-uniform)
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int tt = 0; tt < 6; tt++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[rw][u][ta[tt]]),
+                                                        __builtin_bit_cast(bf16x8, bf[u][tb[tt]]), acc, 0, 0, 0);
+      // acc[e] of lane (column l31, half h) is G[li][l31], li = (e&3) + 8*(e>>2) + 4h
+#pragma unroll
+      for (int e = 0; e < 16; e++) mypart[rw * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc[e];
+    }
+    // exchange: raw barriers (a __syncthreads() would also wait for the tile in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    write_band(mc, tc, mc != m_prev);
+    m_prev = mc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the partials have been read)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -167,6 +508,7 @@ struct CorrBwdPlParams {
   int B, C, H, W;
   int oh, ow, r, gw, s2;
   int off, nA, T;
+  int vr, joff;   // narrow-band mode: see CorrPlParams
 };
 
 __device__ __forceinline__ int corr_tr_swz64(int k, int granule) {      // conv_planes.hip tr_swz<64>
@@ -201,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   const int q = (int)(job % p.s2); job /= p.s2;
   const int y = (int)job;
   if (y >= p.H) return;
-  const int i0 = ia * 32, c0 = cg * 64;
+  const int i0 = ia * p.vr, c0 = cg * 64;
   const int role_lo = p.fuse ? 0 : (int)blockIdx.y, role_hi = p.fuse ? 1 : (int)blockIdx.y;
   unsigned short* tile = lds + wid * TILE;
   const unsigned tile_addr = lds_addr(tile);
@@ -246,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
       ysrc = role == 0 ? y + dyp : y - dyp;
       oy = (role == 0 ? y : y - dyp) - p.off;
       if ((unsigned)ysrc >= (unsigned)p.H || (unsigned)oy >= (unsigned)p.oh) continue;
-      k0 = i0 + 32 * it_t;
+      k0 = i0 + 32 * it_t + p.joff;
       const int xk_lo = q + p.off + p.s2 * k0, xk_hi = q + p.off + p.s2 * (k0 + 31);
       if (xk_hi < 0 || xk_lo >= p.W) continue;
       return true;
@@ -337,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   for (int e = 0; e < 16; e++) {
     const int i = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
     const int x = q + p.off + p.s2 * i;
-    if ((unsigned)x >= (unsigned)p.W) continue;
+    if ((unsigned)x >= (unsigned)p.W || i - i0 >= p.vr) continue;
     float* d = gout + (((size_t)s * p.H + y) * p.W + x) * p.ld_g + c0 + l31;
 #pragma unroll
     for (int c = 0; c < 2; c++) d[32 * c] = acc[c][e] / cf;
@@ -355,6 +697,30 @@ int corr_pl_supported(const CorrGeom& g, int C, const unflow_planes* a, const un
   return 1;
 }
 
+// Tiles of 32 sites per residue class.  Wide band (FlowNetC: r = 10, and the image is one tile wide): the band of a tile reaches
+// into its neighbour tiles, T = ceil(r / 32) Gram tiles on each side.  Narrow band over several tiles (the +-4 cost volume of
+// the north star: r = 4): a tile owns 32 - 2r sites and ONE Gram tile whose columns start r sites to the left covers their
+// whole band — 24 x 9 useful products of 1024 instead of 32 x 9 of 3072.
+static bool corr_nb_enabled() {             // A/B knob: UNFLOW_CORR_NB=0 keeps the streaming kernel in narrow-band mode
+  static const bool on = [] { const char* e = getenv("UNFLOW_CORR_NB"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static bool corr_wb_enabled() {             // A/B knob: UNFLOW_CORR_WB=0 keeps the streaming kernel for wide bands
+  static const bool on = [] { const char* e = getenv("UNFLOW_CORR_WB"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static void corr_pl_tiles(int nq, int r, int* nA, int* T, int* vr, int* joff) {
+  if (nq > 32 && r <= 6) {
+    *vr = 32 - 2 * r; *joff = -r; *T = 0;
+    *nA = (nq + *vr - 1) / *vr;
+  } else {
+    *vr = 32; *joff = 0; *T = (r + 31) / 32;
+    *nA = (nq + 31) / 32;
+  }
+}
+
 int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, float* out, int ld_out, int B, int C, int H,
                 int W, const CorrGeom& g, hipStream_t st) {
   CorrPlParams p{};
@@ -367,8 +733,32 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   p.off = g.md - g.pad;
   const int span = max(g.ow, W - p.off);
   const int nq = (span + g.s2 - 1) / g.s2;
-  p.nA = (nq + 31) / 32;
-  p.T = (g.r + 31) / 32;
+  corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
+  const bool al16 = in0->ld % 8 == 0 && ((reinterpret_cast<uintptr_t>(in0->base) | reinterpret_cast<uintptr_t>(in1->base)) & 15) == 0;
+  if (p.joff != 0 && C % 64 == 0 && C <= 256 && al16 && corr_nb_enabled()) {
+    // (16-byte granules; with ld % 64 == 0 and a 128-byte-aligned base — the step's feature buffers — every DMA
+    // instruction moves 8 whole cache lines)
+    const int nw = C / 64;
+    const int nb_smem = nw * (3 * 32 * 64 * 2 + g.gw * p.vr * g.gw * 4);
+    static int nb_set = 0;
+    if (nb_smem > nb_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_nb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                nb_smem);
+      nb_set = nb_smem;
+    }
+    corr_fwd_nb_kernel<<<B * p.nA * g.s2 * g.oh, 64 * nw, nb_smem, st>>>(p);
+    return launch_status();
+  }
+  if (p.joff == 0 && C % 64 == 0 && C <= 256 && al16 && 32 * g.gw <= 6 * 64 * (C / 64) && corr_wb_enabled()) {
+    const int nw = C / 64;
+    const int wb_smem = nw * (3 * 32 * 64 * 2 + 2 * 32 * 32 * 4);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_wb_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * 32 * 64 * 2 + 2 * 32 * 32 * 4));
+    (void)attr;
+    const int npr = ((g.oh + g.s2 - 1) / g.s2 + 1) / 2;       // row pairs (oy, oy + s2) per row class
+    corr_fwd_wb_kernel<<<B * g.s2 * p.nA * g.s2 * npr, 64 * nw, wb_smem, st>>>(p);
+    return launch_status();
+  }
   const int smem = 3 * 32 * (C + 8) * 2;
   static int smem_set = 0;   // grow-only: benign race, idempotent
   if (smem > smem_set) {
@@ -393,8 +783,7 @@ int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const 
   p.off = g.md - g.pad;
   const int span = max(g.ow, W - p.off);
   const int nq = (span + g.s2 - 1) / g.s2;
-  p.nA = (nq + 31) / 32;
-  p.T = (g.r + 31) / 32;
+  corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
   const int smem = 4 * 3 * 32 * 64 * 2;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -100,6 +100,16 @@ __device__ __forceinline__ void dma3(int voff, u32x4 r0, u32x4 r1, u32x4 r2, uns
       : "memory");
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), so neighbouring tiles — which share
+// source rows (the vertical taps) — sit on different L2s.  This bijective remap of blockIdx.x gives every XCD a contiguous
+// run of tiles instead: its L2 then fetches each source row once, not once per XCD that holds one of the row's consumers.
+__host__ __device__ __forceinline__ int xcd_remap(int b, int n, int on) {
+  if (!on || n < 16) return b;
+  const int xcd = b & 7, idx = b >> 3;
+  const int q = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---- fp32 -> 16-bit operand planes -------------------------------------------------------------------------------------
 // x = hi + mid + lo with three bf16 values (3 x 8 significand bits = the 24 of fp32, same exponent range); a*b is summed
 // from the six terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 (fp32 accumulation); the
