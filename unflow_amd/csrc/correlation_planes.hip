@@ -509,6 +509,7 @@ struct CorrBwdPlParams {
   int oh, ow, r, gw, s2;
   int off, nA, T;
   int vr, joff;   // narrow-band mode: see CorrPlParams
+  unsigned dout_bytes;   // bytes of dout up to its last band entry (0: larger than 1 GiB, dword gathers only)
 };
 
 __device__ __forceinline__ int corr_tr_swz64(int k, int granule) {      // conv_planes.hip tr_swz<64>
@@ -608,11 +609,45 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
       else dma3(voff, f0_rs[0], f0_rs[1], f0_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
     }
   };
-  // the band operand of the current item: av[slab][e] for contracted site k0 + 16 slab + 8 h + e (masked gathers)
+  // the band operand of the current item: av[slab][e] for contracted site k0 + 16 slab + 8 h + e.
+  // Role 1 (site = k, offset own - k): for a fixed e the lanes own = 0 .. 31 read consecutive addresses — 16 coalesced dword
+  // loads.  Role 0 (site = own, offset k - own): for a fixed e the lanes are ld_dout - 1 floats apart, 32 cache lines per
+  // instruction; but the 8 values of a lane's slab half are CONSECUTIVE in memory, so they come as two 16-byte loads (dword
+  // aligned; entries outside the band masked afterwards) — 4 instructions per item instead of 16 on the address path that
+  // bounds this kernel.  A run that would start before / end after the buffer (first / last site only) takes the dword path.
+  const __amdgpu_buffer_rsrc_t dout_rs = make_rsrc(p.dout, p.dout_bytes);
   auto load_band = [&](float (&av)[2][8]) {
     const int role = it_role;
-    const float* drow = p.dout + ((size_t)nd * p.oh + oy) * p.ow * p.ld_dout + it_pi * p.gw + p.r;
+    const size_t srow = ((size_t)nd * p.oh + oy) * p.ow;
     const int own = i0 + l31;
+    if (role == 0 && p.dout_bytes != 0) {
+      const int ox = q + p.s2 * own;
+      const bool site_ok = (unsigned)ox < (unsigned)p.ow;
+      const long base = (long)(srow + (site_ok ? ox : 0)) * p.ld_dout + it_pi * p.gw;      // float index of offset -r
+      int ois[2];
+      bool run_ok[2], edge = false;
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        ois[sl] = k0 + 16 * sl + 8 * h - own + p.r;
+        run_ok[sl] = site_ok && ois[sl] + 7 >= 0 && ois[sl] < p.gw;
+        const long idx = base + ois[sl];
+        edge = edge || (run_ok[sl] && (idx < 0 || (idx + 8) * 4 > (long)p.dout_bytes));
+      }
+      if (!__any(edge)) {
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+          const int voff = run_ok[sl] ? (int)((base + ois[sl]) * 4) : OOB_MARK;
+          const u32x4 lo = buf_ld16(dout_rs, voff), hi = buf_ld16(dout_rs, voff + 16);
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float v = __uint_as_float(e < 4 ? lo[e] : hi[e - 4]);
+            av[sl][e] = (unsigned)(ois[sl] + e) < (unsigned)p.gw ? v : 0.f;
+          }
+        }
+        return;
+      }
+    }
+    const float* drow = p.dout + srow * p.ld_dout + it_pi * p.gw + p.r;
 #pragma unroll
     for (int sl = 0; sl < 2; sl++)
 #pragma unroll
@@ -711,6 +746,11 @@ static bool corr_wb_enabled() {             // A/B knob: UNFLOW_CORR_WB=0 keeps 
   return on;
 }
 
+static bool corr_bwd_b128_enabled() {       // A/B knob: UNFLOW_CORR_BWD_B128=0 keeps the dword gathers of the band operand
+  static const bool on = [] { const char* e = getenv("UNFLOW_CORR_BWD_B128"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static void corr_pl_tiles(int nq, int r, int* nA, int* T, int* vr, int* joff) {
   if (nq > 32 && r <= 6) {
     *vr = 32 - 2 * r; *joff = -r; *T = 0;
@@ -784,6 +824,8 @@ int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const 
   const int span = max(g.ow, W - p.off);
   const int nq = (span + g.s2 - 1) / g.s2;
   corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
+  const size_t dbytes = (((size_t)B * g.oh * g.ow - 1) * (size_t)ld_dout + (size_t)g.gw * g.gw) * 4;
+  p.dout_bytes = dbytes < ((size_t)1 << 30) && corr_bwd_b128_enabled() ? (unsigned)dbytes : 0u;
   const int smem = 4 * 3 * 32 * 64 * 2;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
