@@ -309,6 +309,12 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_nb_kernel(const CorrPlParams 
 // partials (LDS, 4 KB per Gram), barrier, the block sums the waves' partials in a fixed order and writes the band entries
 // of this (displacement row, column tile), barrier.  Column tiles / f1 rows outside the image are not multiplied; their
 // band entries are zero-filled up front, while the first tile is in flight.
+// (Measured and dropped: three rows per block with double-buffered tiles, so that the step's shape is exactly one block per
+// CU instead of 384 pair blocks on 256 CUs: 117 us against 108; issuing the band stores before the next step's MFMAs instead
+// of right before its s_waitcnt; one batch of LDS reads per row before the stores: both neutral to worse.  Ablation of the
+// pair kernel, 113 us on that box: no band exchange 74, no MFMAs 91, neither 55, nothing but fragments and barriers 50 — the
+// per-block prologue and the serial chain of a step, not a throughput limit.)
+constexpr int WB_ROWS = 2;                             // output rows per block
 __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   constexpr int TILE = 3 * 32 * 64;                 // elements per wave: 3 planes x 32 sites x 64 channels
@@ -316,17 +322,17 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  // work order: XCD-contiguous; row pairs fastest, samples slowest (the step's 8 samples: one per XCD)
+  // work order: XCD-contiguous; row groups fastest, samples slowest (the step's 8 samples: one per XCD)
   int b = xcd_remap(blockIdx.x, gridDim.x, 1);
-  const int npr = ((p.oh + p.s2 - 1) / p.s2 + 1) >> 1;
+  const int npr = ((p.oh + p.s2 - 1) / p.s2 + WB_ROWS - 1) / WB_ROWS;
   const int pr = b % npr; b /= npr;
   const int ry = b % p.s2; b /= p.s2;
   const int ia = b % p.nA; b /= p.nA;
   const int q = b % p.s2; b /= p.s2;
   const int n = b;
-  const int oy = ry + p.s2 * 2 * pr;
+  const int oy = ry + p.s2 * WB_ROWS * pr;
   if (oy >= p.oh) return;
-  const bool two = oy + p.s2 < p.oh;                // the pair's second row exists
+  const int nv = min(WB_ROWS, (p.oh - oy + p.s2 - 1) / p.s2);     // rows of the group that exist
   const int i0 = ia * 32, c0 = wid * 64;
   const int n1 = (n + p.shift) % p.B;
   const int y0 = oy + p.off;
@@ -341,18 +347,18 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
   }
   unsigned short* tile = lds + wid * TILE;
   const unsigned tile_addr = lds_addr(tile);
-  float* part = reinterpret_cast<float*>(lds + nw * TILE);     // [wave][output row 0/1][32 x 32]
-  float* mypart = part + wid * 2048;
+  float* part = reinterpret_cast<float*>(lds + nw * TILE);     // [wave][output row][32 x 32]
+  float* mypart = part + wid * (WB_ROWS * 1024);
 
-  // f0 fragments of the two rows, straight to registers (in flight together with the first f1 tile)
-  s16x8 af[2][4][3];
+  // f0 fragments of the rows, straight to registers (in flight together with the first f1 tile)
+  s16x8 af[WB_ROWS][4][3];
   {
     const int xs = q + p.off + p.s2 * (i0 + l31);
     const bool okx = (unsigned)xs < (unsigned)p.W;
 #pragma unroll
-    for (int rw = 0; rw < 2; rw++) {
+    for (int rw = 0; rw < WB_ROWS; rw++) {
       const int yy = y0 + rw * p.s2;
-      const bool ok = okx && (unsigned)yy < (unsigned)p.H && (rw == 0 || two);
+      const bool ok = okx && (unsigned)yy < (unsigned)p.H && rw < nv;
       const int voff = ok ? ((n * p.H + yy) * p.W + xs) * ld2 + (c0 + h * 8) * 2 : OOB_MARK;
 #pragma unroll
       for (int u = 0; u < 4; u++)
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
       dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
     }
   };
-  const int M = two ? p.gw + 1 : p.gw;              // f1 rows y0 + s2 (m - r), m = 0 .. M-1
+  const int M = p.gw + nv - 1;                      // f1 rows y0 + s2 (m - r), m = 0 .. M-1: row m is displacement row m - rw of row rw
   auto live = [&](int m, int t) -> bool {           // has f1 row m, column tile t a site inside the image?
     const int yy = y0 + p.s2 * (m - p.r), k0 = i0 + 32 * t;
     return (unsigned)yy < (unsigned)p.H && q + p.off + p.s2 * k0 < p.W && q + p.off + p.s2 * (k0 + 31) >= 0;
@@ -403,15 +409,18 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
     const int jabs = li + oi - p.r;                                                // column relative to the tile's first site
     const int ox = q + p.s2 * (i0 + li);
     const bool ok = idx < 32 * p.gw && ox < p.ow;
-    e_src[k] = li * 32 + (jabs & 31);
+    e_src[k] = ok ? li * 32 + (jabs & 31) : 0;
     e_tj[k] = ok ? (jabs >> 5) : 0x7ffe;                                           // (matches no tile)
     e_dst[k] = ox * p.ld_out + oi;
   }
+  // (Code size matters here: a block runs each instruction only ~2r+3 times, so the first pass through the kernel is
+  // instruction-fetch bound — measured floor with every phase switched off: 41 us at 27 KB of code.  write_band is therefore
+  // instantiated ONCE, its row loop stays rolled, and the zero-fill of rows outside the image is a plain rolled loop.)
   auto write_band = [&](int m, int tsum, bool zeros) {
 #pragma unroll 1
-    for (int rw = 0; rw < 2; rw++) {
+    for (int rw = 0; rw < WB_ROWS; rw++) {
       const int pi = m - rw;
-      if (pi < 0 || pi >= p.gw || (rw == 1 && !two)) continue;
+      if (pi < 0 || pi >= p.gw || rw >= nv) continue;
       float* orow = p.out + ((size_t)n * p.oh + oy + rw * p.s2) * p.ow * p.ld_out + pi * p.gw;
 #pragma unroll
       for (int k = 0; k < NE; k++) {
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
         if (tj == tsum) {
           const float* src = part + rw * 1024 + e_src[k];
           sum = src[0];
-          for (int w = 1; w < nw; w++) sum += src[w * 2048];
+          for (int w = 1; w < nw; w++) sum += src[w * (WB_ROWS * 1024)];
           sum = pow2 ? sum * rcf : sum / cf;
         } else if (tj == 0x7ffe || !zeros || live(m, tj)) {
           continue;
@@ -431,35 +440,63 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
     }
   };
 
+  // the tile pipeline: `cur` is multiplied in this step, `nxt` is in flight
   int m = 0, t = -p.T - 1;
-  bool have = next_live(m, t);
-  if (have) issue_tile(m, t);
+  bool cur_ok = next_live(m, t), nxt_ok = false;
+  int cur_m = m, cur_t = t, nxt_m = 0, nxt_t = 0;
+  if (cur_ok) issue_tile(cur_m, cur_t);
+#pragma unroll 1
   for (int dm = 0; dm < M; dm++) {                  // f1 rows outside the image: all their entries are zero
     bool any = false;
     for (int dt = -p.T; dt <= p.T; dt++) any = any || live(dm, dt);
-    if (!any) write_band(dm, 0x7fff, true);           // (0x7fff: no entry is summed)
+    if (any) continue;
+#pragma unroll 1
+    for (int rw = 0; rw < nv; rw++) {
+      const int pi = dm - rw;
+      if (pi < 0 || pi >= p.gw) continue;
+      float* orow = p.out + ((size_t)n * p.oh + oy + rw * p.s2) * p.ow * p.ld_out + pi * p.gw;
+#pragma unroll 1
+      for (int idx = threadIdx.x; idx < 32 * p.gw; idx += blockDim.x) {
+        const int li = (int)(((float)idx + 0.5f) * inv_gw), oi = idx - li * p.gw;
+        const int ox = q + p.s2 * (i0 + li);
+        if (ox < p.ow) orow[(size_t)ox * p.ld_out + oi] = 0.f;
+      }
+    }
   }
-  int m_prev = -1;
+  int prv_m = -1, prv_t = 0, pp_m = -1;             // the step whose partial Grams are in LDS, and the f1 row before it
   constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
-  while (have) {
-    const int mc = m, tc = t;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this tile has landed
-    __builtin_amdgcn_sched_barrier(0);
+  // A step: wait for its tile - fragments -> registers - the PREVIOUS step's band (LDS partials -> global stores) - request
+  // a tile - barrier - 24 MFMAs per row, partial Grams -> LDS - barrier; one more pass writes the last band.
+#pragma unroll 1
+  for (;;) {
+    const int mc = cur_m, tc = cur_t;
     s16x8 bf[4][3];
+    if (cur_ok) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this step's tile has landed
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned short* tl = tile;
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+      for (int u = 0; u < 4; u++)
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++)
-        bf[u][pl] = *reinterpret_cast<const s16x8*>(tile + pl * (32 * 64) + l31 * 64 + (((2 * u + h) ^ ((l31 >> 1) & 7)) << 3));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: the tile may be overwritten
+        for (int pl = 0; pl < 3; pl++)
+          bf[u][pl] = *reinterpret_cast<const s16x8*>(tl + pl * (32 * 64) + l31 * 64 + (((2 * u + h) ^ ((l31 >> 1) & 7)) << 3));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments in registers: the tile may be overwritten
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (prv_m >= 0) write_band(prv_m, prv_t, prv_m != pp_m);
+    if (!cur_ok) break;
     __builtin_amdgcn_sched_barrier(0);
-    have = next_live(m, t);
-    if (have) issue_tile(m, t);
+    nxt_ok = next_live(m, t);
+    nxt_m = m; nxt_t = t;
+    if (nxt_ok) issue_tile(nxt_m, nxt_t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the previous partials have been read)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                    // raw barriers: a __syncthreads() would also wait for the tiles in flight
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int rw = 0; rw < 2; rw++) {
+    for (int rw = 0; rw < WB_ROWS; rw++) {
       const int pi = mc - rw;
-      if (pi < 0 || pi >= p.gw || (rw == 1 && !two)) continue;     // (block-uniform)
+      if (pi < 0 || pi >= p.gw || rw >= nv) continue;              // (block-uniform)
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[e] = 0.f;
@@ -473,17 +510,12 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
 #pragma unroll
       for (int e = 0; e < 16; e++) mypart[rw * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc[e];
     }
-    // exchange: raw barriers (a __syncthreads() would also wait for the tile in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    write_band(mc, tc, mc != m_prev);
-    m_prev = mc;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the partials have been read)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    pp_m = prv_m; prv_m = mc; prv_t = tc;
+    cur_ok = nxt_ok; cur_m = nxt_m; cur_t = nxt_t;
   }
 }
 
@@ -791,12 +823,12 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   }
   if (p.joff == 0 && C % 64 == 0 && C <= 256 && al16 && 32 * g.gw <= 6 * 64 * (C / 64) && corr_wb_enabled()) {
     const int nw = C / 64;
-    const int wb_smem = nw * (3 * 32 * 64 * 2 + 2 * 32 * 32 * 4);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_wb_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (3 * 32 * 64 * 2 + 2 * 32 * 32 * 4));
-    (void)attr;
     const int npr = ((g.oh + g.s2 - 1) / g.s2 + 1) / 2;       // row pairs (oy, oy + s2) per row class
-    corr_fwd_wb_kernel<<<B * g.s2 * p.nA * g.s2 * npr, 64 * nw, wb_smem, st>>>(p);
+    constexpr int per_wave = 3 * 32 * 64 * 2 + 2 * 32 * 32 * 4;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_wb_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * per_wave);
+    (void)attr;
+    corr_fwd_wb_kernel<<<B * g.s2 * p.nA * g.s2 * npr, 64 * nw, nw * per_wave, st>>>(p);
     return launch_status();
   }
   const int smem = 3 * 32 * (C + 8) * 2;
