@@ -569,13 +569,16 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int l31 = lane & 31, h = lane >> 5;
   const int ncg = p.C >> 6;
-  long job = (long)blockIdx.x * 4 + wid;
+  // work order: XCD-contiguous (xcd_remap), rows fastest, samples slowest: the blocks resident together on an XCD are
+  // consecutive rows of one (sample, site tile) and share the feature rows their displacement rows read (the step's shape:
+  // one sample per XCD, as before; the 81-channel point: FETCH_SIZE 2.30 -> see DESIGN.md §4.2)
+  long job = (long)xcd_remap(blockIdx.x, gridDim.x, 1) * 4 + wid;
   const int cg = (int)(job % ncg); job /= ncg;
-  const int s = (int)(job % p.B); job /= p.B;
+  const int y = (int)(job % p.H); job /= p.H;
   const int ia = (int)(job % p.nA); job /= p.nA;
   const int q = (int)(job % p.s2); job /= p.s2;
-  const int y = (int)job;
-  if (y >= p.H) return;
+  const int s = (int)job;
+  if (s >= p.B) return;
   const int i0 = ia * p.vr, c0 = cg * 64;
   const int role_lo = p.fuse ? 0 : (int)blockIdx.y, role_hi = p.fuse ? 1 : (int)blockIdx.y;
   unsigned short* tile = lds + wid * TILE;
@@ -609,11 +612,16 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   const int d_site = lane >> 3, d_slot = lane & 7;
 
   // iteration state
-  int it_role = role_lo, it_pi = -1, it_t = p.T;      // advanced before use
+  // The displacement rows are visited in a rotated order (corr_fwd_nb_kernel): step k of a role takes the row whose feature
+  // row R has R / s2 = k (mod 2r+1), so the blocks of neighbouring rows y ask for a feature row in the same step.
+  const int yq = (y - (p.s2 - 1) * (y < 0)) / p.s2;
+  const int rot0 = ((p.r - yq) % p.gw + p.gw) % p.gw, rot1 = (yq + p.r) % p.gw;
+  int it_role = role_lo, it_k = -1, it_pi = 0, it_t = p.T;      // advanced before use
   int nd = 0, ns = 0, ysrc = 0, oy = 0, k0 = 0;
   auto next_item = [&]() -> bool {
     for (;;) {
-      if (++it_t > p.T) { it_t = -p.T; if (++it_pi >= p.gw) { it_pi = 0; if (++it_role > role_hi) return false; } }
+      if (++it_t > p.T) { it_t = -p.T; if (++it_k >= p.gw) { it_k = 0; if (++it_role > role_hi) return false; } }
+      it_pi = it_role == 0 ? (it_k + rot0) % p.gw : ((rot1 - it_k) % p.gw + p.gw) % p.gw;
       const int role = it_role;
       nd = role == 0 ? s : ((s - p.shift) % p.B + p.B) % p.B;
       ns = role == 0 ? (s + p.shift) % p.B : nd;
