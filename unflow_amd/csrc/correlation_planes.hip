@@ -542,6 +542,7 @@ struct CorrBwdPlParams {
   int off, nA, T;
   int vr, joff;   // narrow-band mode: see CorrPlParams
   unsigned dout_bytes;   // bytes of dout up to its last band entry (0: larger than 1 GiB, dword gathers only)
+  int rot;               // rotated displacement-row order
 };
 
 __device__ __forceinline__ int corr_tr_swz64(int k, int granule) {      // conv_planes.hip tr_swz<64>
@@ -615,13 +616,13 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   // The displacement rows are visited in a rotated order (corr_fwd_nb_kernel): step k of a role takes the row whose feature
   // row R has R / s2 = k (mod 2r+1), so the blocks of neighbouring rows y ask for a feature row in the same step.
   const int yq = (y - (p.s2 - 1) * (y < 0)) / p.s2;
-  const int rot0 = ((p.r - yq) % p.gw + p.gw) % p.gw, rot1 = (yq + p.r) % p.gw;
+  const int rot0 = p.rot ? ((p.r - yq) % p.gw + p.gw) % p.gw : 0, rot1 = p.rot ? (yq + p.r) % p.gw : 0;
   int it_role = role_lo, it_k = -1, it_pi = 0, it_t = p.T;      // advanced before use
   int nd = 0, ns = 0, ysrc = 0, oy = 0, k0 = 0;
   auto next_item = [&]() -> bool {
     for (;;) {
       if (++it_t > p.T) { it_t = -p.T; if (++it_k >= p.gw) { it_k = 0; if (++it_role > role_hi) return false; } }
-      it_pi = it_role == 0 ? (it_k + rot0) % p.gw : ((rot1 - it_k) % p.gw + p.gw) % p.gw;
+      it_pi = !p.rot ? it_k : it_role == 0 ? (it_k + rot0) % p.gw : ((rot1 - it_k) % p.gw + p.gw) % p.gw;
       const int role = it_role;
       nd = role == 0 ? s : ((s - p.shift) % p.B + p.B) % p.B;
       ns = role == 0 ? (s + p.shift) % p.B : nd;
@@ -864,6 +865,10 @@ int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const 
   const int span = max(g.ow, W - p.off);
   const int nq = (span + g.s2 - 1) / g.s2;
   corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
+  // rotated row order: HBM reads 1.4x instead of 2.3x / 3.4x algorithmic at both measured shapes, but only the narrow-band
+  // shape got faster with it (758 -> 740 us); the step's wide-band shape lost 7-16 % standalone (consumers of a row in
+  // lock-step), so it keeps the natural order.  UNFLOW_CORR_BWD_ROT=0/1 forces it (A/B knob, read per call).
+  { const char* e = getenv("UNFLOW_CORR_BWD_ROT"); p.rot = e ? (e[0] != '0') : (p.joff != 0); }
   const size_t dbytes = (((size_t)B * g.oh * g.ow - 1) * (size_t)ld_dout + (size_t)g.gw * g.gw) * 4;
   p.dout_bytes = dbytes < ((size_t)1 << 30) && corr_bwd_b128_enabled() ? (unsigned)dbytes : 0u;
   const int smem = 4 * 3 * 32 * 64 * 2;
