@@ -1515,7 +1515,13 @@ inline int plan_pl_wgrad(const WgradGeom& p, int npl) {
   static const int min_kt = getenv("UNFLOW_WGRAD_MIN_KT") ? max(1, atoi(getenv("UNFLOW_WGRAD_MIN_KT"))) : 8;     // tuning knob
   const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
   const int per_cu = min((160 * 1024) / (npl * (128 + bn) * BK * 2), cfg == 1 ? 4 : 3);
-  return fill_one_round(blocks, 256 * per_cu, max_by_k);
+  // blocks to aim for, in % of the CU count (tuning knob; default: every resident slot).  The partial sums a filter gradient
+  // writes and re-reads are (blocks x tile) bytes whatever the layer — 50 MB at 768 blocks, ~1.5 GB per step — but fewer
+  // blocks lose more than that traffic costs: 587 / 594 / 607 image-pairs/s at 100 / 150 / 200 % against ~620 at 300 %.
+  static const int slots_env = getenv("UNFLOW_WGRAD_SLOTS_PCT") ? atoi(getenv("UNFLOW_WGRAD_SLOTS_PCT")) : 0;
+  static const int slots_pct = slots_env > 0 ? max(25, slots_env) : 0;
+  const int slots = slots_pct ? min(256 * per_cu, 256 * slots_pct / 100) : 256 * per_cu;
+  return fill_one_round(blocks, slots, max_by_k);
 }
 
 inline size_t pl_wgrad_partial_bytes(const WgradGeom& p, int ca_out, int nsplit) {
