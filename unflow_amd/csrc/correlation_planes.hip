@@ -1,14 +1,21 @@
 // FlowNetC cost volume (kernel_size 1, stride_1 1 — flownet.py:221-222; CorrelateData of ops/correlation_op.cu.cc:51-117)
 // on the bf16 matrix cores from the features' operand planes (csrc/conv_planes.hip: x = hi + mid + lo, six product terms,
 // fp32 accumulation — the arithmetic class of correlation_mfma.hip's v_mfma_f32_32x32x2_f32 at 6/16 of its matrix-core
-// time).
+// time).  For output row oy, displacement row p and x-residue class q the 2r+1 correlations of a pixel are a band of the
+// 32x32 Gram matrix G[i][j] = sum_c f0[y, x_i, c] * f1[y + s2 p, x_j, c] (correlation_mfma.hip).
 //
-// For output row oy, displacement row p and x-residue class q the 2r+1 correlations of a pixel are a band of the 32x32 Gram
-// matrix G[i][j] = sum_c f0[y, x_i, c] * f1[y + s2 p, x_j, c] (correlation_mfma.hip).  Here a block owns (sample, row,
-// class, 32-site tile): its f0 tile — 32 pixels x C channels x 3 planes — is loaded ONCE into LDS with coalesced
-// 16-byte loads and serves all 2r+1 displacement rows of the block's four waves (padded rows: conflict-free b128 fragment
-// reads); the f1 fragments stream from L2 as 16-byte loads (8 consecutive channels of one pixel and plane = one MFMA operand
-// granule), four K16 slabs in flight per wave.  The forward f0 traffic drops from (2r+1) fetches per row to one.
+// Forward kernels (corr_pl_fwd picks one):
+//   corr_fwd_wb_kernel  wide band (r > 6, or one site tile per row), C % 64 == 0, C <= 256 — the training step's shape:
+//                       K split over the waves, f1 tiles by LDS-DMA in whole cache lines, two output rows per block.
+//   corr_fwd_nb_kernel  narrow band (r <= 6 over several site tiles: the +-4 / 81-channel cost volume), same limits on C:
+//                       tiles own 32 - 2r sites, one Gram per displacement row.
+//   corr_fwd_pl_kernel  every other C % 16 == 0: the first planes kernel.  A block owns (sample, row, class, 32-site tile): its
+//                       f0 tile — 32 pixels x C channels x 3 planes — is loaded ONCE into LDS with coalesced 16-byte loads and
+//                       serves all 2r+1 displacement rows of the block's four waves (padded rows: conflict-free b128 fragment
+//                       reads); the f1 fragments stream from L2 as 16-byte loads (8 consecutive channels of one pixel and
+//                       plane = one MFMA operand granule), four K16 slabs in flight per wave — 32 cache lines per load
+//                       instruction, which is what bounds it.
+// Backward: corr_bwd_pl_kernel (C % 64 == 0), feature operand from the planes by LDS-DMA + transposing reads.
 #include <cstdlib>
 #include "igemm_shared.h"
 #include "correlation_geom.h"
