@@ -159,6 +159,14 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
 int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const unflow_planes* in1, int shift, float* g0, float* g1,
                 int ld_g, int fuse, int B, int C, int H, int W, const CorrGeom& g, hipStream_t st);
 
+// The plane kernels address a plane through one buffer descriptor with 32-bit byte offsets, and the output with int element
+// offsets: larger tensors take the fp32 kernels (64-bit addressing).
+static bool corr_pl_fits_32bit(const unflow_planes* pl, int B, int H, int W, int ld_out, const CorrGeom& g) {
+  const unsigned long long plane_bytes = (unsigned long long)B * H * W * (unsigned long long)pl->ld * 2ull;
+  const unsigned long long out_elems = (unsigned long long)B * g.oh * g.ow * (unsigned long long)ld_out;
+  return plane_bytes < (1ull << 31) && out_elems < (1ull << 31);
+}
+
 static int corr_status(int H, int W, int k, int md, int pad, int s1, int s2, CorrGeom* g) {
   if (k <= 0 || s1 <= 0 || s2 <= 0 || md < 0 || pad < 0) return UNFLOW_ERR_SHAPE;
   if (k % 2 == 0) return UNFLOW_ERR_EVEN_KERNEL;
@@ -206,7 +214,7 @@ UNFLOW_API int unflow_correlation_nhwc_fwd_pl(const float* in0, const float* in1
   const int st = corr_status(H, W, kernel_size, max_displacement, pad, stride_1, stride_2, &g);
   if (st != UNFLOW_OK) return st;
   if (ld_out < g.oc) return UNFLOW_ERR_SHAPE;
-  if (corr_pl_supported(g, C, in0_pl, in1_pl))
+  if (corr_pl_supported(g, C, in0_pl, in1_pl) && corr_pl_fits_32bit(in0_pl, B, H, W, ld_out, g))
     return corr_pl_fwd(in0_pl, in1_pl, pair_shift, out, ld_out, B, C, H, W, g, as_stream(stream));
   return unflow_correlation_nhwc_fwd(in0, in1, ld_in, pair_shift, out, ld_out, B, C, H, W, kernel_size, max_displacement,
                                      pad, stride_1, stride_2, stream);
@@ -245,7 +253,7 @@ UNFLOW_API int unflow_correlation_nhwc_bwd_pl(const float* dout, int ld_dout, co
   static const bool pl_on = !(getenv("UNFLOW_CORR_BWD_PLANES") && atoi(getenv("UNFLOW_CORR_BWD_PLANES")) == 0) &&
                             !(getenv("UNFLOW_CORR_MATH") && !strcmp(getenv("UNFLOW_CORR_MATH"), "fp32")) &&
                             !(getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32"));
-  if (pl_on && C % 64 == 0 && corr_pl_supported(g, C, in0_pl, in1_pl))
+  if (pl_on && C % 64 == 0 && corr_pl_supported(g, C, in0_pl, in1_pl) && corr_pl_fits_32bit(in0_pl, B, H, W, ld_dout, g))
     return corr_pl_bwd(dout, ld_dout, in0_pl, in1_pl, pair_shift, grad0, grad1, ld_grad, accumulate_g1_into_g0, B, C, H, W, g,
                        as_stream(stream));
   return unflow_correlation_nhwc_bwd(dout, ld_dout, in0, in1, ld_in, pair_shift, grad0, grad1, ld_grad, accumulate_g1_into_g0, B,
