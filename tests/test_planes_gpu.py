@@ -297,6 +297,8 @@ CORR_PL_CASES = [
     (2, 48, 5, 100, dict(kernel_size=1, max_displacement=6, pad=6, stride_1=1, stride_2=1)),      # r = 6: 20 owned sites
     (2, 32, 7, 101, dict(kernel_size=1, max_displacement=8, pad=8, stride_1=1, stride_2=2)),      # r = 4 in two classes
     (2, 32, 6, 90, dict(kernel_size=1, max_displacement=2, pad=4, stride_1=1, stride_2=1)),       # pad > displacement
+    (2, 256, 6, 70, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),      # 4 waves (K split), 3 tiles
+    (2, 128, 5, 60, dict(kernel_size=1, max_displacement=6, pad=6, stride_1=1, stride_2=1)),      # 2 waves, r = 6
     # wide band by DMA (C % 64 == 0): row pairs, neighbour column tiles inside / outside the image, odd row counts
     (2, 128, 11, 150, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),  # 3 tiles per class
     (2, 128, 7, 80, dict(kernel_size=1, max_displacement=10, pad=10, stride_1=1, stride_2=1)),    # r = 10 at stride_2 = 1
