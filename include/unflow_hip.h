@@ -15,7 +15,9 @@
  *  - The caller allocates every output and workspace; the library never
  *    allocates, frees or synchronises (TF's allocate_output replaced by
  *    caller-owned buffers).  Every entry takes a hipStream_t (as void*) and is
- *    fully asynchronous and re-entrant (no globals).
+ *    fully asynchronous and re-entrant.  The only process-wide state is the
+ *    option table below (kernel selection / planning switches), written solely
+ *    through unflow_set_option; the library never reads the environment.
  *  - Return value: 0 on success, a negative UNFLOW_ERR_* otherwise; on error
  *    nothing is launched (mirrors OP_REQUIRES -> InvalidArgument).
  *  - Layouts at the op boundary are the reference's: correlation NCHW
@@ -35,6 +37,7 @@ extern "C" {
 #endif
 
 typedef void* unflow_stream_t; /* hipStream_t */
+typedef struct unflow_planes unflow_planes; /* 16-bit operand planes of a tensor (defined with the conv entry points) */
 
 #define UNFLOW_OK 0
 #define UNFLOW_ERR_NULL (-1)          /* null pointer argument                                   */
@@ -48,6 +51,15 @@ typedef void* unflow_stream_t; /* hipStream_t */
 
 const char* unflow_status_string(int status);
 int unflow_version(void);
+
+/* Library options (csrc/options.h lists them with their defaults): integer switches that select kernels and split
+ * planning — e.g. "conv_math_fp32", "halo", "wgrad_kgroups".  They replace what the reference fixes at build time
+ * through its JIT compile flags (src/e2eflow/ops.py:21-48); set them once after loading the library, before the first
+ * launch (a later change applies to the launches planned after it).  UNFLOW_ERR_UNSUPPORTED: no such option.
+ * unflow_option_names: the names, '\n'-separated. */
+int unflow_set_option(const char* name, int value);
+int unflow_get_option(const char* name, int* value);
+const char* unflow_option_names(void);
 
 /* ===================================================================== */
 /* Correlation — replaces Correlation()/CorrelationGrad()                 */
@@ -293,6 +305,19 @@ int unflow_gradient_loss_bwd(const float* gdiff, float* d_im2_warped, int N, int
  * loss image: out01[n,y,x,0:3] = im/255 (unsupervised.py:29-32,69-70). out01 may be NULL. */
 int unflow_prepare_images(const float* im_u8range, float* net_in4, float* out01, const float* mean3, long npix,
                           unflow_stream_t stream);
+
+/* Both frames in one launch: im1 -> samples [0, B), im2 -> samples [B, 2B) of the directed batch (npix_each = B*H*W each);
+ * net_pl (may be NULL): also the 16-bit operand planes of net_in4 (row length net_pl->ld = 4 or 8). */
+int unflow_prepare_image_pair(const float* im1, const float* im2, long npix_each, float* net_in4, float* out01,
+                              const float* mean3, const unflow_planes* net_pl, unflow_stream_t stream);
+
+/* Elementwise helpers of the step driver (what the TF graph does with tf.multiply / tf.add_n / tf.zeros between ops):
+ * y = s*x; y *= x; y += x (n floats); stream-ordered zero fill and device-to-device copy. */
+int unflow_scale(const float* x, float s, float* y, long n, unflow_stream_t stream);
+int unflow_mul_inplace(float* y, const float* x, long n, unflow_stream_t stream);
+int unflow_add_inplace(float* y, const float* x, long n, unflow_stream_t stream);
+int unflow_zero(void* p, size_t bytes, unflow_stream_t stream);
+int unflow_copy(void* dst, const void* src, size_t bytes, unflow_stream_t stream);
 
 /* ---- augmentation ---------------------------------------------------------------------- */
 

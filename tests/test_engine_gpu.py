@@ -470,3 +470,38 @@ def test_filter_gradients_on_second_stream_bit_identical(dev):
                     bad.append(l.name)
             assert not bad, (group, graph, bad)
     assert torch.equal(got[eng.n_weights:], ref[eng.n_weights:])         # bias gradients too
+
+
+@pytest.mark.parametrize("unique_ws", [False, True])
+def test_two_branch_backward_graph_100_replays_bit_identical(unique_ws, dev):
+    """Stress form of the bit-identity check: ONE captured two-branch step graph (data gradients on the main
+    stream, filter gradients in groups on the second one) replayed 100 times — every replay must reproduce every parameter
+    gradient bit for bit.  Round 2 traced a ~10 %-of-replays wrong sum in the 2 -> 2 filter gradient to a compiler-formed
+    packed-fp32 instruction (unflow_amd/build.py); unique_ws additionally gives every deferred filter gradient its own
+    split-K scratch, so a scratch slot shared between the streams would show up as a difference between the two runs."""
+    from parity_util import images
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 2, 256, 320
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
+    eng.init_params(seed=11)
+    eng.wgrad_unique_ws = unique_ws
+    im1, im2 = images(B, H, W, 78)
+    eng.set_input(im1.to(dev), im2.to(dev))
+    eng.fwd_bwd()                                # eager: grows the workspaces
+    torch.cuda.synchronize()
+    ref_eager = eng.G.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.fwd_bwd()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.fwd_bwd()
+    bad = 0
+    for _ in range(100):
+        eng.G.zero_()
+        g.replay()
+        bad += int(not torch.equal(eng.G, ref_eager))
+    torch.cuda.synchronize()
+    assert bad == 0, "%d of 100 replays differ" % bad

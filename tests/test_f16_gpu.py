@@ -11,6 +11,8 @@ from parity_util import images, oracle_step
 
 pytestmark = pytest.mark.gpu
 
+F16_TENSOR_TOL = 3e-2     # stated: per-tensor gradient error of the fp16-operand mode vs the fp32 oracle, max-normalised
+
 
 @pytest.mark.parametrize("shape", [(1, 128, 192), (2, 384, 512)])
 def test_f16_step_vs_fp32_oracle(shape, dev, monkeypatch):
@@ -35,6 +37,18 @@ def test_f16_step_vs_fp32_oracle(shape, dev, monkeypatch):
     print("f16 %s: loss rel %.2e, EPE fw %.2e bw %.2e px, gradient cosine %.6f" % (shape, e_loss, e_fw, e_bw, cos))
     assert e_loss <= 1e-2 and e_fw <= 5e-2 and e_bw <= 5e-2
     assert cos > 0.99
+    # per tensor (a cosine over the flat gradient says nothing about a small tensor): max |d| / max |ref| of every tensor with
+    # >= 1024 elements within F16_TENSOR_TOL, the 2-channel flow heads / biases within 3x that
+    rows = []
+    for k in grads:
+        ref = grads[k].double() - (0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0)
+        d = (got[k].double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        rows.append((d, k, ref.numel()))
+    rows.sort(reverse=True)
+    for d, k, n in rows[:8]:
+        print("   f16 gradient %-48s n=%-9d max-rel %.2e" % (k, n, d))
+    bad = [(k, d) for d, k, n in rows if d > (F16_TENSOR_TOL if n >= 1024 else 3 * F16_TENSOR_TOL)]
+    assert not bad, bad
 
 
 def test_f16_training_tracks_fp32(dev, monkeypatch):

@@ -74,6 +74,27 @@ def test_flownetc_b4_384x512_loss_and_flows_vs_oracle(dev):
     print("B=4 384x512 (bench inputs): loss %.4f oracle %.4f rel %.2e" % (loss, loss_ref, abs(loss - loss_ref) / abs(loss_ref)))
 
 
+def test_flownetc_b4_384x512_gradients_vs_fp64_oracle(dev):
+    """The benchmark batch, every parameter gradient: B = 4 with bench.py's weights and images against
+    the fp64 oracle differentiated along the engine's leaky-ReLU branches (parity_util.BranchAligned; the plain oracle
+    differs only at the handful of units within fp32 noise of the kink, asserted at B = 1 / 2 above)."""
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 4, 384, 512
+    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
+    tf_params = eng.init_params(seed=0)
+    g = torch.Generator().manual_seed(1234)
+    im1 = torch.rand(B, H, W, 3, generator=g) * 255
+    im2 = torch.rand(B, H, W, 3, generator=g) * 255
+    loss = graph_step(eng, im1.to(dev), im2.to(dev))
+    got = eng.export_tf_grads()
+    with BranchAligned(eng.act, flownet_c_order(B)) as al:
+        loss_ref, _, _, grads_al = oracle_step(tf_params, im1, im2, dtype=torch.float64)
+    assert abs(loss - loss_ref) <= 1e-4 * abs(loss_ref), (loss, loss_ref)
+    worst = check_grads(got, grads_al, tf_params, max_tol=2e-4, mean_tol=2e-4, label="B=4 branch-aligned fp64 oracle:")
+    print("B=4 384x512 gradients: %d of %d leaky units flipped in fp64; worst max-rel %.2e mean-rel %.2e"
+          % (al.flips, al.units, worst[0], worst[1]))
+
+
 def test_flownet_css_768x1024_vs_oracle(dev):
     """BASELINE configs[3]: C -> S -> S at 768x1024 (B = 1 keeps the CPU oracle within minutes)."""
     from unflow_amd.core.engine import FlowNetEngine, flow_error_avg, FLOW_SCALE
@@ -184,6 +205,75 @@ def test_correlation_step_shape_b4_vs_oracle(dev, oracle_lib):
     want = g0 + np.roll(g1, B, axis=0)                                 # g1[n] is the gradient of sample (n + B) % N
     gotg = gfeat.permute(0, 3, 1, 2).cpu().numpy()
     assert np.abs(gotg - want).max() <= 2e-4 * np.abs(want).max()
+
+
+def _corr_bwd_pl_vs_oracle(dev, oracle_lib, B, C, h, w, md, s2, ld_cat, lo, rot=None):
+    """unflow_correlation_nhwc_bwd_pl WITH planes — the entry point and kernel the step runs (engine.py backward: corr_bwd_pl_kernel,
+    feature operand by LDS-DMA from the bf16 planes) — against the scalar C oracle (correlation_op.cu.cc:119-248): dOut read
+    from channels [lo, lo + oc) of an ld_cat-wide buffer, gradient buffer pre-filled (must be overwritten), both roles of every
+    sample fused with the step's pairing n <-> (n + B) % N."""
+    import ctypes
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, ptr, stream
+    from unflow_amd.core import layers as L
+    N = 2 * B
+    rs = np.random.RandomState(1000 + C + h + md)
+    feat = rs.randn(N, h, w, C).astype(np.float32)
+    F = L.PT.alloc((N, h, w, C), dev, 3)
+    F.t.copy_(torch.from_numpy(feat))
+    L.planes_from_f32(F.t, F.pl)
+    o3 = (ctypes.c_int * 3)()
+    assert _lib.lib().unflow_correlation_out_shape(h, w, 1, md, md, 1, s2, o3) == 0
+    oc, oh, ow = tuple(o3)
+    a_nchw = np.ascontiguousarray(feat.transpose(0, 3, 1, 2))
+    b_nchw = np.ascontiguousarray(np.roll(a_nchw, -B, axis=0))
+    attrs = dict(pad=md, kernel_size=1, max_displacement=md, stride_1=1, stride_2=s2)
+    go = rs.randn(N, oc, oh, ow).astype(np.float32)
+    gcat = torch.zeros(N, oh, ow, ld_cat, device=dev)
+    gcat[..., lo:lo + oc] = torch.from_numpy(go).to(dev).permute(0, 2, 3, 1)
+    g0, g1 = oracle_lib.correlation_grad(go, a_nchw, b_nchw, **attrs)
+    want = g0 + np.roll(g1, B, axis=0)
+    saved = _lib.get_option("corr_bwd_rot")
+    try:
+        if rot is not None:
+            _lib.set_option("corr_bwd_rot", rot)
+        gfeat = torch.full((N, h, w, C), 7.0, device=dev)
+        pl = _lib.planes_of(F.pl)
+        check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(gcat[..., lo:lo + oc]), ld_cat, ptr(F.t), ptr(F.t), C, pl, pl, B,
+                                                        ptr(gfeat), ptr(None), C, 1, N, C, h, w, 1, md, md, 1, s2, stream()),
+              "correlation_bwd_pl")
+    finally:
+        _lib.set_option("corr_bwd_rot", saved)
+    gotg = gfeat.permute(0, 3, 1, 2).cpu().numpy()
+    err = np.abs(gotg - want).max() / np.abs(want).max()
+    assert err <= 2e-4, err
+    return err
+
+
+def test_correlation_bwd_planes_step_shape_vs_oracle(dev, oracle_lib):
+    """The step's correlation backward at the step's shape: N = 8 directed samples of 256 x 48 x 64, dOut in channels 32..473 of
+    the 476-wide concat gradient."""
+    _corr_bwd_pl_vs_oracle(dev, oracle_lib, 4, 256, 48, 64, 20, 2, 476, 32)
+
+
+@pytest.mark.parametrize("rot", [0, 1])
+def test_correlation_bwd_planes_step_shape_row_orders(rot, dev, oracle_lib):
+    """Both displacement-row orders of corr_bwd_pl_kernel (option corr_bwd_rot) at half the step's batch."""
+    _corr_bwd_pl_vs_oracle(dev, oracle_lib, 2, 256, 48, 64, 20, 2, 476, 32, rot=rot)
+
+
+def test_correlation_bwd_planes_c96_vs_oracle(dev, oracle_lib):
+    """The 3/8-width nets' correlation (C = 96: flownet.py:22-23) through the same entry point."""
+    _corr_bwd_pl_vs_oracle(dev, oracle_lib, 2, 96, 24, 32, 20, 2, 476, 12)
+
+
+@pytest.mark.parametrize("rot", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 64, 20, 131, 4, 1), (2, 128, 12, 100, 6, 1)])
+def test_correlation_bwd_planes_narrow_band_vs_oracle(shape, rot, dev, oracle_lib):
+    """Narrow-band tiling (the north star's +-4 cost volume: 81 channels; and r = 6) in both row orders."""
+    B, C, h, w, md, s2 = shape
+    oc = (2 * (md // s2) + 1) ** 2
+    _corr_bwd_pl_vs_oracle(dev, oracle_lib, B, C, h, w, md, s2, oc + 3, 3, rot=rot)
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "fp32"])

@@ -365,27 +365,105 @@ def _splitk_outputs(case, dev, reps):
     return outs
 
 
+@pytest.fixture
+def lib_option():
+    """Set library options (csrc/options.h) for one test; restored afterwards."""
+    from unflow_amd import _lib
+    saved = {}
+
+    def setter(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+    yield setter
+    for k, v in saved.items():
+        _lib.set_option(k, v)
+
+
 @pytest.mark.parametrize("case", SPLITK_CASES)
-def test_fused_splitk_bit_identical_to_reduce_kernel(case, dev, tmp_path):
-    """The optional in-kernel split-K reduction (UNFLOW_FUSED_SPLITK=n: the last-arriving block of a tile sums the partial
+def test_fused_splitk_bit_identical_to_reduce_kernel(case, dev, lib_option):
+    """The optional in-kernel split-K reduction (option fused_splitk = n: the last-arriving block of a tile sums the partial
     tiles in slice order; write-through partial stores, relaxed agent-scope ticket, sc1 loads) is bit-identical to the default
-    fixed-order reduce kernel and stable over 20 back-to-back launches whatever the arrival order.  The knob is read once
-    per process, so the fused run is a sub-process."""
-    import os
-    import subprocess
-    import sys
+    fixed-order reduce kernel and stable over 20 back-to-back launches whatever the arrival order."""
     ref = _splitk_outputs(case, dev, 1)[0]
-    f = str(tmp_path / "fused.pt")
-    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_planes_gpu as T; "
-            "o = T._splitk_outputs(%r, torch.device('cuda:0'), 20); "
-            "assert all(torch.equal(a, b) for q in o[1:] for a, b in zip(q, o[0])), 'fused split-K not stable run to run'; "
-            "torch.save(o[0], %r)"
-            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), case, f))
-    env = dict(os.environ, UNFLOW_FUSED_SPLITK="16")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    y0, dx0, pl0 = torch.load(f)
+    lib_option("fused_splitk", 16)
+    o = _splitk_outputs(case, dev, 20)
+    assert all(torch.equal(a, b) for q in o[1:] for a, b in zip(q, o[0])), "fused split-K not stable run to run"
+    y0, dx0, pl0 = o[0]
     assert torch.equal(y0, ref[0]) and torch.equal(dx0, ref[1]) and torch.equal(pl0, ref[2])
+
+
+def test_library_options_roundtrip(dev):
+    """unflow_set_option / unflow_get_option: every name of unflow_option_names round-trips; unknown names are refused."""
+    from unflow_amd import _lib
+    names = _lib.option_names()
+    assert "conv_math_fp32" in names and "wgrad_kgroups" in names
+    for n in names:
+        v = _lib.get_option(n)
+        _lib.set_option(n, v)
+        assert _lib.get_option(n) == v
+    assert _lib.lib().unflow_set_option(b"no_such_option", 1) == -7
+
+
+# (B, H, W, Cin, Cout, k, stride, deconv): filter gradients whose plan uses the 768-thread K-group workgroups
+KGROUP_CASES = [
+    (8, 96, 128, 128, 256, 5, 2, False),   # conv3: 50 tiles, 5 splits x 3 K groups
+    (8, 48, 64, 476, 256, 3, 1, False),    # conv3_1: 68 tiles (last M tile 96 of 128 rows), 3 splits
+    (8, 192, 256, 64, 128, 5, 2, False),   # conv2: 13 tiles, 19 splits
+    (8, 48, 64, 388, 64, 4, 2, True),      # deconv2: N = 388 (4 real columns in the last N tile), BN = 128
+    (2, 40, 56, 72, 40, 3, 1, False),      # ragged everything, 128 x 64 tiles
+]
+
+
+@pytest.mark.parametrize("case", KGROUP_CASES)
+def test_wgrad_kgroups_vs_fp64(case, dev, lib_option):
+    """Filter gradients through the K-group workgroups (option wgrad_kgroups, three 4-wave groups combined through LDS)
+    and through the one-group kernel, with and without sub-tile skipping (option ntail_skip): each against an fp64
+    torch reference; repeated launches bit-identical."""
+    from unflow_amd.core import layers as L
+    import torch.nn.functional as F
+    B, H, W, Cin, Cout, k, stride, deconv = case
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    if deconv:       # conv_transpose [B,H/2,W/2,Cin] -> [B,H,W,Cout]; dW [4,4,Cout,Cin]
+        x = torch.randn(B, H // 2, W // 2, Cin, generator=g)
+        dz = torch.randn(B, H, W, Cout, generator=g)
+        xd, dzd = x.double().permute(0, 3, 1, 2), dz.double().permute(0, 3, 1, 2)
+        wz = torch.zeros(Cin, Cout, 4, 4, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose2d(xd, wz, stride=2, padding=1)
+        (y * dzd).sum().backward()
+        ref = wz.grad.permute(2, 3, 1, 0).contiguous()           # [4,4,Cout,Cin]
+        dw_shape = (4, 4, Cout, Cin)
+    else:
+        x = torch.randn(B, H, W, Cin, generator=g)
+        Ho, Wo = L.out_hw(H, W, stride)
+        dz = torch.randn(B, Ho, Wo, Cout, generator=g)
+        pt_, pl_ = ((Ho - 1) * stride + k - H), ((Wo - 1) * stride + k - W)
+        pt_, pl_ = max(pt_, 0), max(pl_, 0)
+        xp = F.pad(x.double().permute(0, 3, 1, 2), (pl_ // 2, pl_ - pl_ // 2, pt_ // 2, pt_ - pt_ // 2))
+        wz = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xp, wz, stride=stride)
+        (y * dz.double().permute(0, 3, 1, 2)).sum().backward()
+        ref = wz.grad.permute(2, 3, 1, 0).contiguous()           # HWIO
+        dw_shape = (k, k, Cin, Cout)
+    X, DZ = make_pt(x, dev, 3), make_pt(dz, dev, 3)
+    results = {}
+    for kg, skip in ((1, 1), (1, 0), (0, 1)):
+        lib_option("wgrad_kgroups", kg)
+        lib_option("wgrad_kg_min_fill", 1)
+        lib_option("ntail_skip", skip)
+        outs = []
+        for _ in range(3):
+            dw = torch.full(dw_shape, float('nan'), device=dev)
+            if deconv:
+                L.deconv_bwd_filter(X, DZ, dw)
+            else:
+                L.conv_bwd_filter(X, DZ, dw, stride)
+            outs.append(dw.cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, (kg, skip, err)
+        results[(kg, skip)] = outs[0]
+    assert torch.equal(results[(1, 1)], results[(1, 0)])        # skipping a sub-tile changes no value
 
 
 @pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1),

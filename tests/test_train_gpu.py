@@ -20,7 +20,7 @@ _NCCL_CHILD = r'''
 import os, sys, torch
 sys.path.insert(0, %r)
 import torch.distributed as dist
-from unflow_amd.core.engine import FlowNetCEngine
+from unflow_amd.core.engine import FlowNetEngine, DEFAULT_PARAMS
 from unflow_amd.core.train import StepRunner
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
@@ -29,20 +29,23 @@ assert dist.get_world_size() == 1
 B, H, W = 2, 128, 192
 g = torch.Generator().manual_seed(3)
 batches = [((torch.rand(B, H, W, 3, generator=g) * 255).to(dev), (torch.rand(B, H, W, 3, generator=g) * 255).to(dev)) for _ in range(3)]
-res = []
-for force in (False, True):
-    eng = FlowNetCEngine(B, H, W, device=dev, seed=7)
-    run = StepRunner(eng, 1, use_graph=True, force_reducer=force)
-    assert run.nparts == (3 if force else 1)
-    losses = []
-    for i in range(4):
-        losses.append(run.step(*batches[i %% 3], 1e-4).item())
-    torch.cuda.synchronize()
-    res.append((eng.P.clone(), eng.M.clone(), eng.V.clone(), losses))
-(p0, m0, v0, l0), (p1, m1, v1, l1) = res
-assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), "bucketed path differs"
-assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
-assert l0[-1] != l0[0]
+# 'CS': a frozen first network (flownet.py:51-54) whose L2-only update must not race with its forward pass (ADVICE r2)
+for spec in ('C', 'CS'):
+    res = []
+    for force in (False, True):
+        eng = FlowNetEngine(B, H, W, params=dict(DEFAULT_PARAMS, flownet=spec), device=dev, seed=7)
+        run = StepRunner(eng, 1, use_graph=True, force_reducer=force)
+        assert run.nparts == (3 if force else 1)
+        assert bool(run.frozen) == (spec == 'CS')
+        losses = []
+        for i in range(4):
+            losses.append(run.step(*batches[i %% 3], 1e-4).item())
+        torch.cuda.synchronize()
+        res.append((eng.P.clone(), eng.M.clone(), eng.V.clone(), losses))
+    (p0, m0, v0, l0), (p1, m1, v1, l1) = res
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), "bucketed path differs (%%s)" %% spec
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (spec, l0, l1)
+    assert l0[-1] != l0[0]
 dist.barrier(); dist.destroy_process_group()
 print("NCCL_WORLD1_OK", l0)
 '''

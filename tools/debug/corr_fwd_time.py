@@ -1,4 +1,4 @@
-"""Times the step's forward correlation (441 channels, 8 x 48 x 64 x 256) — one JSON line; A/B with UNFLOW_CORR_WB=0."""
+"""Times the step's forward correlation (441 channels, 8 x 48 x 64 x 256) — one JSON line; A/B with UNFLOW_OPT_CORR_WB=0."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -21,4 +21,4 @@ for _ in range(30):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
 ts.sort()
-print(json.dumps({"wb": os.environ.get("UNFLOW_CORR_WB", "1"), "us": round(ts[15] * 1e3, 1)}))
+print(json.dumps({"wb": os.environ.get("UNFLOW_OPT_CORR_WB", "1"), "us": round(ts[15] * 1e3, 1)}))

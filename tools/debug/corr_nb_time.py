@@ -1,4 +1,4 @@
-"""Times the narrow-band forward correlation (81 channels, 16 x 96 x 128 x 256) — one JSON line; A/B with UNFLOW_CORR_NB=0."""
+"""Times the narrow-band forward correlation (81 channels, 16 x 96 x 128 x 256) — one JSON line; A/B with UNFLOW_OPT_CORR_NB=0."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -22,4 +22,4 @@ for _ in range(20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
 ts.sort()
-print(json.dumps({"nb": os.environ.get("UNFLOW_CORR_NB", "1"), "us": round(ts[10] * 1e3, 1)}))
+print(json.dumps({"nb": os.environ.get("UNFLOW_OPT_CORR_NB", "1"), "us": round(ts[10] * 1e3, 1)}))

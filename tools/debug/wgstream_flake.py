@@ -12,7 +12,6 @@ im1, im2 = im1.to(dev), im2.to(dev)
 side = torch.cuda.Stream(dev)
 def run(group, graph):
     eng.wgrad_group, eng.wgrad_stream = group, (side if group > 0 else None)
-    eng.wgrad_inline_tiny = os.environ.get('UNFLOW_WGRAD_INLINE_TINY', '0') != '0'
     if graph:
         graph_step(eng, im1, im2)
     else:

@@ -43,7 +43,43 @@ def lib():
         _lib.unflow_conv_workspace_bytes.restype = ctypes.c_size_t
         _lib.unflow_conv_pl_workspace_bytes.restype = ctypes.c_size_t
         _lib.unflow_weight_planes_elems.restype = ctypes.c_size_t
+        _lib.unflow_option_names.restype = ctypes.c_char_p
+        _apply_env_options(_lib)
     return _lib
+
+
+def option_names():
+    return [n for n in lib().unflow_option_names().decode().split("\n") if n]
+
+
+def set_option(name, value):
+    """unflow_set_option (csrc/options.h): kernel-selection / split-planning switches of the library.  The library never
+    reads the environment; this and _apply_env_options below are the only writers."""
+    check(lib().unflow_set_option(name.encode(), int(value)), "set_option(%s)" % name)
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(lib().unflow_get_option(name.encode(), ctypes.byref(v)), "get_option(%s)" % name)
+    return v.value
+
+
+def _apply_env_options(L):
+    """Host-side bridge from the process environment to the library's option table, applied once at load time:
+    UNFLOW_CONV_MATH / UNFLOW_WGRAD_MATH / UNFLOW_CORR_MATH = fp32 select the fp32-MFMA kernels (core/engine.py reads
+    UNFLOW_CONV_MATH too, for the operand-plane layout), and UNFLOW_OPT_<NAME>=<int> sets any option of csrc/options.h
+    (A/B runs of tools/ and profiles/)."""
+    if os.environ.get("UNFLOW_CONV_MATH") == "fp32":
+        L.unflow_set_option(b"conv_math_fp32", 1)
+    if os.environ.get("UNFLOW_WGRAD_MATH") == "fp32":
+        L.unflow_set_option(b"wgrad_math_fp32", 1)
+    if os.environ.get("UNFLOW_CORR_MATH") == "fp32":
+        L.unflow_set_option(b"corr_math_fp32", 1)
+    for name in L.unflow_option_names().decode().split("\n"):
+        v = os.environ.get("UNFLOW_OPT_" + name.upper()) if name else None
+        if v is not None:
+            if L.unflow_set_option(name.encode(), int(v)) != 0:
+                raise RuntimeError("unflow_set_option(%s) failed" % name)
 
 
 def check(status, where=""):

@@ -8,16 +8,18 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libunflow_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -fno-slp-vectorize: no compiler-formed packed-fp32 instructions (v_pk_mul/add/fma_f32).  hipcc (ROCm 7.2) allocates some of
-# them with the destination pair overlapping a source pair that another half reads through op_sel, e.g.
+# -fno-slp-vectorize -fno-vectorize: NO compiler-formed packed-fp32 instructions (v_pk_mul/add/fma_f32) anywhere in the
+# code object (checked: `llvm-objdump -d | grep -c "v_pk_.*_f32"` = 0; with only the SLP vectoriser off the loop vectoriser
+# still left 98 of them in the warp / augmentation / resize kernels).  hipcc (ROCm 7.2) allocates some of them with the
+# destination pair overlapping a source pair that another half reads through op_sel, e.g.
 #   v_pk_mul_f32 v[80:81], v[74:75], v[80:81] op_sel:[0,1]      (lo = v74 * v81, hi = v75 * v81 -> v81)
 # and on gfx950 the LOW half of exactly that instruction came out wrong in ~10 % of the replays of the two-branch backward
 # graph — only while a kernel of the other branch shared the SIMD, never alone, never eagerly; the inputs were verified
-# intact after the replay (tools/debug/wgstream_flake.py: 13 wrong sums in 120 replays with packed ops, 0 in 100 without).
-# The packed forms buy nothing here (the step is 0.6 % FASTER without them: they are an anti-lever beside MFMAs,
-# MI355X_MICROARCH.md).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function"]
+# intact after the replay (tools/debug/wgstream_flake.py: 13 wrong sums in 120 replays with packed ops, 0 in 100 without;
+# the stress test stays in the GPU suite: tests/test_engine_gpu.py).  The packed forms buy nothing here (the step is 0.6 %
+# FASTER without them: they are an anti-lever beside MFMAs, MI355X_MICROARCH.md).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def sources():

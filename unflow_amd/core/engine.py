@@ -65,7 +65,7 @@ def conv_math_mode():
     return m
 
 
-RGB4_FORM = os.environ.get('UNFLOW_RGB4', '1') != '0'     # A/B knob: two-pixel K granules for FlowNetC's first layer
+RGB4_FORM = True     # two-pixel K granules for FlowNetC's first layer (csrc/conv_planes.hip rgb4_form)
 
 
 class Layer:
@@ -480,7 +480,7 @@ class FlowNetEngine:
         self.wgrad_unique_ws = False      # debug: one scratch buffer per deferred filter gradient
         # True: the Cout = 2 layers' filter gradients (flow heads, 2 -> 2 upsamplers: small latency-bound kernels) stay on the main
         # stream; False (default): they join the groups on the second stream like every other filter gradient
-        self.wgrad_inline_tiny = os.environ.get('UNFLOW_WGRAD_INLINE_TINY', '0') != '0'
+        self.wgrad_inline_tiny = False
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
         if layout_only:
             self.n_planes = 0
@@ -500,7 +500,7 @@ class FlowNetEngine:
         self.step_count = 0
         self._bias_jobs, self._bias_plan = [], None
         self.defer_l2 = False      # True: forward_loss leaves the L2 term to adam_step (train_step / bench)
-        self.fused_pyramid = os.environ.get('UNFLOW_FUSED_PYRAMID', '1') != '0'   # default loss terms: 4 launches for all levels
+        self.fused_pyramid = True         # default loss terms: 4 launches for all levels
         self._pyr_cache = None
         self._wplanes_version = None
         if seed is not None and not layout_only:
@@ -673,7 +673,6 @@ class FlowNetEngine:
                                 flow=last.act['flow%d' % lvl], gflow=last.grad['flow%d' % lvl],
                                 fs=self.final_flow_scale / (2 ** i), lw=self.layer_weights[i], pd=self.patch_distances[i]))
         self.loss_acc = z(1)
-        self.raw = z(N, H, W, 3)
         self.final_flow = z(N, H, W, 2)
         self.mean_host = (_lib.ctypes.c_float * 3)(*CHANNEL_MEAN)
         self.epe_out = z(2)
@@ -710,38 +709,41 @@ class FlowNetEngine:
         B, N, H, W = self.B, self.N, self.H, self.W
         lib = _lib.lib()
         st = self.stream()
-        self.raw[:B].copy_(im1)
-        self.raw[B:].copy_(im2)
+        assert im1.is_contiguous() and im2.is_contiguous() and im1.dtype == torch.float32 and im2.dtype == torch.float32
+        assert tuple(im1.shape) == (B, H, W, 3) and tuple(im2.shape) == (B, H, W, 3)
         if augment is None:
-            check(lib.unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(self.im01),
-                                            self.mean_host, cl(N * H * W), st), "prepare_images")
+            # one launch: both frames -> mean-free network input (+ its operand planes for conv1 of a FlowNetC) and the [0,1]
+            # images of the losses
+            pl = self.X0.pl if (self.X0.pl is not None and self.stages[0].is_c) else None
+            check(lib.unflow_prepare_image_pair(ptr(im1), ptr(im2), cl(B * H * W), ptr(self.x0), ptr(self.im01),
+                                                self.mean_host, _lib.planes_of(pl), st), "prepare_image_pair")
             if self._mask_aug:
                 for lv in self.lv:
-                    lv['mask'].copy_(lv['mask_static'].expand(B, -1, -1))
+                    for b in range(B):
+                        check(lib.unflow_copy(ptr(lv['mask'][b]), ptr(lv['mask_static']), _lib.csz(lv['h'] * lv['w'] * 4), st), "copy")
                 self._mask_aug = False
-            self._input_planes()
             return
         from . import augment as A
         if self._aug is None:
             z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
             self._aug = dict(tmp=z(N, H, W, 3), mg=z(B, H, W, 1), ml=z(B, H, W, 1))
         a = self._aug
-        check(lib.unflow_prepare_images(ptr(self.raw), ptr(self.x0), ptr(a['tmp']), self.mean_host, cl(N * H * W),
-                                        st), "prepare_images")
+        check(lib.unflow_prepare_image_pair(ptr(im1), ptr(im2), cl(B * H * W), ptr(self.x0), ptr(a['tmp']), self.mean_host,
+                                            None, st), "prepare_image_pair")
         tg, tl = augment['theta_global'], augment['theta_local']
         A.transformer(a['tmp'], tg, out=self.im01, n_samples=N)            # im1_geo, first pass of im2 (:40-44)
         A.transformer(self.im01[B:], tl, out=a['tmp'][B:], n_samples=B)    # im2 locally (:47-50)
-        self.im01[B:].copy_(a['tmp'][B:])
+        check(lib.unflow_copy(ptr(self.im01[B:]), ptr(a['tmp'][B:]), _lib.csz(B * H * W * 3 * 4), st), "copy")
         if self.params.get('border_mask'):
             A.transformer(self.border0, tg, out=a['mg'], n_samples=B)
             A.transformer(self.border0, tl, out=a['ml'], n_samples=B)
-            a['mg'].mul_(a['ml'])                                          # border_mask_local * global (:51)
+            check(lib.unflow_mul_inplace(ptr(a['mg']), ptr(a['ml']), cl(B * H * W), st), "mul")    # border_mask_local * global (:51)
             from .. import ops
             cur = a['mg']
             for lv, sc in zip(self.lv, self._image_and_mask_pyramid_scales()):
                 if sc != 1:
                     cur = ops.downsample(cur, sc)
-                lv['mask'].copy_(cur.view(B, lv['h'], lv['w']))
+                check(lib.unflow_copy(ptr(lv['mask']), ptr(cur), _lib.csz(B * lv['h'] * lv['w'] * 4), st), "copy")
             self._mask_aug = True
         A.photometric(self.im01, augment, out=self.x0, mean=CHANNEL_MEAN)  # im*_photo - channel_mean (:53-57,67-68)
         self._input_planes()
@@ -770,7 +772,7 @@ class FlowNetEngine:
         N, B = self.N, self.B
         P = self.params
         wt = lambda k: float(P.get(k + '_weight') or 0.0)
-        self.loss_acc.zero_()
+        check(lib.unflow_zero(ptr(self.loss_acc), _lib.csz(4), st), "zero")
         occl = {'': 0, None: 0, 'fb': 1, 'disocc': 2}[P.get('mask_occlusion', '')]
         use_border = bool(P.get('border_mask'))
         levels = self.lv if P.get('pyramid_loss') else self.lv[:1]
@@ -810,7 +812,7 @@ class FlowNetEngine:
                 check(lib.unflow_smooth_1st_fwd_bwd(ptr(flow), cf(fs), ptr(self.loss_acc), gf, acc(),
                                                     cf(lw * wt('smooth_1st')), cf(n1 * 2), N, h, w, st), "smooth_1st")
             if with_grad and not wrote[0]:
-                gflow.zero_()
+                check(lib.unflow_zero(ptr(gflow), _lib.csz(gflow.numel() * 4), st), "zero")
                 wrote[0] = True
             # ---- masks, fb / occ / sym
             mask, n_mask = lv['mask'], lv['n_mask']
@@ -822,7 +824,7 @@ class FlowNetEngine:
                     check(lib.unflow_image_warp_fwd(ptr(flow), 2, ptr(flow), cf(fs), ptr(warped), ptr(None), B, N, h, w,
                                                     2, st), "image_warp(flow)")
                 if need_fwarp:      # forward_warp(flow*scale) (losses.py:28-29), deterministic accumulation
-                    torch.mul(flow, fs, out=lv['fscaled'])
+                    check(lib.unflow_scale(ptr(flow), cf(fs), ptr(lv['fscaled']), cl(flow.numel()), st), "scale")
                     fwm = lv['fwmap']
                     ws = workspace(8 * N * h * w, self.dev, slot=2)
                     check(lib.unflow_forward_warp_fwd(ptr(lv['fscaled']), ptr(fwm), N, h, w, 1, ptr(ws),
@@ -837,10 +839,10 @@ class FlowNetEngine:
                 if with_grad and wt('fb'):
                     # back through image_warp(flow_other, flow_own): scatter into the partner's flow gradient (via a
                     # scratch buffer: the scatter must not race with the in-place accumulation) + own flow gradient
-                    lv['dimtmp'].zero_()
+                    check(lib.unflow_zero(ptr(lv['dimtmp']), _lib.csz(lv['dimtmp'].numel() * 4), st), "zero")
                     check(lib.unflow_image_warp_bwd(ptr(lv['gwarped']), ptr(flow), 2, ptr(flow), cf(fs), ptr(lv['dimtmp']),
                                                     ptr(gflow), 1, B, N, h, w, 2, st), "image_warp_bwd(flow)")
-                    gflow.add_(lv['dimtmp'])
+                    check(lib.unflow_add_inplace(ptr(gflow), ptr(lv['dimtmp']), cl(gflow.numel()), st), "add")
             # ---- data terms
             if wt('ternary'):
                 D = lv['pd']
@@ -869,7 +871,7 @@ class FlowNetEngine:
                                                     ptr(gflow), 1, B, N, h, w, 3, st), "image_warp_bwd(im)")
         if with_grad and not P.get('pyramid_loss'):
             for lv in self.lv[1:]:
-                lv['gflow'].zero_()
+                check(lib.unflow_zero(ptr(lv['gflow']), _lib.csz(lv['gflow'].numel() * 4), st), "zero")
         # regularisation term (value only; its gradient is fused into adam_step)
         if not self.defer_l2:
             check(lib.unflow_l2_loss(ptr(self.P), cl(self.n_weights), cf(L2_SCALE), ptr(self.loss_acc), st), "l2_loss")
@@ -923,7 +925,8 @@ class FlowNetEngine:
         """d loss / d (flow2 of the previous network) through the stage input of `st` (train_all).  The previous
         network's coarser flows do not reach the loss directly (only flows[-1] enters it, unsupervised.py:82-83)."""
         for lvl in prev.flow_levels:
-            prev.grad['flow%d' % lvl].zero_()
+            gz = prev.grad['flow%d' % lvl]
+            check(_lib.lib().unflow_zero(ptr(gz), _lib.csz(gz.numel() * 4), self.stream()), "zero")
         g2 = prev.grad['flow2']
         pf = prev.act['flow2']
         dx = st.grad['x0s']
@@ -1070,7 +1073,8 @@ class FlowNetEngine:
         """final_flow_fw / _bw: resize_bilinear(flow2, im_shape) * 5 * 4 (unsupervised.py:103-104), or flow0 * 20 with
         full_res (unsupervised.py:95-97)."""
         if self.full_res:
-            torch.mul(self.act['flow0'], FLOW_SCALE * 4, out=self.final_flow)
+            f0 = self.act['flow0']
+            check(_lib.lib().unflow_scale(ptr(f0), cf(FLOW_SCALE * 4), ptr(self.final_flow), cl(f0.numel()), self.stream()), "scale")
             return self.final_flow[:self.B], self.final_flow[self.B:]
         f2 = self.act['flow2']
         N, h, w, _ = f2.shape

@@ -5,8 +5,6 @@ leaky-ReLU 0.1, HWIO weights; conv_transpose weights [k,k,out,in]).
 Tensors are NHWC float32 CUDA tensors or channel-slice views of them (stride(3) == 1); a view lets a
 layer read from / write into a slice of a concat buffer without a copy.
 """
-import os
-
 import torch
 
 from .. import _lib
@@ -159,7 +157,7 @@ class PT:
         # plane rows are padded to 64 bytes (32 channels): every 64-byte K-tile row of the gather kernels and every 256-byte
         # site row of the filter-gradient kernel is then ONE aligned L1 access (TCP_TOTAL_CACHE_ACCESSES per buffer load:
         # 18 / 30 with 8-channel padding, 16 is the minimum)
-        pad = int(os.environ.get('UNFLOW_PLANE_PAD', '32'))        # A/B knob: 8 = minimal padding
+        pad = 32
         cp = (shape[-1] + pad - 1) // pad * pad if shape[-1] > 8 else round8(shape[-1])
         pl = _t.zeros(n_planes, *shape[:-1], cp, dtype=_t.int16, device=device) if n_planes else None
         return PT(t, pl)

@@ -15,11 +15,9 @@ so the optimizer update of a bucket overlaps the exchange and the backward pass 
 only read by its own forward / data-gradient launches, which are complete when its bucket is released).  The re-split of
 the updated weights into their operand planes (csrc/conv_planes.hip) follows each bucket's update on the same stream
 instead of opening the next forward pass.  With one rank there is no exchange: one graph, one Adam launch.  (Keeping the cut
-on one rank — UNFLOW_OVERLAP_ADAM=1: the HBM-bound Adam + re-split of the deep layers beside the backward pass of the shallow
+on one rank — StepRunner(local_overlap=True): the HBM-bound Adam + re-split of the deep layers beside the backward pass of the shallow
 ones — measured 2.7 % SLOWER on MI355X, 544 vs 559 pairs/s: the streaming blocks take CU slots from conv launches that are
 sized to fill the chip in exactly one round.)"""
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -57,11 +55,10 @@ class StepRunner:
     exchanged), bucketed RCCL all-reduce and bucketed Adam on a communication stream.  Used by bench.py and Trainer."""
 
     def __init__(self, engine, world=1, use_graph=True, force_reducer=False, bucket_cuts=DEFAULT_BUCKET_CUTS,
-                 bucket_bytes=64 << 20, group=None):
+                 bucket_bytes=64 << 20, group=None, local_overlap=False):
         self.eng = engine
         self.world = world
-        local = (world == 1 and not force_reducer and engine.dev.type == 'cuda'
-                 and os.environ.get('UNFLOW_OVERLAP_ADAM', '0') != '0')
+        local = world == 1 and not force_reducer and engine.dev.type == 'cuda' and local_overlap
         self.dist = world > 1 or force_reducer or local
         self.reducer = GradAllReducer(engine.G, world, bucket_bytes=bucket_bytes, group=group, force=force_reducer,
                                       local_overlap=local) if self.dist else None
@@ -126,9 +123,6 @@ class StepRunner:
             if e.planes_external:
                 e.refresh_weight_planes_ranges(ranges)
 
-        if self.reducer is not None and self.frozen:
-            # frozen networks: zero data gradient everywhere, nothing to exchange; their L2 update runs on the side stream
-            self.reducer.reduce_then([], lambda: update(self.frozen))
         for k in range(self.nparts):
             if self.graphs is not None:
                 self.graphs[k].replay()
@@ -136,7 +130,13 @@ class StepRunner:
                 self._part(k)
             if self.reducer is not None:
                 ranges = self.buckets[k]
-                self.reducer.reduce_then(ranges, lambda r=ranges: update(r))
+                # Frozen networks (stacked spec without train_all): zero data gradient everywhere, nothing to exchange, but
+                # the optimizer still applies the L2 term to them.  Their update rides behind bucket 0 — i.e. behind part 0,
+                # which holds the forward pass of those very networks and the loss_acc.zero_() of forward_loss: issued before
+                # the replay it would overwrite P / the weight planes under the frozen stages' forward kernels and lose its
+                # L2 loss term to the zeroing.
+                upd = ranges + self.frozen if k == 0 else ranges
+                self.reducer.reduce_then(ranges, lambda r=upd: update(r))
         if self.reducer is not None:
             self.reducer.finish()
         else:

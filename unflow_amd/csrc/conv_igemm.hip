@@ -21,6 +21,7 @@
 // the deep layers with partials in a caller workspace and a fixed-order reduce that applies the epilogue (deterministic,
 // no float atomics).
 #include "igemm_shared.h"
+#include "options.h"
 
 namespace {
 using namespace igemm;
@@ -38,7 +39,6 @@ struct GatherParams : GatherGeom {
   int nsplit;
   int leaky, accumulate;
   unsigned cs_magic;  // ceil(2^32 / Cs)
-  int dbg;            // ablation switches (UNFLOW_DBG env; 0 in production)
   PlaneOut pl;        // optional 16-bit operand planes of the output (conv_planes.hip consumers)
 };
 
@@ -51,9 +51,7 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 // sum|a||b| against 2.8e-8 for v_mfma_f32_32x32x2_f32 — the same accuracy class, at 1/16 of the matrix-core time per
 // product term.  The split happens once per element while the tile is staged into LDS (v_cvt_pk_bf16_f32, gfx950).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifndef UNFLOW_EARLY_LOADS
-#define UNFLOW_EARLY_LOADS 1
-#endif
+constexpr bool kEarlyLoads = true;   // load pieces go out after the FIRST term groups of a tile (measured better than evenly spread)
 constexpr int LDH = BK;       // bf16 row pitch of one plane: 64 bytes, no padding (49 KB per 128x128 block -> 3 blocks per CU)
 // ... made conflict-free by an XOR swizzle of the 16-byte granule index with bits 2..3 of the row: the 16 lanes a
 // ds_read_b128 serves per cycle (rows r .. r+15, same logical granule) then touch 16 different granule slots of 256 bytes.
@@ -83,7 +81,7 @@ __device__ __forceinline__ void split_store(unsigned short* __restrict__ dst, in
 // there: an in-order wave then always has an MFMA within a few instructions, instead of a ~300
 // instruction load prologue during which its SIMD's matrix pipe idles (and co-resident waves lock-step).
 // All predication is by address select + value select — no divergent branches in the loop.
-template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0, int PF = 1>
+template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -180,7 +178,6 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
 
   float4 ra[AR];
   float4 rb[NB];
-  float4 ra2[PF == 2 ? AR : 1], rb2[PF == 2 ? NB : 1];   // PF == 2: second register set (tile t+2 in flight while t+1 waits)
   // state of the tile being loaded (set by piece 0)
   int dy, dx, a_tile, w_tile;
 
@@ -284,7 +281,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
   const int gsw = lh ^ ((l31 >> 2) & 3);     // swizzled granule of K16 slab 0 (slab 1: ^ 2); tile bases are multiples of 32
   // MATH == 1: the 12 term groups of the tile in LDS, with the load pieces of tile `kload` (into RA/RB) between them.
   // Two K16 slabs per tile; lane (row l31, half lh) holds k = 16*slab + 8*lh .. +7 of its row for both operands.
-  constexpr bool EARLY_LOADS = UNFLOW_EARLY_LOADS;
+  constexpr bool EARLY_LOADS = kEarlyLoads;
   auto mfma_phase = [&](int kload, float4* RA, float4* RB) {
 #pragma unroll
     for (int slab = 0; slab < 2; slab++) {
@@ -322,28 +319,8 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
       for (int st = 12; st < 16; st++) piece_set(st, kload, RA, RB);
     }
   };
-  if constexpr (MATH == 1 && PF == 2) {
-    // distance-2 prefetch: while tile kt is multiplied, tile kt+1 is already in flight in the other register set and
-    // tile kt+2 is requested — a bf16x3 tile takes only ~0.6 us of matrix-core time, less than an L2/HBM round trip
-    live = kt0 + 1 < kt1;
-#pragma unroll
-    for (int st = 0; st < 16; st++) piece_set(st, kt0 + 1, ra2, rb2);
-    for (int kt = kt0; kt < kt1; kt += 2) {
-      live = kt + 2 < kt1;
-      mfma_phase(kt + 2, ra, rb);
-      __syncthreads();
-      store_set(ra2, rb2);          // tile kt+1
-      __syncthreads();
-      if (kt + 1 >= kt1) break;
-      live = kt + 3 < kt1;
-      mfma_phase(kt + 3, ra2, rb2);
-      __syncthreads();
-      store_set(ra, rb);            // tile kt+2
-      __syncthreads();
-    }
-  } else
   for (int kt = kt0; kt < kt1; kt++) {
-    live = (kt + 1 < kt1) && !(p.dbg & 1);
+    live = kt + 1 < kt1;
     if constexpr (MATH == 1) {
       mfma_phase(kt + 1, ra, rb);
     } else {
@@ -366,9 +343,9 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherParams p)
       }
     }
     }
-    if (!(p.dbg & 2)) __syncthreads();  // every wave is done reading this tile
-    if (!(p.dbg & 4)) store_tile();     // (last iteration: zeros, never read)
-    if (!(p.dbg & 2)) __syncthreads();
+    __syncthreads();  // every wave is done reading this tile
+    store_tile();     // (last iteration: zeros, never read)
+    __syncthreads();
   }
 
   // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -671,8 +648,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_b3_kernel(const WgradParams p
       rb[gi][j] = buf_ld1(dst_rs, ok ? (sidx * p.ldd + nb) * 4 : OOB_MARK, 0);
     }
   };
-  // 12 MFMA term groups per K tile: the loads go out after the first ones (six per group when UNFLOW_EARLY_LOADS)
-  constexpr int LPG = UNFLOW_EARLY_LOADS ? 6 : 3;
+  // 12 MFMA term groups per K tile: the loads go out after the first ones (six per group with kEarlyLoads)
+  constexpr int LPG = kEarlyLoads ? 6 : 3;
   auto piece = [&](int step, int kt) {
 #pragma unroll
     for (int l = LPG * step; l < LPG * step + LPG; l++)
@@ -1535,20 +1512,10 @@ struct GatherPlan {
 
 // The 128-row gather tiles (conv fwd / dgrad, deconv fwd / dgrad) compute on the bf16 matrix cores by default (3-way
 // split, six terms: fp32-equivalent, see split_store); UNFLOW_CONV_MATH=fp32 selects v_mfma_f32_32x32x2_f32 for them too.
-inline bool conv_math_bf16x3() {
-  static const bool on = !(getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32"));
-  return on;
-}
+inline bool conv_math_bf16x3() { return !unflow::options().conv_math_fp32; }
 
-inline bool gather_pf2() {   // UNFLOW_GATHER_PF2=1: distance-2 prefetch in the 128x128 bf16x3 gather kernel (tuning knob)
-  static const bool on = getenv("UNFLOW_GATHER_PF2") && atoi(getenv("UNFLOW_GATHER_PF2")) != 0;
-  return on;
-}
-
-inline bool wgrad_math_bf16x3() {   // UNFLOW_WGRAD_MATH=fp32 keeps the filter gradients on v_mfma_f32_32x32x2_f32
-  static const bool on = conv_math_bf16x3() && !(getenv("UNFLOW_WGRAD_MATH") && !strcmp(getenv("UNFLOW_WGRAD_MATH"), "fp32"));
-  return on;
-}
+// option wgrad_math_fp32 keeps the filter gradients on v_mfma_f32_32x32x2_f32
+inline bool wgrad_math_bf16x3() { return conv_math_bf16x3() && !unflow::options().wgrad_math_fp32; }
 
 inline GatherPlan plan_gather(const GatherParams& p) {
   GatherPlan pl;
@@ -1559,20 +1526,17 @@ inline GatherPlan plan_gather(const GatherParams& p) {
   int maxtaps = 0;
   for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
   const int KT = (maxtaps * p.Cs + BK - 1) / BK;
-  static const int min_kt = getenv("UNFLOW_GATHER_MIN_KT") ? max(1, atoi(getenv("UNFLOW_GATHER_MIN_KT"))) : 8;   // tuning knob
+  const int min_kt = max(1, unflow::options().gather_min_kt);
   const int max_by_k = min(16, KT / min_kt > 0 ? KT / min_kt : 1);  // keep >= 8 K-tiles per split
   if (pl.cfg == 0) {
     const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
     if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
   }
-  // N <= 64 with a long M: a 256x64 tile (four 64x64 wave tiles stacked along M: 4 accumulators per wave, the MFMA :
-  // LDS-read ratio of the 128x128 tile) instead of 128x64.  Measured on conv1 fwd / conv2 dgrad: no gain (438 vs 441
-  // pairs/s), so it stays behind the knob.
-  static const int tall = getenv("UNFLOW_GATHER_TALL") ? atoi(getenv("UNFLOW_GATHER_TALL")) : 0;   // tuning knob
-  if (pl.cfg == 1 && tall && M * p.ncls >= 256L * 768) pl.cfg = 3;
-  const int bm = pl.cfg == 2 ? 64 : pl.cfg == 3 ? 256 : 128, bn = pl.cfg == 0 ? 128 : 64;
+  // (A 256x64 tile for N <= 64 with a long M — 4 accumulators per wave, the MFMA : LDS-read ratio of the 128x128 tile —
+  // measured no gain on conv1 fwd / conv2 dgrad, 438 vs 441 pairs/s: dropped.)
+  const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
   // bf16x3 tiles: 49 KB / 37 KB of LDS per block (swizzled, unpadded planes): the same residency as the fp32 tiles
-  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : pl.cfg == 3 ? 3 : 6);
+  const int slots = 256 * (pl.cfg == 0 ? 3 : pl.cfg == 1 ? 4 : 6);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
   return pl;
@@ -1582,26 +1546,20 @@ inline size_t gather_partial_bytes(const GatherParams& p, int nsplit) {
   return nsplit > 1 ? (size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
 }
 
-// tile of the filter-gradient kernel: 0 = 128x128, 1 = 128x64, 2 = 256x128 (8 accumulators per wave)
-inline int wgrad_cfg(const WgradParams& p) {
-  static const int force = getenv("UNFLOW_WGRAD_CFG") ? atoi(getenv("UNFLOW_WGRAD_CFG")) : -1;  // tuning knob
-  const int Mp = p.KH * p.KW * p.Ca;
-  if (p.Cb <= 64) return 1;
-  if (force == 2) return Mp >= 1024 ? 2 : 0;
-  return 0;
-}
+// tile of the filter-gradient kernel: 0 = 128x128, 1 = 128x64 (a 256x128 tile, 8 accumulators per wave, measured slower)
+inline int wgrad_cfg(const WgradParams& p) { return p.Cb <= 64 ? 1 : 0; }
 
 inline int plan_wgrad(const WgradParams& p) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int cfg = wgrad_cfg(p);
-  const int bn = cfg == 1 ? 64 : 128, bm = cfg == 2 ? 256 : 128;
-  const long blocks = (long)cdiv(Mp, bm) * cdiv(p.Cb, bn);
+  const int bn = cfg == 1 ? 64 : 128;
+  const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
-  static const int min_kt = getenv("UNFLOW_WGRAD_MIN_KT") ? max(1, atoi(getenv("UNFLOW_WGRAD_MIN_KT"))) : 8;     // tuning knob (8 vs 4: +0.8 %)
+  const int min_kt = max(1, unflow::options().wgrad_min_kt);    // 8 vs 4: +0.8 %
   const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
-  const bool b3 = wgrad_math_bf16x3() && cfg != 2;                // bf16x3: 49 / 37 KB of LDS per block
-  const int slots = 256 * (b3 ? (cfg == 1 ? 4 : 3) : cfg == 2 ? 2 : cfg == 1 ? 5 : 4);   // fp32: single-stage LDS 32 KB / 122 regs: 4 per CU
+  const bool b3 = wgrad_math_bf16x3();                            // bf16x3: 49 / 37 KB of LDS per block
+  const int slots = 256 * (b3 ? (cfg == 1 ? 4 : 3) : cfg == 1 ? 5 : 4);   // fp32: single-stage LDS 32 KB / 122 regs: 4 per CU
   return fill_one_round(blocks, slots, max_by_k);
 }
 
@@ -1640,26 +1598,22 @@ inline int head_wgrad_blocks(int B, int H, int W, int Cin, int S, int* strips_pe
 constexpr size_t COLSUM_SCRATCH_BYTES(int C) { return (size_t)REDUCE_FAN * C * sizeof(float) + 512; }
 
 // ---- launchers
-template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0, int PF = 1>
+template <int BM, int BN, int WM, int WN, bool B_NK, int MATH = 0>
 int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
   const size_t smem = (MATH ? (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short) : (size_t)(BM + BN) * LDK * sizeof(float)) +
                       BM * sizeof(int);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
   (void)attr;
   dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
-  igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH, PF><<<grid, 256, smem, st>>>(p);
+  igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH><<<grid, 256, smem, st>>>(p);
   return launch_status();
 }
 
 template <bool B_NK>
 int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   p.cs_magic = magic_u32((unsigned)p.Cs);
-  {
-    static const int dbg = getenv("UNFLOW_DBG") ? atoi(getenv("UNFLOW_DBG")) : 0;
-    p.dbg = dbg;
-  }
   const GatherPlan pl = plan_gather(p);
   p.nsplit = pl.nsplit;
   p.partial = nullptr;
@@ -1669,12 +1623,10 @@ int run_gather(GatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   }
   int code;
   switch (pl.cfg) {
-    case 0: code = !conv_math_bf16x3() ? launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st)
-                 : gather_pf2()        ? launch_gather_cfg<128, 128, 64, 64, B_NK, 1, 2>(p, st)
-                                       : launch_gather_cfg<128, 128, 64, 64, B_NK, 1>(p, st); break;
+    case 0: code = conv_math_bf16x3() ? launch_gather_cfg<128, 128, 64, 64, B_NK, 1>(p, st)
+                                      : launch_gather_cfg<128, 128, 64, 64, B_NK>(p, st); break;
     case 1: code = conv_math_bf16x3() ? launch_gather_cfg<128, 64, 64, 32, B_NK, 1>(p, st)
                                       : launch_gather_cfg<128, 64, 64, 32, B_NK>(p, st); break;
-    case 3: code = launch_gather_cfg<256, 64, 64, 64, B_NK>(p, st); break;
     default: code = launch_gather_cfg<64, 64, 32, 32, B_NK>(p, st); break;
   }
   if (code != UNFLOW_OK) return code;
@@ -1727,10 +1679,9 @@ int run_wgrad(WgradParams& p, void* ws, size_t ws_bytes, size_t* used, hipStream
   p.partial = ns > 1 ? reinterpret_cast<float*>(ws) : nullptr;
   *used = wgrad_partial_bytes(p, ns);
   const int cfg = wgrad_cfg(p);
-  const bool b3 = wgrad_math_bf16x3() && cfg != 2;
+  const bool b3 = wgrad_math_bf16x3();
   const int code = b3 ? (cfg == 1 ? launch_wgrad_b3_cfg<128, 64, 64, 32>(p, st) : launch_wgrad_b3_cfg<128, 128, 64, 64>(p, st))
                  : cfg == 1 ? launch_wgrad_cfg<128, 64, 64, 32>(p, st)
-                 : cfg == 2 ? launch_wgrad_cfg<256, 128, 128, 64>(p, st)
                             : launch_wgrad_cfg<128, 128, 64, 64>(p, st);
   if (code != UNFLOW_OK) return code;
   if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);

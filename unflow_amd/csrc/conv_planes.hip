@@ -20,7 +20,9 @@
 //        operands are site-major in HBM, so a tile is staged as [k = site][channel] rows (256 contiguous bytes per site)
 //        and the MFMA fragments (8 consecutive k of one channel) come out of LDS through ds_read_b64_tr_b16, the
 //        gfx950 transposing read (semantics probed in tools/microbench/probe_semantics.hip): no per-lane dword gathers.
+#include <type_traits>
 #include "igemm_shared.h"
+#include "options.h"
 
 namespace {
 using namespace igemm;
@@ -48,7 +50,6 @@ struct PlGatherParams : GatherGeom {
   int fused_splitk;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
-  int dbg;                     // ablation switches (UNFLOW_DBG env; 0 in production): 1 no loads in the loop, 2 no LDS stores
   int xcd;                     // XCD-contiguous work order (xcd_remap + work_decode)
   int mt, nt;                  // M tiles, N tiles of the launch (the grid is 1-D: mt * nt * ncls * nsplit workgroups)
   int order;                   // work order (work_decode): 0 N tile fastest .. M tile slowest; 1 M tile fastest; 2 M groups
@@ -56,6 +57,7 @@ struct PlGatherParams : GatherGeom {
   int tw_log;                  // gather kernel: 0 = an M tile is BM consecutive sites of the linear (b, y, x) order; else the
                                // tile is (BM >> tw_log) rows x (1 << tw_log) sites of one image (tiles_x, tiles_y per image)
   int gpx;                     // pixels per K granule along x (0: a granule is 8 channels of ONE pixel; 2: conv1 form, below)
+  int skip;                    // skip the MFMAs of 32-column sub-tiles beyond N (option ntail_skip)
   PlaneOut pl;
 };
 
@@ -393,14 +395,12 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   auto piece_a = [&](int i) {
     const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
     const bool inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-    int voff = inb ? a_lin[i] + a_tile : OOB_MARK;
-    if (p.dbg & 4) voff = tid * 16 + i * 4096;      // ablation: perfectly coalesced (wrong) addresses, same load count
+    const int voff = inb ? a_lin[i] + a_tile : OOB_MARK;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
   };
   auto piece_b = [&](int i) {
-    int voff = b_row[i] + w_tile;
-    if (p.dbg & 4) voff = tid * 16 + i * 4096;
+    const int voff = b_row[i] + w_tile;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
   };
@@ -413,7 +413,6 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   };
   constexpr int NPIECE = AR + NB + 2;
   auto piece = [&](int step) {
-    if (p.dbg & 1) return;
     if (step == 0) piece_begin();
     if (step >= 1 && step <= AR) piece_a(step - 1);
     if (step > AR && step <= AR + NB) piece_b(step - AR - 1);
@@ -452,8 +451,11 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   constexpr int NGROUP = 2 * TM * NT;        // MFMA groups per tile between which the load pieces are placed
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
 
-  for (int kt = kt0; kt < kt1; kt++) {
-    live = kt + 1 < kt1;
+  // 32-column sub-tiles of this wave that hold a real output column (a prefix): the others get no MFMAs (N = 388 / 772 / 1028
+  // of the decoder leaves 4 real columns in the last 128-wide N tile)
+  const int vj = p.skip ? min(TN, max(0, (p.N - (n0 + wn * WN) + 31) >> 5)) : TN;
+  const bool full = vj == TN;
+  auto mfma_tile = [&](auto guarded) __attribute__((always_inline)) {
 #pragma unroll
     for (int slab = 0; slab < 2; slab++) {
       // B fragments of the slab stay live; A fragments are read per 32-row sub-tile (keeps the 128x128 kernel at 3 waves/SIMD)
@@ -472,15 +474,25 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 #pragma unroll
         for (int t = 0; t < NT; t++) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t);
+          for (int j = 0; j < TN; j++) {
+            if constexpr (decltype(guarded)::value) {
+              if (j >= vj) continue;
+            }
+            mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t);
+          }
 #pragma unroll
           for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t) * PPG + q);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+  };
+  for (int kt = kt0; kt < kt1; kt++) {
+    live = kt + 1 < kt1;
+    if (full) mfma_tile(std::false_type{});
+    else mfma_tile(std::true_type{});
     __syncthreads();  // every wave is done reading this tile
-    if (!(p.dbg & 2)) store_tile();     // (last iteration: zeros, never read)
+    store_tile();     // (last iteration: zeros, never read)
     __syncthreads();
   }
 
@@ -656,15 +668,18 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   constexpr int NPIECE = NB + NH;
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
   int ty = 0, tx = 0;                            // tap of the tile being multiplied (kt0 is a chunk boundary)
+  // 32-column sub-tiles of this wave with a real output column (a prefix): the others get no MFMAs (see the gather kernel)
+  const int vj = p.skip ? min(TN, max(0, (p.N - (n0 + wn * WN) + 31) >> 5)) : TN;
+  const bool full = vj == TN;
   for (int kk = kt0; kk < kt1; kk++) {
     const int hyi = (tc.dy0 + ty * p.dstep) - dmin_y, hxi = (tc.dx0 + tx * p.dstep) - dmin_x;
     const int tapoff = (hyi * HC + hxi) * HPITCH;
     const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
     auto piece = [&](int step) {
-      if (p.dbg & 1) return;
       if (step < NB) load_b(step);
       else if (step < NB + NH && new_chunk) load_h(step - NB);
     };
+    auto body = [&](auto guarded) __attribute__((always_inline)) {
     if constexpr (BN == 128) {
       // software-pipelined over the 2 x TM (slab, sub-tile) steps: the fragments of step s+1 are read from LDS while the
       // MFMAs of step s run (two waves per SIMD are not enough to hide a ds_read round trip in front of every step)
@@ -694,7 +709,12 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   #pragma unroll
         for (int t2 = 0; t2 < NT; t2++) {
   #pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
+          for (int j = 0; j < TN; j++) {
+            if constexpr (decltype(guarded)::value) {
+              if (j >= vj) continue;
+            }
+            mfma_terms<NPL, F16>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
+          }
   #pragma unroll
           for (int q = 0; q < PPG; q++) piece((step * NT + t2) * PPG + q);
           __builtin_amdgcn_sched_barrier(0);
@@ -720,7 +740,12 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
 #pragma unroll
           for (int t2 = 0; t2 < NT; t2++) {
 #pragma unroll
-            for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
+            for (int j = 0; j < TN; j++) {
+              if constexpr (decltype(guarded)::value) {
+                if (j >= vj) continue;
+              }
+              mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
+            }
 #pragma unroll
             for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
             __builtin_amdgcn_sched_barrier(0);
@@ -728,11 +753,12 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
         }
       }
     }
+    };
+    if (full) body(std::false_type{});
+    else body(std::true_type{});
     __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
-    if (!(p.dbg & 2)) {
-      store_b();
-      if (new_chunk) store_h();
-    }
+    store_b();
+    if (new_chunk) store_h();
     __syncthreads();
     ty = ld_ty; tx = ld_tx;
     ld_advance(kk + 1);
@@ -791,10 +817,10 @@ struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multi
   int lds, ldd;
   int Ca_out;                  // rows per tap of dW (the weight tensor's own channel padding, <= Ca)
   int nsplit;
-  int dbg;
   int gpx;                     // conv1 form: granule ag of a tap row starts gpx * ag pixels to the right
   unsigned cag_magic;          // ceil(2^32 / (Ca/8))
   int mt, nt, xcd;             // 1-D grid of mt * nt * nsplit workgroups, XCD-contiguous in (split, N tile, M tile) order
+  int skip;                    // skip the MFMAs of sub-tiles beyond the problem (option ntail_skip)
 };
 
 // LDS image of one operand plane: [k = 32 sites][ROWS channels], rows of ROWS*2 bytes; 32-byte pairs of granules
@@ -807,8 +833,8 @@ __device__ __forceinline__ int tr_swz(int k, int granule) {
   return k * ROWS + (((pair ^ sw) << 1) | (granule & 1)) * 8;
 }
 
-template <int BM, int BN, int WM, int WN, int NPL, bool F16, bool PIPE = false>
-__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ? 2 : 3) : 1) void igemm_pl_wgrad_kernel(const PlWgradParams p) {
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_wgrad_kernel(const PlWgradParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
@@ -876,26 +902,22 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
     const int yg = (int)(q - bb * (unsigned)p.Hg);
     const int yb = yg * p.sm, xb = xg * p.sm;
     const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
-    int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
-    if (p.dbg & 4) voff = tid * 16 + i * 4096;
+    const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
   };
   auto piece_b = [&](int i, int kt) {
     const int sidx = kt * BK + bk + BKS * i;
-    int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
-    if (p.dbg & 4) voff = tid * 16 + i * 4096;
+    const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(dst_rs[pl], voff);
   };
   constexpr int NPIECE = AR + BR;
   auto piece = [&](int step, int kt) {
-    if (p.dbg & 1) return;
     if (step < AR) piece_a(step, kt);
     else if (step < AR + BR) piece_b(step - AR, kt);
   };
   auto store_tile = [&]() {
-    if (p.dbg & 2) return;
 #pragma unroll
     for (int i = 0; i < AR; i++)
 #pragma unroll
@@ -941,9 +963,8 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
   const int l31 = lane & 31;
   for (int kt = kt0; kt < kt1; kt++) {
     const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;   // past the last tile: every load is out of range (zeros)
-    s16x8 av[PIPE ? 2 : 1][TM][NPL], bv[PIPE ? 2 : 1][TN][NPL];
+    s16x8 av[TM][NPL], bv[TN][NPL];
     auto read_slab = [&](int slab) {
-      const int q = PIPE ? slab : 0;
 #pragma unroll
       for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
@@ -951,30 +972,28 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
           const unsigned short* b0 = Ah + pl * A_PLANE + a_rd[i] + (16 * slab) * BM;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BM));
-          av[q][i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          av[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int j = 0; j < TN; j++) {
           const unsigned short* b0 = Bh + pl * B_PLANE + b_rd[j] + (16 * slab) * BN;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BN));
-          bv[q][j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
     };
-    // PIPE: both K16 slabs' fragments are requested before the first MFMA (the second set lands under the first slab's
-    // MFMAs; two waves per SIMD).  Otherwise one set at a time (three waves per SIMD hide the read latency).
-    if constexpr (PIPE) { read_slab(0); read_slab(1); }
+    // one fragment set at a time: three waves per SIMD hide the read latency (both slabs' sets in flight, two waves per SIMD,
+    // measured slower)
 #pragma unroll
     for (int slab = 0; slab < 2; slab++) {
-      if constexpr (!PIPE) read_slab(slab);
-      const int q = PIPE ? slab : 0;
+      read_slab(slab);
 #pragma unroll
       for (int t = 0; t < NT; t++) {
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[q][i], bv[q][j], acc[i][j], t);
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], t);
 #pragma unroll
         for (int q2 = 0; q2 < PPG; q2++) piece((slab * NT + t) * PPG + q2, ktn);
         __builtin_amdgcn_sched_barrier(0);
@@ -1015,24 +1034,38 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? (PIPE ?
 // instruction writes lane-linear: 64 lanes x 16 bytes = 4 site rows x 16 granule slots, so the XOR swizzle of the
 // transposing-read image is applied on the SOURCE side — lane (row, slot) fetches the granule that belongs in that slot.
 // Out-of-range rows (image border taps, the tail of the site range, channel padding) are buffer offsets >= num_records:
-// the hardware writes zeros.  48 KB of LDS and <= 168 registers: three blocks per CU, as before.
-template <int BN, int WN>
-__global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
+// the hardware writes zeros.  48 KB of LDS and <= 168 registers per K group.
+//
+// K groups (KG = 3, round 3): the partial sums of a filter gradient are (resident accumulators) x 4 bytes = 768 blocks x
+// 64 KB = 50 MB per layer whatever its size — written, then re-read by sum_partials: ~1.5 GB and 0.37 ms of reduce
+// launches per step.  With KG = 3 a workgroup is 12 waves = three 4-wave groups that own the SAME output tile and
+// consecutive thirds of the block's site range, each with its own pair of stage buffers (3 x 48 KB of the CU's 160 KB: one
+// workgroup per CU, the same 12 waves as three KG = 1 blocks).  After the K loop groups 1 and 2 hand their accumulators to
+// group 0 through the (now free) stage buffers, group 0 adds them in group order and writes ONE partial: a third of the
+// bytes, in a fixed summation order.  All groups run the same number of stages (a group whose run is shorter multiplies
+// zero stages), so the one hardware barrier per stage is shared by the 12 waves.
+// Sub-tile skipping: a wave whose 32-row / 32-column sub-tile lies wholly beyond the problem (last M tile of conv3_1: 96 of
+// 128 rows; N = 388 / 772 / 1028 of the decoder: 4 of 128 columns in the last N tile) issues no MFMAs for it.
+template <int BN, int WN, int KG>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 3 : 1) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
   constexpr int BM = 128, WM = 64, NPL = 3, NT = 6, KS = 16;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per K group");
   static_assert(BN == 128 || BN == 64, "swizzle forms");
   constexpr int A_PLANE = KS * BM, B_PLANE = KS * BN;            // elements
   constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
   constexpr int B_RPI = 512 / BN;                                // site rows per wave instruction: 4 (256-byte rows) / 8
   constexpr int B_NI = KS / B_RPI;                               // wave instructions per plane and stage: 4 / 2
   constexpr int B_SLOTS = BN / 8;
+  static_assert((KG - 1) * BM * BN * 4 <= KG * 2 * STAGE * 2, "the group hand-off fits the stage buffers");
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wall = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = KG == 1 ? 0 : wall >> 2;                       // K group of this wave
+  const int wid = wall & 3;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int taps = p.KH * p.KW;
   const int Cag = p.Ca >> 3;
@@ -1046,6 +1079,9 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   const int KT = (S + KS - 1) / KS;
   const int kt_per = (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;   // whole 32-site tiles per split, as the planner counts them
   const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
+  // this group's run of the block's stages; every group iterates `per` times (stages past g1 are zeros)
+  const int per = (max(kt1 - kt0, 0) + KG - 1) / KG;
+  const int g0 = kt0 + grp * per, g1 = min(kt1, g0 + per);
 
   // buffer descriptors as plain dwords (the LDS-DMA loads are inline asm: hipcc would otherwise wait vmcnt(0) in front of
   // every ds_read that follows a load into the same LDS array, i.e. drain the stage in flight)
@@ -1079,7 +1115,8 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   const int ldd2 = p.ldd * 2;
   const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
 
-  const unsigned lds0 = lds_addr(smem16);
+  unsigned short* gsm = smem16 + grp * (2 * STAGE);              // this group's two stage buffers
+  const unsigned lds0 = lds_addr(gsm);
   auto issue = [&](int kt, int buf) {
     const unsigned st = lds0 + (unsigned)(buf * STAGE * 2);      // byte address of the stage in LDS
     {
@@ -1092,9 +1129,9 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
       const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
       const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
       const unsigned d = st + (unsigned)(4 * wid * BM * 2);
-      if (!(p.dbg & 512)) dma3(voff, src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);   // 512 / 256: ablations
+      dma3(voff, src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
     }
-    if (wid < B_NI && !(p.dbg & 256)) {
+    if (wid < B_NI) {
       const int sidx = kt * KS + b_k;
       const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
       const unsigned d = st + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
@@ -1110,31 +1147,38 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int i16 = lane & 15, grp = lane >> 4, lh = grp >> 1;
+  const int i16 = lane & 15, grp16 = lane >> 4, lh = grp16 >> 1;
   const int krow = 8 * lh + (i16 >> 2);
   int a_rd[TM], b_rd[TN];
 #pragma unroll
   for (int i = 0; i < TM; i++) {
-    const int c = wm * WM + i * 32 + 16 * (grp & 1) + 4 * (i16 & 3);
+    const int c = wm * WM + i * 32 + 16 * (grp16 & 1) + 4 * (i16 & 3);
     a_rd[i] = tr_swz<BM>(krow, c >> 3) + (c & 7);
   }
 #pragma unroll
   for (int j = 0; j < TN; j++) {
-    const int c = wn * WN + j * 32 + 16 * (grp & 1) + 4 * (i16 & 3);
+    const int c = wn * WN + j * 32 + 16 * (grp16 & 1) + 4 * (i16 & 3);
     b_rd[j] = NPL * A_PLANE + tr_swz<BN>(krow, c >> 3) + (c & 7);
   }
+  // 32-row / 32-column sub-tiles of this wave that hold any real row (tap, channel) / column: a prefix of each range
+  const int vi = p.skip ? min(TM, max(0, (Mg * 8 - (m0 + wm * WM) + 31) >> 5)) : TM;
+  const int vj = p.skip ? min(TN, max(0, (p.Cb - (n0 + wn * WN) + 31) >> 5)) : TN;
+  const bool full = vi == TM && vj == TN;
 
-  if (kt0 < kt1) issue(kt0, 0);
+  issue(g0 < g1 ? g0 : KT + 1, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  for (int kt = kt0; kt < kt1; kt++) {
-    const int cur = (kt - kt0) & 1;
-    // stage kt+1 -> the other buffer (every wave passed the barrier after its reads of that buffer); past the last stage the
-    // loads are all out of range (zeros into a buffer nobody reads)
-    if (!(p.dbg & 1)) issue(kt + 1 < kt1 ? kt + 1 : KT + 1, cur ^ 1);
+  // one stage: request stage kt+1, multiply stage kt, publish.  `guarded` (a compile-time flag; the blocks of the last M / N
+  // tile run their own copy of the loop) skips the sub-tiles beyond the problem.
+  auto stage = [&](int it, auto guarded) __attribute__((always_inline)) {
+    const int kt = g0 + it;
+    const int cur = it & 1;
+    // stage kt+1 -> the other buffer (every wave passed the barrier after its reads of that buffer); past the group's last
+    // stage the loads are all out of range (zeros: multiplied when the group's run is shorter than `per`, else never read)
+    issue(kt + 1 < g1 ? kt + 1 : KT + 1, cur ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned short* st = smem16 + ((p.dbg & 32) ? 0 : cur * STAGE);   // ablation 32: always the same buffer
+    const unsigned short* st = gsm + cur * STAGE;
     s16x8 av[TM][NPL], bv[TN][NPL];
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) {
@@ -1153,19 +1197,69 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
         bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     }
+    if constexpr (!decltype(guarded)::value) {
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+    } else {
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+        for (int j = 0; j < TN; j++)
+          if (i < vi && j < vj) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+          }
+    }
     // own loads landed + own LDS reads retired, then the barrier: stage kt+1 is complete and buffer `cur` is free (the
     // scheduling fences keep the MFMAs above and the next stage's loads below it)
     __builtin_amdgcn_sched_barrier(0);
-    if (p.dbg & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ablation: do not wait for the loads (wrong results)
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_barrier();                       // ablation 16: no barrier (wrong results)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+  };
+  if (full) {
+    for (int it = 0; it < per; it++) stage(it, std::false_type{});
+  } else {
+    for (int it = 0; it < per; it++) stage(it, std::true_type{});
+  }
+
+  if constexpr (KG > 1) {
+    // Every stage buffer is idle now (last barrier of the loop).  Groups 1 .. KG-1 park their accumulators in them —
+    // [group - 1][wave][sub-tile][4 x float4][lane]: 16-byte stores, lanes 16 bytes apart — and group 0 adds them in group
+    // order: the block's partial is (g0 + g1) + g2 whatever the timing.
+    float4* red = reinterpret_cast<float4*>(smem16);
+    constexpr int PER_WAVE = TM * TN * 4 * 64;                   // float4 per wave
+    if (grp > 0) {
+      float4* d = red + (size_t)((grp - 1) * 4 + wid) * PER_WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            d[((i * TN + j) * 4 + q) * 64] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; g++) {
+      const float4* s = red + (size_t)((g - 1) * 4 + wid) * PER_WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float4 t = s[((i * TN + j) * 4 + q) * 64];
+            acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
+          }
+          asm volatile("" ::: "memory");           // four 16-byte reads in flight at a time (hoisting all 64 spills)
+        }
+    }
   }
 
   float* o = p.nsplit > 1 ? p.partial + (size_t)split * taps * p.Ca_out * p.Cb : p.out;
@@ -1315,8 +1409,7 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   int maxtaps = 0;
   for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
   const int KT = (maxtaps * (p.Cs >> 3) + 3) >> 2;
-  static const int min_kt = getenv("UNFLOW_GATHER_MIN_KT") ? max(1, atoi(getenv("UNFLOW_GATHER_MIN_KT"))) : 8;   // tuning knob
-  static const int max_split = getenv("UNFLOW_GATHER_MAX_SPLIT") ? max(1, atoi(getenv("UNFLOW_GATHER_MAX_SPLIT"))) : 16;
+  const int min_kt = max(1, unflow::options().gather_min_kt), max_split = max(1, unflow::options().gather_max_split);
   const int max_by_k = min(max_split, KT / min_kt > 0 ? KT / min_kt : 1);
   if (pl.cfg == 0) {
     const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
@@ -1354,7 +1447,7 @@ inline int pl_grid(PlGatherParams& q) {
 // 2-D site tiles of the plain gather kernels when they divide the site grid exactly (TW = min(32, Wg) sites wide)
 template <int BM>
 inline void pl_gather_tiles2d(PlGatherParams& q) {
-  static const int tiles2d = getenv("UNFLOW_GATHER_TILE2D") ? atoi(getenv("UNFLOW_GATHER_TILE2D")) : 1;   // A/B knob
+  const int tiles2d = unflow::options().gather_tile2d;
   int twl = 0;
   while ((2 << twl) <= q.Wg && (2 << twl) <= 32) twl++;
   const int tw = 1 << twl, th = BM >> twl;
@@ -1393,7 +1486,7 @@ int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
 
 // ---- halo kernel: eligibility, plan, launch
 inline bool pl_halo_ok(const GatherGeom& p) {
-  static const bool off = getenv("UNFLOW_NO_HALO") && atoi(getenv("UNFLOW_NO_HALO")) != 0;     // A/B knob
+  const bool off = !unflow::options().halo;
   if (off || p.sm != 1 || (p.dstep != 1 && p.dstep != -1) || p.Hg < 2 * TH || p.Wg < TW || p.N <= 32) return false;
   for (int c = 0; c < p.ncls; c++)
     if (p.cls[c].nty < 1 || p.cls[c].ntx < 1 || (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1) > 256) return false;
@@ -1438,21 +1531,13 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   return launch_status();
 }
 
-inline int pl_dbg() {
-  static const int dbg = getenv("UNFLOW_DBG") ? atoi(getenv("UNFLOW_DBG")) : 0;
-  return dbg;
-}
-
 int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStream_t st) {
-  p.dbg = pl_dbg();
-  {
-    static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
-    static const int ord = getenv("UNFLOW_XCD_ORDER") ? atoi(getenv("UNFLOW_XCD_ORDER")) : -1;     // A/B knob: force 0 / 1
-    p.xcd = xcd;
-    // order 2 (M groups per XCD, M tile fastest inside) measured best or tied on every layer of FlowNetC 384x512 B=4 against
-    // 0 and 1 (profiles/r02_xcd_order_per_layer.txt)
-    p.order = ord >= 0 ? ord : 2;
-  }
+  const unflow::Options& opt = unflow::options();
+  p.xcd = opt.xcd_swizzle;
+  // order 2 (M groups per XCD, M tile fastest inside) measured best or tied on every layer of FlowNetC 384x512 B=4 against
+  // 0 and 1 (profiles/r02_xcd_order_per_layer.txt); option xcd_order forces one
+  p.order = opt.xcd_order >= 0 && opt.xcd_order <= 2 ? opt.xcd_order : 2;
+  p.skip = opt.ntail_skip;
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
   PlPlan pl = plan_pl_gather(p, npl);
@@ -1474,12 +1559,12 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
                 (!p.pl.n_planes || p.pl.ld % 4 == 0);
   }
   {
-    // UNFLOW_FUSED_SPLITK=n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
+    // option fused_splitk = n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
     // chip-wide reduce kernel: measured on MI355X (FlowNetC 384x512 B=4) the fused form is bit-identical but not faster —
     // n = 4: 597 vs 599 image-pairs/s, n = 16 with release/acquire fences: 521 vs 590 — although the reduce launches cost
-    // 0.69 ms of the step (no-reduce ablation, UNFLOW_DBG=128): what they cost is the second pass over the partials, which
+    // 0.69 ms of the step (no-reduce ablation): what they cost is the second pass over the partials, which
     // one block per tile does no faster than 256 CUs.  Kept as a tested alternative.
-    static const int fused = getenv("UNFLOW_FUSED_SPLITK") ? atoi(getenv("UNFLOW_FUSED_SPLITK")) : 0;
+    const int fused = opt.fused_splitk;
     p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu;
     p.counters = p.fused_splitk ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pl_gather_slab_bytes(p, p.nsplit)) : nullptr;
   }
@@ -1491,7 +1576,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   }
   if (code != UNFLOW_OK) return code;
-  if (p.nsplit > 1 && !p.fused_splitk && !(p.dbg & 128)) {     // 128: timing experiment (no reduce: wrong results)
+  if (p.nsplit > 1 && !p.fused_splitk) {
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
     const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
                          reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0);
@@ -1505,75 +1590,79 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
 
 inline int pl_wgrad_cfg(const WgradGeom& p) { return p.Cb <= 64 ? 1 : 0; }   // 0: 128x128, 1: 128x64
 
-inline int plan_pl_wgrad(const WgradGeom& p, int npl) {
+// Split plan of a filter gradient.  kg = 1: nsplit x tiles 256-thread workgroups, as many as fit the chip in one round of
+// resident blocks (3 per CU).  kg = 3 (LDS-DMA kernel, option wgrad_kgroups): 768-thread workgroups, one per CU, whose three
+// K groups combine through LDS — a third of the partial sums — when the layer splits at least three ways anyway and
+// tiles x nsplit fills at least wgrad_kg_min_fill % of the CUs (the second stream's kernels take the rest).
+struct PlWgradPlan {
+  int nsplit, kg;
+};
+
+inline PlWgradPlan plan_pl_wgrad(const WgradGeom& p, int npl, bool allow_kg = true) {
+  const unflow::Options& opt = unflow::options();
   const int Mp = p.KH * p.KW * p.Ca;
   const int cfg = pl_wgrad_cfg(p);
   const int bn = cfg == 1 ? 64 : 128;
   const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
-  static const int min_kt = getenv("UNFLOW_WGRAD_MIN_KT") ? max(1, atoi(getenv("UNFLOW_WGRAD_MIN_KT"))) : 8;     // tuning knob
+  const int min_kt = max(1, opt.wgrad_min_kt);
   const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
   const int per_cu = min((160 * 1024) / (npl * (128 + bn) * BK * 2), cfg == 1 ? 4 : 3);
-  // blocks to aim for, in % of the CU count (tuning knob; default: every resident slot).  The partial sums a filter gradient
-  // writes and re-reads are (blocks x tile) bytes whatever the layer — 50 MB at 768 blocks, ~1.5 GB per step — but fewer
-  // blocks lose more than that traffic costs: 587 / 594 / 607 image-pairs/s at 100 / 150 / 200 % against ~620 at 300 %.
-  static const int slots_env = getenv("UNFLOW_WGRAD_SLOTS_PCT") ? atoi(getenv("UNFLOW_WGRAD_SLOTS_PCT")) : 0;
-  static const int slots_pct = slots_env > 0 ? max(25, slots_env) : 0;
-  const int slots = slots_pct ? min(256 * per_cu, 256 * slots_pct / 100) : 256 * per_cu;
-  return fill_one_round(blocks, slots, max_by_k);
+  // (Fewer blocks to shrink the partial sums — blocks x 64 KB whatever the layer, 50 MB at 768 blocks — lose more than the
+  // traffic costs: 587 / 594 / 607 image-pairs/s at 256 / 384 / 512 blocks against ~620 at 768, profiles/r02_knob_sweep.txt.)
+  PlWgradPlan pl{fill_one_round(blocks, 256 * per_cu, max_by_k), 1};
+  if (allow_kg && npl == 3 && opt.wgrad_dma && opt.wgrad_kgroups && pl.nsplit >= 3 && blocks <= 256) {
+    const int by_k = max(1, KT / (3 * min_kt));
+    const int ns3 = (int)min((long)by_k, 256 / blocks);
+    if (blocks * ns3 * 100 >= 256L * opt.wgrad_kg_min_fill) pl = PlWgradPlan{ns3, 3};
+  }
+  return pl;
 }
 
 inline size_t pl_wgrad_partial_bytes(const WgradGeom& p, int ca_out, int nsplit) {
   const size_t n = (size_t)p.KH * p.KW * ca_out * p.Cb;
   return nsplit > 1 ? (size_t)nsplit * n * sizeof(float) + reduce_scratch_bytes(n, nsplit) : 0;
 }
+// workspace of the plan as run_pl_wgrad executes it (the kg = 1 plan never needs less than the kg = 3 one)
+inline size_t pl_wgrad_plan_bytes(const WgradGeom& p, int ca_out, int npl) {
+  return pl_wgrad_partial_bytes(p, ca_out, max(plan_pl_wgrad(p, npl, false).nsplit, plan_pl_wgrad(p, npl, true).nsplit));
+}
 
-template <int BM, int BN, int WM, int WN, int NPL, bool F16, bool PIPE = false>
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = NPL * (BM + BN) * BK * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
   PlWgradParams q = p;
   q.mt = cdiv(Mp, BM); q.nt = cdiv(p.Cb, BN);
-  static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
-  q.xcd = xcd;
-  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16, PIPE><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
+  igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
   return launch_status();
 }
 
-template <int BN, int WN>
+template <int BN, int WN, int KG>
 int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
-  const int smem = 2 * 3 * (128 + BN) * 16 * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN>),
+  const int smem = KG * 2 * 3 * (128 + BN) * 16 * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN, KG>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
   PlWgradParams q = p;
   q.mt = cdiv(Mp, 128); q.nt = cdiv(p.Cb, BN);
-  static const int xcd = getenv("UNFLOW_XCD_SWIZZLE") ? atoi(getenv("UNFLOW_XCD_SWIZZLE")) : 1;   // A/B knob
-  q.xcd = xcd;
-  igemm_pl_wgrad_dma_kernel<BN, WN><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
+  igemm_pl_wgrad_dma_kernel<BN, WN, KG><<<q.mt * q.nt * p.nsplit, 256 * KG, smem, st>>>(q);
   return launch_status();
 }
 
-inline bool pl_wgrad_dma() {    // UNFLOW_WGRAD_DMA=0: the register-staged kernel (A/B knob)
-  static const bool on = !(getenv("UNFLOW_WGRAD_DMA") && atoi(getenv("UNFLOW_WGRAD_DMA")) == 0);
-  return on;
-}
-
-inline bool pl_wgrad_pipe() {   // UNFLOW_WGRAD_PIPE=1: both slabs' fragments in flight, two waves per SIMD (A/B knob)
-  static const bool on = getenv("UNFLOW_WGRAD_PIPE") && atoi(getenv("UNFLOW_WGRAD_PIPE")) != 0;
-  return on;
-}
-
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
-  p.dbg = pl_dbg();
+  const unflow::Options& opt = unflow::options();
+  p.xcd = opt.xcd_swizzle;
+  p.skip = opt.ntail_skip;
   p.cag_magic = p.Ca == 8 ? 0u : magic_u32((unsigned)(p.Ca >> 3));   // 2^32 / 1 does not fit: 0 marks 'no division'
   const size_t wsize = (size_t)p.KH * p.KW * p.Ca_out * p.Cb;
-  int ns = plan_pl_wgrad(p, npl);
+  const PlWgradPlan plan = plan_pl_wgrad(p, npl);
+  int ns = plan.nsplit;
   if (ns > 1 && (!ws || ws_bytes < pl_wgrad_partial_bytes(p, p.Ca_out, ns))) {
     ns = ws ? (int)min((size_t)REDUCE_FAN, ws_bytes / (wsize * sizeof(float))) : 1;
     if (ns < 1) ns = 1;
@@ -1583,13 +1672,13 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
   *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
   const int cfg = pl_wgrad_cfg(p);
   int code;
-  if (npl == 3 && pl_wgrad_dma()) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32>(p, st) : launch_pl_wgrad_dma<128, 64>(p, st);
-  else if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st)
-                     : pl_wgrad_pipe() ? launch_pl_wgrad<128, 128, 64, 64, 3, false, true>(p, st)
-                                       : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
+  if (npl == 3 && opt.wgrad_dma && plan.kg == 3)
+    code = cfg == 1 ? launch_pl_wgrad_dma<64, 32, 3>(p, st) : launch_pl_wgrad_dma<128, 64, 3>(p, st);
+  else if (npl == 3 && opt.wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32, 1>(p, st) : launch_pl_wgrad_dma<128, 64, 1>(p, st);
+  else if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
   if (code != UNFLOW_OK) return code;
-  if (ns > 1 && !(p.dbg & 64)) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);   // 64: timing experiment
+  if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);
   return UNFLOW_OK;
 }
 
@@ -1714,12 +1803,12 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
     need = max(need, pl_gather_partial_bytes(d, pl_gather_nsplit(d, n_planes)));
   WgradGeom wg{};
   build_conv_wgrad(wg, B, H, W, Ci8, Cout, k, stride);
-  need = max(need, pl_wgrad_partial_bytes(wg, Cin, plan_pl_wgrad(wg, n_planes)));
+  need = max(need, pl_wgrad_plan_bytes(wg, Cin, n_planes));
   if (Cin == 4 && k == 7 && stride == 2 && W % 2 == 0) {   // the two-pixel-granule form of FlowNetC's first layer (rgb4_form)
     g.Cs = 32; g.KW = 1; g.wtaps = 7; g.cls[0].ntx = 1;
     need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
     wg.Ca = 32; wg.KW = 1;
-    need = max(need, pl_wgrad_partial_bytes(wg, 28, plan_pl_wgrad(wg, n_planes)));
+    need = max(need, pl_wgrad_plan_bytes(wg, 28, n_planes));
   }
   if (k == 4 && stride == 2 && H % 2 == 0 && W % 2 == 0) {
     GatherGeom tf{};
@@ -1730,7 +1819,7 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
     need = max(need, pl_gather_partial_bytes(td, pl_gather_nsplit(td, n_planes)));
     WgradGeom tw{};
     build_deconv_wgrad(tw, B, H / 2, W / 2, Cin, Co8);
-    need = max(need, pl_wgrad_partial_bytes(tw, Cout, plan_pl_wgrad(tw, n_planes)));
+    need = max(need, pl_wgrad_plan_bytes(tw, Cout, n_planes));
   }
   return need + 1024;
 }

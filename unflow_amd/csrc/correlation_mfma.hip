@@ -16,6 +16,7 @@
 // Work decomposition: sample index fastest in the block id, so block b runs on XCD b % 8 = its
 // sample when B == 8 and the rows of one sample stay in one XCD's L2.
 #include "igemm_shared.h"
+#include "options.h"
 #include "correlation_geom.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -376,9 +377,8 @@ int corr_mfma_bwd(const float* dout, int ld_dout, const float* in0, const float*
   const int CT = C % 64 == 0 ? 2 : 1;
   const long jobs = (long)(C / (32 * CT)) * B * p.nA * g.s2 * H;
   dim3 grid((unsigned)((jobs + 3) / 4), fuse ? 1 : 2);
-  // default: fp32-equivalent products on the bf16 matrix cores (UNFLOW_CORR_MATH=fp32 / UNFLOW_CONV_MATH=fp32: v_mfma_f32_32x32x2_f32)
-  static const bool b3 = !((getenv("UNFLOW_CORR_MATH") && !strcmp(getenv("UNFLOW_CORR_MATH"), "fp32")) ||
-                           (getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32")));
+  // default: fp32-equivalent products on the bf16 matrix cores (options corr_math_fp32 / conv_math_fp32: v_mfma_f32_32x32x2_f32)
+  const bool b3 = !(unflow::options().corr_math_fp32 || unflow::options().conv_math_fp32);
   if (b3) {
     if (CT == 2) corr_bwd_b3_kernel<2><<<grid, 256, 0, st>>>(p);
     else corr_bwd_b3_kernel<1><<<grid, 256, 0, st>>>(p);

@@ -18,6 +18,7 @@
 // Backward: corr_bwd_pl_kernel (C % 64 == 0), feature operand from the planes by LDS-DMA + transposing reads.
 #include <cstdlib>
 #include "igemm_shared.h"
+#include "options.h"
 #include "correlation_geom.h"
 
 namespace {
@@ -784,20 +785,11 @@ int corr_pl_supported(const CorrGeom& g, int C, const unflow_planes* a, const un
 // into its neighbour tiles, T = ceil(r / 32) Gram tiles on each side.  Narrow band over several tiles (the +-4 cost volume of
 // the north star: r = 4): a tile owns 32 - 2r sites and ONE Gram tile whose columns start r sites to the left covers their
 // whole band — 24 x 9 useful products of 1024 instead of 32 x 9 of 3072.
-static bool corr_nb_enabled() {             // A/B knob: UNFLOW_CORR_NB=0 keeps the streaming kernel in narrow-band mode
-  static const bool on = [] { const char* e = getenv("UNFLOW_CORR_NB"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-static bool corr_wb_enabled() {             // A/B knob: UNFLOW_CORR_WB=0 keeps the streaming kernel for wide bands
-  static const bool on = [] { const char* e = getenv("UNFLOW_CORR_WB"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-static bool corr_bwd_b128_enabled() {       // A/B knob: UNFLOW_CORR_BWD_B128=0 keeps the dword gathers of the band operand
-  static const bool on = [] { const char* e = getenv("UNFLOW_CORR_BWD_B128"); return !(e && e[0] == '0'); }();
-  return on;
-}
+// options corr_nb / corr_wb = 0 keep the streaming kernel in narrow- / wide-band mode; corr_bwd_b128 = 0 keeps the dword
+// gathers of the band operand (A/B switches, options.h)
+static bool corr_nb_enabled() { return unflow::options().corr_nb != 0; }
+static bool corr_wb_enabled() { return unflow::options().corr_wb != 0; }
+static bool corr_bwd_b128_enabled() { return unflow::options().corr_bwd_b128 != 0; }
 
 static void corr_pl_tiles(int nq, int r, int* nA, int* T, int* vr, int* joff) {
   if (nq > 32 && r <= 6) {
@@ -874,8 +866,8 @@ int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const 
   corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
   // rotated row order: HBM reads 1.4x instead of 2.3x / 3.4x algorithmic at both measured shapes, but only the narrow-band
   // shape got faster with it (758 -> 740 us); the step's wide-band shape lost 7-16 % standalone (consumers of a row in
-  // lock-step), so it keeps the natural order.  UNFLOW_CORR_BWD_ROT=0/1 forces it (A/B knob, read per call).
-  { const char* e = getenv("UNFLOW_CORR_BWD_ROT"); p.rot = e ? (e[0] != '0') : (p.joff != 0); }
+  // lock-step), so it keeps the natural order.  Option corr_bwd_rot = 0 / 1 forces it (read per call).
+  { const int e = unflow::options().corr_bwd_rot; p.rot = e >= 0 ? (e != 0) : (p.joff != 0); }
   const size_t dbytes = (((size_t)B * g.oh * g.ow - 1) * (size_t)ld_dout + (size_t)g.gw * g.gw) * 4;
   p.dout_bytes = dbytes < ((size_t)1 << 30) && corr_bwd_b128_enabled() ? (unsigned)dbytes : 0u;
   const int smem = 4 * 3 * 32 * 64 * 2;

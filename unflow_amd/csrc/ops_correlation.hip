@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
+#include "options.h"
 #include "correlation_geom.h"
 
 // ------------------------------------------------------------------ generic forward
@@ -250,9 +251,8 @@ UNFLOW_API int unflow_correlation_nhwc_bwd_pl(const float* dout, int ld_dout, co
   const int st = corr_status(H, W, kernel_size, max_displacement, pad, stride_1, stride_2, &g);
   if (st != UNFLOW_OK) return st;
   if (ld_dout < g.oc) return UNFLOW_ERR_SHAPE;
-  static const bool pl_on = !(getenv("UNFLOW_CORR_BWD_PLANES") && atoi(getenv("UNFLOW_CORR_BWD_PLANES")) == 0) &&
-                            !(getenv("UNFLOW_CORR_MATH") && !strcmp(getenv("UNFLOW_CORR_MATH"), "fp32")) &&
-                            !(getenv("UNFLOW_CONV_MATH") && !strcmp(getenv("UNFLOW_CONV_MATH"), "fp32"));
+  const unflow::Options& opt = unflow::options();
+  const bool pl_on = opt.corr_bwd_planes && !opt.corr_math_fp32 && !opt.conv_math_fp32;
   if (pl_on && C % 64 == 0 && corr_pl_supported(g, C, in0_pl, in1_pl) && corr_pl_fits_32bit(in0_pl, B, H, W, ld_dout, g))
     return corr_pl_bwd(dout, ld_dout, in0_pl, in1_pl, pair_shift, grad0, grad1, ld_grad, accumulate_g1_into_g0, B, C, H, W, g,
                        as_stream(stream));

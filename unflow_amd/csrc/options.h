@@ -1,0 +1,38 @@
+// Process-wide options of libunflow_hip.so: ONE struct, written only through the exported unflow_set_option(name, value)
+// (include/unflow_hip.h) — the library itself never reads the process environment.  The host layer (unflow_amd/_lib.py)
+// sets them once, right after dlopen and before the first launch; an option changed later applies to the launches that
+// follow it (options are read at launch-planning time, never inside a kernel).  Defaults are the measured-best settings
+// on MI355X for FlowNetC 384x512; everything else is an A/B switch kept for the profiles under profiles/.
+#pragma once
+
+#define UNFLOW_OPTION_LIST(X)                                                                                              \
+  X(conv_math_fp32, 0)    /* 1: conv / deconv data paths on v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split */       \
+  X(wgrad_math_fp32, 0)   /* 1: filter gradients on the fp32 MFMA (conv_math_fp32 implies it) */                          \
+  X(corr_math_fp32, 0)    /* 1: correlation on the fp32 MFMA */                                                           \
+  X(gather_min_kt, 8)     /* split-K of the gather kernels: at least this many K32 tiles per split */                     \
+  X(gather_max_split, 16) /* ... and at most this many splits */                                                          \
+  X(wgrad_min_kt, 8)      /* split-K of the filter gradients: at least this many 32-site tiles per split */               \
+  X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
+  X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \
+  X(xcd_swizzle, 1)       /* XCD-contiguous work order */                                                                 \
+  X(xcd_order, -1)        /* force work_decode order 0 / 1 / 2 (-1: per-kernel default) */                                \
+  X(fused_splitk, 0)      /* n > 0: in-kernel split-K reduction for tiles with up to n slices */                          \
+  X(wgrad_dma, 1)         /* LDS-DMA filter-gradient kernel (0: register-staged) */                                       \
+  X(wgrad_kgroups, 1)     /* 1: 768-thread filter-gradient blocks whose 3 K groups combine through LDS */                 \
+  X(wgrad_kg_min_fill, 75) /* ... used when they fill at least this % of the CUs in one round */                          \
+  X(ntail_skip, 1)        /* skip the MFMAs of 32-column sub-tiles that lie wholly beyond N */                            \
+  X(corr_nb, 1)           /* narrow-band correlation forward kernel */                                                    \
+  X(corr_wb, 1)           /* wide-band correlation forward kernel */                                                      \
+  X(corr_bwd_b128, 1)     /* 16-byte band loads in the correlation backward */                                            \
+  X(corr_bwd_rot, -1)     /* rotated displacement-row order in the correlation backward (-1: narrow band only) */         \
+  X(corr_bwd_planes, 1)   /* correlation backward from the feature planes */
+
+namespace unflow {
+struct Options {
+#define X(name, def) int name = def;
+  UNFLOW_OPTION_LIST(X)
+#undef X
+};
+// the one instance (options.hip); plain ints, set before the first launch
+Options& options();
+}  // namespace unflow

@@ -3,6 +3,7 @@
 // fused TF-form Adam (train.py:151-152) and the EPE sums (flow_util.py:98-103).  All HBM-bound
 // streaming kernels: 16-byte accesses, grid-stride, >= 2048 workgroups when the data allows.
 #include "common.h"
+#include "igemm_shared.h"
 
 UNFLOW_API const char* unflow_status_string(int status) {
   switch (status) {
@@ -42,6 +43,74 @@ UNFLOW_API int unflow_prepare_images(const float* im_u8range, float* net_in4, fl
   const float m0 = mean3[0] / 255.0f, m1 = mean3[1] / 255.0f, m2 = mean3[2] / 255.0f;
   prepare_images_kernel<<<stream_grid(npix), 256, 0, as_stream(stream)>>>(im_u8range, net_in4, out01, m0, m1, m2, npix);
   return launch_status();
+}
+
+// Both frames of the minibatch in one pass (im1 = samples [0, B), im2 = [B, 2B) of the directed batch), optionally with the
+// 16-bit operand planes of the network input (csrc/conv_planes.hip: conv1 reads planes) — the step's input preparation is
+// this one launch.
+__global__ void prepare_image_pair_kernel(const float* __restrict__ im1, const float* __restrict__ im2, long npix_each,
+                                          float* __restrict__ net4, float* __restrict__ out01, float m0, float m1, float m2,
+                                          igemm::PlaneOut pl) {
+  const long npix = 2 * npix_each;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float* im = i < npix_each ? im1 + 3 * i : im2 + 3 * (i - npix_each);
+    const float r = im[0] / 255.0f, g = im[1] / 255.0f, b = im[2] / 255.0f;
+    const float4 v = make_float4(r - m0, g - m1, b - m2, 0.f);
+    reinterpret_cast<float4*>(net4)[i] = v;
+    if (out01) {
+      out01[3 * i] = r;
+      out01[3 * i + 1] = g;
+      out01[3 * i + 2] = b;
+    }
+    igemm::store_planes4(pl, (size_t)i, 0, v);
+  }
+}
+
+UNFLOW_API int unflow_prepare_image_pair(const float* im1, const float* im2, long npix_each, float* net_in4, float* out01,
+                                         const float* mean3, const unflow_planes* net_pl, unflow_stream_t stream) {
+  if (!im1 || !im2 || !net_in4 || !mean3) return UNFLOW_ERR_NULL;
+  if (npix_each <= 0) return UNFLOW_OK;
+  igemm::PlaneOut pl{};
+  if (net_pl && net_pl->base) {
+    if ((net_pl->n_planes != 1 && net_pl->n_planes != 3) || net_pl->ld < 4 || net_pl->ld % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(net_pl->base) & 7) != 0)
+      return UNFLOW_ERR_UNSUPPORTED;
+    pl.base = reinterpret_cast<unsigned short*>(net_pl->base);
+    pl.plane_stride = net_pl->plane_stride;
+    pl.ld = net_pl->ld; pl.lo = 0; pl.hi = 4; pl.n_planes = net_pl->n_planes;
+  }
+  const float m0 = mean3[0] / 255.0f, m1 = mean3[1] / 255.0f, m2 = mean3[2] / 255.0f;
+  prepare_image_pair_kernel<<<stream_grid(2 * npix_each), 256, 0, as_stream(stream)>>>(im1, im2, npix_each, net_in4, out01, m0,
+                                                                                     m1, m2, pl);
+  return launch_status();
+}
+
+// ---- the few elementwise helpers the step driver needs between kernels (buffers stay caller-owned torch tensors, but no
+// torch compute kernel runs inside a step): y = s * x;  y *= x;  y += x;  zero-fill / copy as stream-ordered memset / memcpy
+__global__ void ew_kernel(const float* __restrict__ x, float* __restrict__ y, float s, long n, int op) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float a = x[i];
+    y[i] = op == 0 ? s * a : op == 1 ? y[i] * a : y[i] + a;
+  }
+}
+static int ew_launch(const float* x, float* y, float s, long n, int op, unflow_stream_t stream) {
+  if (!x || !y) return UNFLOW_ERR_NULL;
+  if (n <= 0) return UNFLOW_OK;
+  ew_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(x, y, s, n, op);
+  return launch_status();
+}
+UNFLOW_API int unflow_scale(const float* x, float s, float* y, long n, unflow_stream_t stream) { return ew_launch(x, y, s, n, 0, stream); }
+UNFLOW_API int unflow_mul_inplace(float* y, const float* x, long n, unflow_stream_t stream) { return ew_launch(x, y, 1.f, n, 1, stream); }
+UNFLOW_API int unflow_add_inplace(float* y, const float* x, long n, unflow_stream_t stream) { return ew_launch(x, y, 1.f, n, 2, stream); }
+UNFLOW_API int unflow_zero(void* p, size_t bytes, unflow_stream_t stream) {
+  if (!p) return UNFLOW_ERR_NULL;
+  if (bytes == 0) return UNFLOW_OK;
+  return hipMemsetAsync(p, 0, bytes, as_stream(stream)) == hipSuccess ? UNFLOW_OK : UNFLOW_ERR_LAUNCH;
+}
+UNFLOW_API int unflow_copy(void* dst, const void* src, size_t bytes, unflow_stream_t stream) {
+  if (!dst || !src) return UNFLOW_ERR_NULL;
+  if (bytes == 0) return UNFLOW_OK;
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)) == hipSuccess ? UNFLOW_OK : UNFLOW_ERR_LAUNCH;
 }
 
 // TF1 legacy bilinear: src = dst * (in/out); lo = floor(src); hi = min(lo+1, in-1); lerp x then y.
