@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the UNFLOW_CONV_MATH=fp32 re-measurement (a sub-process)")
     ap.add_argument("--no-parity", action="store_true", help="skip the step-1 loss/flow comparison with the CPU oracle")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the two secondary configs (BASELINE configs[3] CSS 768x1024 B=2 and configs[4] fp16 B=8: sub-processes)")
+    ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the second timing pass without the all-reduce")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 (default): fp32-equivalent arithmetic (UNFLOW_CONV_MATH picks the kernels); f16: fp16 activations "
                          "and weights into the fp16 MFMA with fp32 accumulation (BASELINE configs[4], use --batch 8)")
@@ -106,6 +109,8 @@ def main():
     force_dist = os.environ.get("UNFLOW_FORCE_REDUCER") == "1" and "RANK" in os.environ   # test knob
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "INFO":      # the comm record quotes RCCL's algorithm / protocol lines
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/unflow_rccl_%h_%p.log")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -197,11 +202,14 @@ def main():
         out["parity"] = parity
     if world > 1 or force_dist:
         out["rccl_world_size"] = dist.get_world_size()      # the rank count the RCCL communicator reports
+        out["comm"] = measure_comm(runner, eng, step, barrier, args, world, ms, dev, dist)
 
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = measure_roofline(eng, args)
     if rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C' and eng.math in ("bf16x3", "bf16x3_inline"):
         out["value_fp32_mfma_only"] = measure_alt_fp32(args)      # same step with every conv kernel on the fp32 MFMA
+    if rank == 0 and world == 1 and not args.no_secondary and (args.flownet, args.dtype, H, W) == ('C', 'f32', 384, 512):
+        out["secondary"] = measure_secondary(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.flownet == 'C':
         out["cpu_baseline"] = measure_cpu_baseline(H, W)
         if out["cpu_baseline"]["value"]:
@@ -300,6 +308,88 @@ def measure_roofline(eng, args):
             "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
 
 
+def measure_comm(runner, eng, step, barrier, args, world, ms_with, dev, dist):
+    """What the gradient exchange costs, measured inside this run: the same K steps once more with the collectives skipped
+    (GradAllReducer.dry: identical stream choreography, bucketed Adam + weight re-split still on the communication stream), so
+    allreduce_ms_exposed = ms/step with the exchange - ms/step without = the part of the all-reduce the backward pass and the
+    optimizer did not hide.  bytes_per_step = the fp32 gradient bytes every rank contributes (frozen stages excluded:
+    train.py:388-422 skips None gradients).  With NCCL_DEBUG=INFO the RCCL log lines naming algorithm / protocol are attached
+    (a ring over xGMI is per-link bound, ~1.8 ms for 157 MB at 8 ranks; direct reduce-scatter + all-gather ~0.26)."""
+    import torch
+    red = runner.reducer
+    ranges = [r for part in runner.buckets for r in part]
+    nbytes = 4 * sum(hi - lo for lo, hi in ranges)
+    sub = sum((hi - lo + red.per - 1) // red.per for lo, hi in ranges)
+    out = {"bytes_per_step": nbytes, "buckets": len(runner.buckets), "collectives_per_step": sub,
+           "bucket_bytes": [4 * sum(hi - lo for lo, hi in part) for part in runner.buckets],
+           "sub_bucket_bytes_max": red.per * 4, "backward_parts": runner.nparts,
+           "overlap": "all-reduce of a part's gradients + their fused L2/Adam + weight re-split run on a communication stream "
+                      "under the remaining backward parts (unflow_amd/core/train.py)",
+           "env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG", "RCCL_MSCCL_ENABLE") if k in os.environ}}
+    if not args.no_comm:
+        red.dry = True
+        try:
+            for _ in range(2):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            dd = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dd], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dd = tmax.item()
+        finally:
+            red.dry = False
+        ms_dry = dd / args.steps * 1e3
+        out.update(ms_per_step_without_allreduce=round(ms_dry, 4), allreduce_ms_exposed=round(ms_with - ms_dry, 4),
+                   note="the parameters of the ranks diverge during the dry pass (no exchange); it runs after every timed figure")
+    log = os.environ.get("NCCL_DEBUG_FILE")
+    if os.environ.get("NCCL_DEBUG", "").upper() == "INFO" and log:
+        try:
+            import glob
+            import re
+            lines = []
+            for f in glob.glob(re.sub(r"%[hp]", "*", log)):
+                for ln in open(f, errors="ignore"):
+                    if re.search(r"[Aa]lgo|[Pp]roto|Ring|Tree|Direct|channels", ln) and len(lines) < 12:
+                        lines.append(ln.strip()[:240])
+            out["rccl_info"] = lines
+        except Exception as e:
+            out["rccl_info"] = "failed: %r" % (e,)
+    return out
+
+
+def measure_secondary(args):
+    """BASELINE configs[3] and configs[4] in the driver's own line: each the same script in a sub-process (own roofline leg,
+    no CPU baseline / fp32 re-measurement / sustained pass), reduced to the fields a reader needs."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--no-cpu-baseline", "--no-alt", "--no-parity", "--no-secondary", "--sustain-seconds", "0"]
+    cfgs = [("FlowNetCSS 768x1024 B=2 (BASELINE configs[3]; last network trained, the two in front frozen)",
+             ["--flownet", "CSS", "--batch", "2", "--height", "768", "--width", "1024"], None),
+            ("FlowNetC f16 B=8 384x512 (BASELINE configs[4])", ["--dtype", "f16", "--batch", "8"],
+             "vs the fp32 oracle: loss rel <= 1e-2, final-flow EPE <= 5e-2 px, per-tensor gradient max-rel <= 3e-2 "
+             "(tests/test_f16_gpu.py); the reference has no fp16 path (ops are float-only, correlation_op.cc:134-135)")]
+    out = []
+    for name, extra, tol in cfgs:
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+            rf = d.get("roofline") or {}
+            e = {"config": name, "dtype": d["dtype"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                 "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "algorithmic_gflop_per_step",
+                                                     "ms_per_step_in_kernel_class")}}
+            if tol:
+                e["tolerance"] = tol
+            out.append(e)
+        except Exception as ex:
+            out.append({"config": name, "value": None, "error": repr(ex)[:300]})
+    return out
+
+
 def measure_alt_fp32(args):
     """image-pairs/s of the same step with UNFLOW_CONV_MATH=fp32 (the library reads the knob once per process, so this
     is a sub-process of this script)."""
@@ -307,7 +397,7 @@ def measure_alt_fp32(args):
     env = dict(os.environ, UNFLOW_CONV_MATH="fp32")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch",
            str(args.batch), "--height", str(args.height), "--width", str(args.width), "--no-cpu-baseline", "--no-roofline",
-           "--no-alt", "--no-parity", "--sustain-seconds", "0"] + (["--no-graph"] if args.no_graph else [])
+           "--no-alt", "--no-parity", "--no-secondary", "--sustain-seconds", "0"] + (["--no-graph"] if args.no_graph else [])
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]

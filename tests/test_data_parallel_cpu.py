@@ -201,3 +201,41 @@ def test_engine_buckets_cover_the_gradient_once_and_reduce_to_the_sum(tmp_path):
     # the first bucket is the big one (decoder + conv6_1 + conv6): it leaves while two thirds of the backward pass remain
     (lo, hi), = r[0]['buckets'][0]
     assert (hi - lo) * 4 > 100e6
+
+
+@pytest.mark.parametrize("spec, extra, cuts", [
+    ('C', {}, ('conv6', 'conv4')), ('C', {}, ()), ('CS', {}, ('conv6', 'conv4')), ('CSS', {}, ('conv6', 'conv4')),
+    ('CS', dict(train_all=True), ()), ('S', dict(full_res=True), ('conv6', 'conv4')), ('cs', {}, ('conv4',)),
+])
+def test_part_buckets_and_frozen_ranges_partition_the_parameters(spec, extra, cuts):
+    """part_buckets() (what is all-reduced and updated after each backward part) + frozen_ranges() (updated with the L2 term
+    only, nothing to exchange) cover [0, n_params) exactly once, for every way StepRunner cuts a spec (train.py:163-183:
+    every variable gets exactly one averaged gradient and one optimizer update)."""
+    from unflow_amd.core.engine import FlowNetEngine
+    eng = FlowNetEngine(1, 64, 64, params=dict(flownet=spec, **extra), device='cpu', layout_only=True)
+    nparts = eng.set_backward_parts(() if eng.train_all else cuts)
+    buckets, frozen = eng.part_buckets(), eng.frozen_ranges()
+    assert len(buckets) == nparts == len(cuts if not eng.train_all else ()) + 1
+    seen = torch.zeros(eng.n_params, dtype=torch.int32)
+    for part in buckets:
+        for lo, hi in part:
+            assert 0 <= lo < hi <= eng.n_params
+            seen[lo:hi] += 1
+    for lo, hi in frozen:
+        seen[lo:hi] += 1
+    assert torch.all(seen == 1)
+    assert bool(frozen) == (len(spec) > 1 and not eng.train_all)
+    # every weight tensor lies wholly inside ONE range (a bucket never cuts a tensor: its Adam update is one launch range)
+    ranges = [r for part in buckets for r in part] + frozen
+    for l in eng.layers:
+        lo = (l.dw.data_ptr() - eng.G.data_ptr()) // 4
+        assert any(a <= lo and lo + l.dw.numel() <= b for a, b in ranges), l.name
+    # the gradients of a part are those of the layers its backward slice runs (final when the part returns)
+    st = eng.stages[-1]
+    if not eng.train_all:
+        for k in range(nparts):
+            lo, hi = st.part_weight_range(k)
+            names = [op.l.name for op, _, _, _ in st.bwd[st.part_bounds[k]:st.part_bounds[k + 1]] if op.kind == 'layer']
+            for l in st.layers:
+                inside = lo <= (l.dw.data_ptr() - eng.G.data_ptr()) // 4 < hi
+                assert inside == (l.name in names), (k, l.name)

@@ -30,6 +30,7 @@ class GradAllReducer:
         self.bounds = [(i, min(n, i + per)) for i in range(0, n, per)]
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.dry = False        # measurement switch (bench.py comm record): reduce_then keeps its stream order but skips the collectives
 
     def all_reduce(self):
         """SUM over ranks, in place (scale by 1/world in the optimizer).  Returns after enqueueing; the
@@ -89,8 +90,9 @@ class GradAllReducer:
         cur = torch.cuda.current_stream(self.g.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            works = [dist.all_reduce(self.g[a:min(hi, a + self.per)], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                     for lo, hi in ranges for a in range(lo, hi, self.per)]
+            works = [] if self.dry else [
+                dist.all_reduce(self.g[a:min(hi, a + self.per)], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                for lo, hi in ranges for a in range(lo, hi, self.per)]
             for w in works:
                 w.wait()          # stream-level: the side stream waits for the collective, the host does not
             fn()
