@@ -44,7 +44,7 @@ for spec in ('C', 'CS'):
         res.append((eng.P.clone(), eng.M.clone(), eng.V.clone(), losses))
     (p0, m0, v0, l0), (p1, m1, v1, l1) = res
     assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), "bucketed path differs (%%s)" %% spec
-    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(l0, l1)), (spec, l0, l1)
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (spec, l0, l1)    # (the L2 loss term is summed per bucket: float-atomic order)
     assert l0[-1] != l0[0]
 dist.barrier(); dist.destroy_process_group()
 print("NCCL_WORLD1_OK", l0)

@@ -38,26 +38,74 @@ def load_params_npz(path):
     return out
 
 
+def load_params(path):
+    """Variables of one saved network as {name: float32 tensor}: `path` is an .npz (save_params_npz), a TF checkpoint-V2
+    prefix (`model.ckpt-70000`, read by core/tf_checkpoint.py without TensorFlow) or an experiment directory holding a
+    `checkpoint` state file (what util.py:75-85 / experiment.py hand to train.py:48-64).  Optimizer slots
+    ('.../Adam', '.../Adam_1'), beta powers and global_step are dropped: only conv weights and biases are returned."""
+    import os
+    from . import tf_checkpoint as T
+    if path.endswith('.npz'):
+        return load_params_npz(path)
+    prefix = path
+    if os.path.isdir(path):
+        prefix = T.latest_checkpoint(path)
+        if prefix is None:
+            raise FileNotFoundError("no `checkpoint` state file in %s" % path)
+    if not os.path.exists(prefix + '.index'):
+        raise FileNotFoundError("%s: neither an .npz nor a checkpoint prefix (no %s.index)" % (path, prefix))
+    out = OrderedDict()
+    for k, v in T.read_checkpoint(prefix).items():
+        if k.endswith('/weights') or k.endswith('/biases'):
+            out[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
+
+
+def network_scope(i):
+    """Variable-name prefixes of network i of a spec (flownet.py:72-77, train.py:29): the first network's variables live
+    under 'flownet_c' / 'flownet_c_features' (a FlowNetC) or 'flownet_s' (a FlowNetS), the others under 'stack_<i>_flownet/'."""
+    return ('flownet_c', 'flownet_s') if i == 0 else ('stack_%d_flownet/' % i,)
+
+
 def restore_networks(engine, params, net_files):
-    """restore_networks (core/train.py:23-65) for .npz files: net_files[i] holds the variables of network i of the spec
-    ('flownet_c*' for the first, 'stack_<i>_flownet/' for the others); networks without a file keep their
-    initialisation.  Like the reference's fallback (:56-63), 'full_res' variables missing from a file keep theirs."""
+    """restore_networks (core/train.py:23-65): net_files[i] holds the variables of network i of the engine's spec — an .npz,
+    a TF checkpoint prefix or an experiment directory (load_params); networks without a file keep their initialisation.
+    Every variable of a restored network must be in its file with the network's shape — except, exactly like the reference's
+    second attempt (:56-63: `if not 'full_res' in v.name`), the 'full_res' variables, which keep their initialisation when
+    the file predates them.  Anything else missing raises, as tf.train.Saver.restore does."""
     cur = engine.export_tf_params()
-    spec = params.get('flownet', 'S')
+    spec = engine.spec
+    if len(net_files) > len(spec):
+        raise ValueError("%d files for the %d networks of spec %r (train.py:31: len(finetune) <= flownet_num)"
+                         % (len(net_files), len(spec), spec))
     for i, f in enumerate(net_files):
-        if f is None or i >= len(spec):
+        if f is None:
             continue
-        scope = ('flownet_c', 'flownet_s') if i == 0 else ('stack_%d_flownet/' % i,)
-        loaded = load_params_npz(f)
-        for k, v in loaded.items():
-            if k.startswith(scope):
-                if k not in cur:
-                    raise KeyError("variable %s of %s is not part of spec %r" % (k, f, spec))
+        scope = network_scope(i)
+        loaded = load_params(f)
+        want = [k for k in cur if k.startswith(scope)]
+        missing = [k for k in want if k not in loaded]
+        hard = [k for k in missing if 'full_res' not in k]
+        if hard:
+            raise KeyError("%s lacks %d variable(s) of network %d of spec %r, e.g. %s" % (f, len(hard), i, spec, hard[0]))
+        for k in want:
+            if k in loaded:
+                v = loaded[k]
                 if tuple(v.shape) != tuple(cur[k].shape):
                     raise ValueError("%s: shape %s in %s, %s in the network" % (k, tuple(v.shape), f, tuple(cur[k].shape)))
                 cur[k] = v
     engine.load_tf_params(cur)
     return cur
+
+
+def save_checkpoint(prefix, tf_params, global_step=None):
+    """Write parameters as a TF checkpoint-V2 bundle under the reference's variable names (readable by tf.train.Saver.restore
+    of the reference graph, train.py:40-44)."""
+    from . import tf_checkpoint as T
+    t = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in tf_params.items()}
+    if global_step is not None:
+        t['global_step'] = np.asarray(global_step, dtype=np.int64)
+    T.write_checkpoint(prefix, t)
 
 
 # ----------------------------------------------------------------------------------------------------------- .flo
@@ -105,6 +153,8 @@ def decode_png(data):
             idat.append(body)
         elif typ == b'IEND':
             break
+    if hdr is None:
+        raise ValueError("PNG without an IHDR chunk")
     w, h, depth, ctype, _, _, interlace = hdr
     if interlace or depth not in (8, 16) or ctype not in (0, 2, 6):
         raise NotImplementedError("PNG variant (depth %d, colour type %d, interlace %d)" % (depth, ctype, interlace))
@@ -112,27 +162,40 @@ def decode_png(data):
     bpp = ch * depth // 8
     stride = w * bpp
     raw = zlib.decompress(b''.join(idat))
-    out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
+    if len(raw) < h * (stride + 1):
+        raise ValueError("truncated PNG image data")
+    out = np.zeros((h, w, bpp), dtype=np.uint8)
+    prev = np.zeros((w, bpp), dtype=np.int32)
+    zero = np.zeros(bpp, dtype=np.int32)
     for y in range(h):
         ft = raw[y * (stride + 1)]
-        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32)
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32).reshape(w, bpp)
         if ft == 0:
             cur = line
-        elif ft == 2:
+        elif ft == 1:      # Sub: every byte lane of a pixel is a running sum along the row (mod 256)
+            cur = np.cumsum(line, axis=0) & 255
+        elif ft == 2:      # Up
             cur = (line + prev) & 255
-        elif ft == 1 or ft == 3 or ft == 4:
-            cur = np.zeros(stride, dtype=np.int32)
-            for i in range(stride):
-                a = cur[i - bpp] if i >= bpp else 0
-                b = prev[i]
-                c = prev[i - bpp] if i >= bpp else 0
-                pred = a if ft == 1 else ((a + b) >> 1 if ft == 3 else _paeth(a, b, c))
-                cur[i] = (line[i] + pred) & 255
+        elif ft == 3 or ft == 4:
+            # Average / Paeth depend on the pixel to the left: one step per PIXEL, all bpp byte lanes of it at once (a KITTI
+            # flow map is 1242 x 6 bytes per row: 1242 short vector steps instead of 7452 interpreted byte steps)
+            cur = np.empty((w, bpp), dtype=np.int32)
+            a, c = zero, zero
+            for x in range(w):
+                b_ = prev[x]
+                if ft == 3:
+                    pred = (a + b_) >> 1
+                else:
+                    pa, pb, pc = np.abs(b_ - c), np.abs(a - c), np.abs(a + b_ - 2 * c)
+                    pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b_, c))
+                a = (line[x] + pred) & 255
+                cur[x] = a
+                c = b_
         else:
             raise ValueError("bad PNG filter %d" % ft)
         out[y] = cur
         prev = cur
+    out = out.reshape(h, stride)
     if depth == 16:
         return out.reshape(h, w, ch, 2).astype(np.uint16).dot(np.array([256, 1], dtype=np.uint16)).astype(np.uint16)
     return out.reshape(h, w, ch)

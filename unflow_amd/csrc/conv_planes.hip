@@ -63,9 +63,12 @@ struct PlGatherParams : GatherGeom {
 
 // LDS bytes of one gather block: the operand tiles, or (larger for n_planes == 1) the four wave-private staging areas of
 // the epilogue (32 rows x (WN + 4) floats each); the destination-pixel table follows.
-constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
-  const int tiles = npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4;
-  return tiles > stage ? tiles : stage;
+// With kg K groups (the 768-thread form of the gather kernel) every group has its own tiles, and the groups' accumulators
+// meet in (kg - 1) x BM x BN floats of the same memory after the K loop.
+constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl, int kg = 1) {
+  const int tiles = kg * npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4, red = (kg - 1) * bm * bn * 4;
+  const int m = tiles > stage ? tiles : stage;
+  return m > red ? m : red;
 }
 
 // (xcd_remap: igemm_shared.h)
@@ -280,8 +283,13 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
 // stage, 118 registers.  A K16 stage of a gathered operand is 32 bytes per row: conv2 / conv3 forward 261 -> 326 us,
 // 251 -> 329 us, stride-2 data gradients 142 -> 173 us, the step 598 -> 570 image-pairs/s.  The 64-byte row pieces of a
 // K32 tile are the smallest unit the L1 / TA path moves efficiently; two K32 stages are 96 KB of LDS, one block per CU.)
-template <int BM, int BN, int WM, int WN, int NPL, bool F16>
-__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_gather_kernel(const PlGatherParams p) {
+// K groups (KG = 3): the same idea as in igemm_pl_wgrad_dma_kernel for the layers that split K because they have few output
+// tiles (conv4 .. conv6_1, the decoder's deep deconvs and their data gradients): a 768-thread workgroup = three 4-wave groups
+// with their own operand tiles that own the SAME output tile and consecutive thirds of the block's K range; after the loop
+// groups 1 and 2 hand their accumulators to group 0 through LDS and ONE partial (or, when the layer then no longer splits,
+// the final result with its epilogue) is written: a third of the split-K partial traffic, 12 resident waves per CU as before.
+template <int BM, int BN, int WM, int WN, int NPL, bool F16, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && BN == 128) ? 3 : 1)) void igemm_pl_gather_kernel(const PlGatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
@@ -291,11 +299,12 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   constexpr int NT = NPL == 3 ? 6 : 1;           // product terms per K16 slab
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  unsigned short* Ah = smem16;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;                       // within the K group
+  const int grp = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));    // K group of this wave
+  unsigned short* Ah = smem16 + grp * (NPL * (A_PLANE + B_PLANE));
   unsigned short* Bh = Ah + NPL * A_PLANE;
-  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_gather_main_bytes(BM, BN, WN, NPL));
+  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_gather_main_bytes(BM, BN, WN, NPL, KG));
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   int mtile, ntile, cls_id, split;
   work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, mtile, ntile, cls_id, split);
@@ -308,8 +317,9 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   const int Kg = ntaps * Cg;
   const int KT = (Kg + 3) >> 2;
   const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
-  const int kt0 = split * kt_per;
-  const int kt1 = min(KT, kt0 + kt_per);
+  const int bk0 = split * kt_per, bk1 = min(KT, bk0 + kt_per);       // the block's K tiles
+  const int per = (max(bk1 - bk0, 0) + KG - 1) / KG;                  // ... cut into KG runs; every group iterates `per` times
+  const int kt0 = bk0 + grp * per, kt1 = min(bk1, kt0 + per);         // (tiles past kt1 are zeros)
 
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
       a_lin[i] = OOB_MARK;   // rows past M: every load out of range (zeros)
     }
   }
-  if (tid < BM) {
+  if (threadIdx.x < BM) {
     int b, yg, xg, v = -1;
     if (site_of(tid, b, yg, xg)) v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
     pix[tid] = v;
@@ -487,8 +497,8 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
       }
     }
   };
-  for (int kt = kt0; kt < kt1; kt++) {
-    live = kt + 1 < kt1;
+  for (int it = 0; it < per; it++) {
+    live = kt0 + it + 1 < kt1;
     if (full) mfma_tile(std::false_type{});
     else mfma_tile(std::true_type{});
     __syncthreads();  // every wave is done reading this tile
@@ -496,10 +506,49 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
     __syncthreads();
   }
 
+  if constexpr (KG > 1) {
+    // every tile is idle (the loop's last barrier): groups 1 .. KG-1 park their accumulators — [group - 1][wave][sub-tile]
+    // [4 x float4][lane], 16-byte stores, lanes 16 bytes apart — and group 0 adds them in group order.  The second barrier
+    // keeps the parked values intact until every wave of group 0 has read them (its epilogue stages through the same memory).
+    float4* red = reinterpret_cast<float4*>(smem16);
+    constexpr int PER_WAVE = TM * TN * 4 * 64;
+    if (grp > 0) {
+      float4* d = red + (size_t)((grp - 1) * 4 + wid) * PER_WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            d[((i * TN + j) * 4 + q) * 64] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int g = 1; g < KG; g++) {
+        const float4* s = red + (size_t)((g - 1) * 4 + wid) * PER_WAVE + lane;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const float4 t = s[((i * TN + j) * 4 + q) * 64];
+              acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
+            }
+            asm volatile("" ::: "memory");
+          }
+      }
+    }
+    __syncthreads();
+    if (grp > 0) return;
+  }
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
-  if (p.fused_splitk) {
-    if (!splitk_last_arriver(p, (cls_id * p.mt + mtile) * p.nt + ntile, pix + BM)) return;
-    splitk_tile_reduce<BM, BN>(p, pix, n0);
+  if constexpr (KG == 1) {
+    if (p.fused_splitk) {
+      if (!splitk_last_arriver(p, (cls_id * p.mt + mtile) * p.nt + ntile, pix + BM)) return;
+      splitk_tile_reduce<BM, BN>(p, pix, n0);
+    }
   }
 }
 
@@ -1389,9 +1438,12 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b)
 struct PlPlan {
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
   int nsplit;
+  int kg;   // K groups per workgroup: 1, or 3 (768 threads; cfg 0 only)
 };
 
-inline int pl_smem_gather(int bm, int bn, int npl) { return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl) + bm * 4 + 16; }   // + the pixel table + the split-K flag
+inline int pl_smem_gather(int bm, int bn, int npl, int kg = 1) {   // + the pixel table + the split-K flag
+  return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl, kg) + bm * 4 + 16;
+}
 
 // blocks per CU by LDS (160 KB) and registers (<= 168: 3 waves per SIMD)
 inline int pl_blocks_per_cu(int bm, int bn, int npl) {
@@ -1400,8 +1452,9 @@ inline int pl_blocks_per_cu(int bm, int bn, int npl) {
   return byl < byr ? byl : byr;
 }
 
-inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
+inline PlPlan plan_pl_gather(const GatherGeom& p, int npl, bool allow_kg = true) {
   PlPlan pl;
+  pl.kg = 1;
   const long M = (long)p.B * p.Hg * p.Wg;
   if (p.N <= 32) pl.cfg = 2;
   else if (p.N <= 64) pl.cfg = 1;
@@ -1419,6 +1472,13 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   const int slots = 256 * pl_blocks_per_cu(bm, bn, npl);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
+  // K groups: when the layer splits anyway and one round of 768-thread workgroups (one per CU) fills enough of the chip
+  const unflow::Options& opt = unflow::options();
+  if (allow_kg && npl == 3 && opt.gather_kgroups && pl.cfg == 0 && pl.nsplit >= 2 && blocks <= 256) {
+    const int by_k = max(1, KT / (3 * max(1, opt.gather_kg_min_kt)));
+    const int ns3 = (int)min((long)by_k, 256 / blocks);
+    if (blocks * ns3 * 100 >= 256L * opt.gather_kg_min_fill) { pl.nsplit = ns3; pl.kg = 3; }
+  }
   return pl;
 }
 
@@ -1459,11 +1519,11 @@ inline void pl_gather_tiles2d(PlGatherParams& q) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+template <int BM, int BN, int WM, int WN, int NPL, bool F16, int KG = 1>
 int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
-  const int smem = pl_smem_gather(BM, BN, NPL);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16>),
+  const int smem = pl_smem_gather(BM, BN, NPL, KG);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16, KG>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
   PlGatherParams q = p;
@@ -1471,12 +1531,15 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   pl_gather_tiles2d<BM>(q);
   const int grid = pl_grid(q);
   if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
-  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q);
+  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16, KG><<<grid, 256 * KG, smem, st>>>(q);
   return launch_status();
 }
 
 template <int NPL, bool F16>
-int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
+int run_pl_gather_mode(PlGatherParams& p, int cfg, int kg, hipStream_t st) {
+  if constexpr (NPL == 3) {
+    if (cfg == 0 && kg == 3) return launch_pl_gather<128, 128, 64, 64, NPL, F16, 3>(p, st);
+  }
   switch (cfg) {
     case 0: return launch_pl_gather<128, 128, 64, 64, NPL, F16>(p, st);
     case 1: return launch_pl_gather<128, 64, 64, 32, NPL, F16>(p, st);
@@ -1565,7 +1628,8 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     // 0.69 ms of the step (no-reduce ablation): what they cost is the second pass over the partials, which
     // one block per tile does no faster than 256 CUs.  Kept as a tested alternative.
     const int fused = opt.fused_splitk;
-    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu;
+    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu &&
+                     (halo || pl.kg == 1);
     p.counters = p.fused_splitk ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pl_gather_slab_bytes(p, p.nsplit)) : nullptr;
   }
   int code;
@@ -1573,7 +1637,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
     else code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
   } else {
-    code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
+    code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, pl.kg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, 1, st);
   }
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1 && !p.fused_splitk) {
@@ -1785,7 +1849,7 @@ UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const 
 
 static int pl_gather_nsplit(const GatherGeom& g, int npl) {
   int bn;
-  return pl_halo_ok(g) ? plan_pl_halo(g, npl, &bn) : plan_pl_gather(g, npl).nsplit;
+  return pl_halo_ok(g) ? plan_pl_halo(g, npl, &bn) : plan_pl_gather(g, npl, false).nsplit;   // (the K-group plan never splits more)
 }
 
 UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes) {
