@@ -397,7 +397,7 @@ def test_library_options_roundtrip(dev):
     """unflow_set_option / unflow_get_option: every name of unflow_option_names round-trips; unknown names are refused."""
     from unflow_amd import _lib
     names = _lib.option_names()
-    assert "conv_math_fp32" in names and "wgrad_kgroups" in names
+    assert "conv_math_fp32" in names and "fused_splitk" in names
     for n in names:
         v = _lib.get_option(n)
         _lib.set_option(n, v)
@@ -405,21 +405,20 @@ def test_library_options_roundtrip(dev):
     assert _lib.lib().unflow_set_option(b"no_such_option", 1) == -7
 
 
-# (B, H, W, Cin, Cout, k, stride, deconv): filter gradients whose plan uses the 768-thread K-group workgroups
-KGROUP_CASES = [
-    (8, 96, 128, 128, 256, 5, 2, False),   # conv3: 50 tiles, 5 splits x 3 K groups
-    (8, 48, 64, 476, 256, 3, 1, False),    # conv3_1: 68 tiles (last M tile 96 of 128 rows), 3 splits
-    (8, 192, 256, 64, 128, 5, 2, False),   # conv2: 13 tiles, 19 splits
-    (8, 48, 64, 388, 64, 4, 2, True),      # deconv2: N = 388 (4 real columns in the last N tile), BN = 128
+# (B, H, W, Cin, Cout, k, stride, deconv): filter gradients at the step's split-K plans
+WGRAD_CASES = [
+    (8, 96, 128, 128, 256, 5, 2, False),   # conv3: 50 tiles x 15 splits
+    (8, 48, 64, 476, 256, 3, 1, False),    # conv3_1: 68 tiles (last M tile 96 of 128 rows)
+    (8, 192, 256, 64, 128, 5, 2, False),   # conv2: 13 tiles x 59 splits (two-level partial sums)
+    (8, 48, 64, 388, 64, 4, 2, True),      # deconv2-like: N = 388 (4 real columns in the last N tile)
     (2, 40, 56, 72, 40, 3, 1, False),      # ragged everything, 128 x 64 tiles
 ]
 
 
-@pytest.mark.parametrize("case", KGROUP_CASES)
-def test_wgrad_kgroups_vs_fp64(case, dev, lib_option):
-    """Filter gradients through the K-group workgroups (option wgrad_kgroups, three 4-wave groups combined through LDS)
-    and through the one-group kernel, with and without sub-tile skipping (option ntail_skip): each against an fp64
-    torch reference; repeated launches bit-identical."""
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_planes_vs_fp64(case, dev, lib_option):
+    """Filter gradients of the plane kernels (LDS-DMA form and, option wgrad_dma = 0, the register-staged form) against an
+    fp64 torch reference at the step's large shapes; repeated launches bit-identical."""
     from unflow_amd.core import layers as L
     import torch.nn.functional as F
     B, H, W, Cin, Cout, k, stride, deconv = case
@@ -447,10 +446,8 @@ def test_wgrad_kgroups_vs_fp64(case, dev, lib_option):
         dw_shape = (k, k, Cin, Cout)
     X, DZ = make_pt(x, dev, 3), make_pt(dz, dev, 3)
     results = {}
-    for kg, skip in ((1, 1), (1, 0), (0, 1)):
-        lib_option("wgrad_kgroups", kg)
-        lib_option("wgrad_kg_min_fill", 1)
-        lib_option("ntail_skip", skip)
+    for dma in (1, 0):
+        lib_option("wgrad_dma", dma)
         outs = []
         for _ in range(3):
             dw = torch.full(dw_shape, float('nan'), device=dev)
@@ -461,9 +458,8 @@ def test_wgrad_kgroups_vs_fp64(case, dev, lib_option):
             outs.append(dw.cpu())
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
-        assert err < 2e-5, (kg, skip, err)
-        results[(kg, skip)] = outs[0]
-    assert torch.equal(results[(1, 1)], results[(1, 0)])        # skipping a sub-tile changes no value
+        assert err < 2e-5, (dma, err)
+        results[dma] = outs[0]
 
 
 @pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1),

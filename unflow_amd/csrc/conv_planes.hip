@@ -20,7 +20,6 @@
 //        operands are site-major in HBM, so a tile is staged as [k = site][channel] rows (256 contiguous bytes per site)
 //        and the MFMA fragments (8 consecutive k of one channel) come out of LDS through ds_read_b64_tr_b16, the
 //        gfx950 transposing read (semantics probed in tools/microbench/probe_semantics.hip): no per-lane dword gathers.
-#include <type_traits>
 #include "igemm_shared.h"
 #include "options.h"
 
@@ -57,18 +56,14 @@ struct PlGatherParams : GatherGeom {
   int tw_log;                  // gather kernel: 0 = an M tile is BM consecutive sites of the linear (b, y, x) order; else the
                                // tile is (BM >> tw_log) rows x (1 << tw_log) sites of one image (tiles_x, tiles_y per image)
   int gpx;                     // pixels per K granule along x (0: a granule is 8 channels of ONE pixel; 2: conv1 form, below)
-  int skip;                    // skip the MFMAs of 32-column sub-tiles beyond N (option ntail_skip)
   PlaneOut pl;
 };
 
 // LDS bytes of one gather block: the operand tiles, or (larger for n_planes == 1) the four wave-private staging areas of
 // the epilogue (32 rows x (WN + 4) floats each); the destination-pixel table follows.
-// With kg K groups (the 768-thread form of the gather kernel) every group has its own tiles, and the groups' accumulators
-// meet in (kg - 1) x BM x BN floats of the same memory after the K loop.
-constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl, int kg = 1) {
-  const int tiles = kg * npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4, red = (kg - 1) * bm * bn * 4;
-  const int m = tiles > stage ? tiles : stage;
-  return m > red ? m : red;
+constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
+  const int tiles = npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4;
+  return tiles > stage ? tiles : stage;
 }
 
 // (xcd_remap: igemm_shared.h)
@@ -283,13 +278,12 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
 // stage, 118 registers.  A K16 stage of a gathered operand is 32 bytes per row: conv2 / conv3 forward 261 -> 326 us,
 // 251 -> 329 us, stride-2 data gradients 142 -> 173 us, the step 598 -> 570 image-pairs/s.  The 64-byte row pieces of a
 // K32 tile are the smallest unit the L1 / TA path moves efficiently; two K32 stages are 96 KB of LDS, one block per CU.)
-// K groups (KG = 3): the same idea as in igemm_pl_wgrad_dma_kernel for the layers that split K because they have few output
-// tiles (conv4 .. conv6_1, the decoder's deep deconvs and their data gradients): a 768-thread workgroup = three 4-wave groups
-// with their own operand tiles that own the SAME output tile and consecutive thirds of the block's K range; after the loop
-// groups 1 and 2 hand their accumulators to group 0 through LDS and ONE partial (or, when the layer then no longer splits,
-// the final result with its epilogue) is written: a third of the split-K partial traffic, 12 resident waves per CU as before.
-template <int BM, int BN, int WM, int WN, int NPL, bool F16, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && BN == 128) ? 3 : 1)) void igemm_pl_gather_kernel(const PlGatherParams p) {
+// (Round 3 measured and dropped: 768-thread workgroups whose three 4-wave K groups own one output tile and combine their
+// accumulators through LDS — a third of the split-K partial traffic for conv4 .. conv6_1 and the deep deconvs: time-neutral
+// where one round of such workgroups fills the chip, 20 % slower at 75 % fill; and skipping the MFMAs of 32-column
+// sub-tiles beyond N (N = 388 / 772 / 1028): neutral.  profiles/r03_kgroups_ab.txt)
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
+__global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) void igemm_pl_gather_kernel(const PlGatherParams p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
@@ -299,11 +293,10 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && B
   constexpr int NT = NPL == 3 ? 6 : 1;           // product terms per K16 slab
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;                       // within the K group
-  const int grp = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));    // K group of this wave
-  unsigned short* Ah = smem16 + grp * (NPL * (A_PLANE + B_PLANE));
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned short* Ah = smem16;
   unsigned short* Bh = Ah + NPL * A_PLANE;
-  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_gather_main_bytes(BM, BN, WN, NPL, KG));
+  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_gather_main_bytes(BM, BN, WN, NPL));
 
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   int mtile, ntile, cls_id, split;
@@ -317,9 +310,8 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && B
   const int Kg = ntaps * Cg;
   const int KT = (Kg + 3) >> 2;
   const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
-  const int bk0 = split * kt_per, bk1 = min(KT, bk0 + kt_per);       // the block's K tiles
-  const int per = (max(bk1 - bk0, 0) + KG - 1) / KG;                  // ... cut into KG runs; every group iterates `per` times
-  const int kt0 = bk0 + grp * per, kt1 = min(bk1, kt0 + per);         // (tiles past kt1 are zeros)
+  const int kt0 = split * kt_per;
+  const int kt1 = min(KT, kt0 + kt_per);
 
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
@@ -364,7 +356,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && B
       a_lin[i] = OOB_MARK;   // rows past M: every load out of range (zeros)
     }
   }
-  if (threadIdx.x < BM) {
+  if (tid < BM) {
     int b, yg, xg, v = -1;
     if (site_of(tid, b, yg, xg)) v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
     pix[tid] = v;
@@ -461,11 +453,8 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && B
   constexpr int NGROUP = 2 * TM * NT;        // MFMA groups per tile between which the load pieces are placed
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
 
-  // 32-column sub-tiles of this wave that hold a real output column (a prefix): the others get no MFMAs (N = 388 / 772 / 1028
-  // of the decoder leaves 4 real columns in the last 128-wide N tile)
-  const int vj = p.skip ? min(TN, max(0, (p.N - (n0 + wn * WN) + 31) >> 5)) : TN;
-  const bool full = vj == TN;
-  auto mfma_tile = [&](auto guarded) __attribute__((always_inline)) {
+  for (int kt = kt0; kt < kt1; kt++) {
+    live = kt + 1 < kt1;
 #pragma unroll
     for (int slab = 0; slab < 2; slab++) {
       // B fragments of the slab stay live; A fragments are read per 32-row sub-tile (keeps the 128x128 kernel at 3 waves/SIMD)
@@ -484,71 +473,22 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((NPL == 3 && BM == 128 && B
 #pragma unroll
         for (int t = 0; t < NT; t++) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) {
-            if constexpr (decltype(guarded)::value) {
-              if (j >= vj) continue;
-            }
-            mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t);
-          }
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t);
 #pragma unroll
           for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t) * PPG + q);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-  };
-  for (int it = 0; it < per; it++) {
-    live = kt0 + it + 1 < kt1;
-    if (full) mfma_tile(std::false_type{});
-    else mfma_tile(std::true_type{});
     __syncthreads();  // every wave is done reading this tile
     store_tile();     // (last iteration: zeros, never read)
     __syncthreads();
   }
 
-  if constexpr (KG > 1) {
-    // every tile is idle (the loop's last barrier): groups 1 .. KG-1 park their accumulators — [group - 1][wave][sub-tile]
-    // [4 x float4][lane], 16-byte stores, lanes 16 bytes apart — and group 0 adds them in group order.  The second barrier
-    // keeps the parked values intact until every wave of group 0 has read them (its epilogue stages through the same memory).
-    float4* red = reinterpret_cast<float4*>(smem16);
-    constexpr int PER_WAVE = TM * TN * 4 * 64;
-    if (grp > 0) {
-      float4* d = red + (size_t)((grp - 1) * 4 + wid) * PER_WAVE + lane;
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            d[((i * TN + j) * 4 + q) * 64] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-    }
-    __syncthreads();
-    if (grp == 0) {
-#pragma unroll
-      for (int g = 1; g < KG; g++) {
-        const float4* s = red + (size_t)((g - 1) * 4 + wid) * PER_WAVE + lane;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const float4 t = s[((i * TN + j) * 4 + q) * 64];
-              acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
-            }
-            asm volatile("" ::: "memory");
-          }
-      }
-    }
-    __syncthreads();
-    if (grp > 0) return;
-  }
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
-  if constexpr (KG == 1) {
-    if (p.fused_splitk) {
-      if (!splitk_last_arriver(p, (cls_id * p.mt + mtile) * p.nt + ntile, pix + BM)) return;
-      splitk_tile_reduce<BM, BN>(p, pix, n0);
-    }
+  if (p.fused_splitk) {
+    if (!splitk_last_arriver(p, (cls_id * p.mt + mtile) * p.nt + ntile, pix + BM)) return;
+    splitk_tile_reduce<BM, BN>(p, pix, n0);
   }
 }
 
@@ -717,9 +657,6 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   constexpr int NPIECE = NB + NH;
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
   int ty = 0, tx = 0;                            // tap of the tile being multiplied (kt0 is a chunk boundary)
-  // 32-column sub-tiles of this wave with a real output column (a prefix): the others get no MFMAs (see the gather kernel)
-  const int vj = p.skip ? min(TN, max(0, (p.N - (n0 + wn * WN) + 31) >> 5)) : TN;
-  const bool full = vj == TN;
   for (int kk = kt0; kk < kt1; kk++) {
     const int hyi = (tc.dy0 + ty * p.dstep) - dmin_y, hxi = (tc.dx0 + tx * p.dstep) - dmin_x;
     const int tapoff = (hyi * HC + hxi) * HPITCH;
@@ -728,7 +665,6 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
       if (step < NB) load_b(step);
       else if (step < NB + NH && new_chunk) load_h(step - NB);
     };
-    auto body = [&](auto guarded) __attribute__((always_inline)) {
     if constexpr (BN == 128) {
       // software-pipelined over the 2 x TM (slab, sub-tile) steps: the fragments of step s+1 are read from LDS while the
       // MFMAs of step s run (two waves per SIMD are not enough to hide a ds_read round trip in front of every step)
@@ -758,12 +694,7 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   #pragma unroll
         for (int t2 = 0; t2 < NT; t2++) {
   #pragma unroll
-          for (int j = 0; j < TN; j++) {
-            if constexpr (decltype(guarded)::value) {
-              if (j >= vj) continue;
-            }
-            mfma_terms<NPL, F16>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
-          }
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
   #pragma unroll
           for (int q = 0; q < PPG; q++) piece((step * NT + t2) * PPG + q);
           __builtin_amdgcn_sched_barrier(0);
@@ -789,12 +720,7 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
 #pragma unroll
           for (int t2 = 0; t2 < NT; t2++) {
 #pragma unroll
-            for (int j = 0; j < TN; j++) {
-              if constexpr (decltype(guarded)::value) {
-                if (j >= vj) continue;
-              }
-              mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
-            }
+            for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
 #pragma unroll
             for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
             __builtin_amdgcn_sched_barrier(0);
@@ -802,9 +728,6 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
         }
       }
     }
-    };
-    if (full) body(std::false_type{});
-    else body(std::true_type{});
     __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
     store_b();
     if (new_chunk) store_h();
@@ -869,7 +792,6 @@ struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multi
   int gpx;                     // conv1 form: granule ag of a tap row starts gpx * ag pixels to the right
   unsigned cag_magic;          // ceil(2^32 / (Ca/8))
   int mt, nt, xcd;             // 1-D grid of mt * nt * nsplit workgroups, XCD-contiguous in (split, N tile, M tile) order
-  int skip;                    // skip the MFMAs of sub-tiles beyond the problem (option ntail_skip)
 };
 
 // LDS image of one operand plane: [k = 32 sites][ROWS channels], rows of ROWS*2 bytes; 32-byte pairs of granules
@@ -1085,36 +1007,27 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 // Out-of-range rows (image border taps, the tail of the site range, channel padding) are buffer offsets >= num_records:
 // the hardware writes zeros.  48 KB of LDS and <= 168 registers per K group.
 //
-// K groups (KG = 3, round 3): the partial sums of a filter gradient are (resident accumulators) x 4 bytes = 768 blocks x
-// 64 KB = 50 MB per layer whatever its size — written, then re-read by sum_partials: ~1.5 GB and 0.37 ms of reduce
-// launches per step.  With KG = 3 a workgroup is 12 waves = three 4-wave groups that own the SAME output tile and
-// consecutive thirds of the block's site range, each with its own pair of stage buffers (3 x 48 KB of the CU's 160 KB: one
-// workgroup per CU, the same 12 waves as three KG = 1 blocks).  After the K loop groups 1 and 2 hand their accumulators to
-// group 0 through the (now free) stage buffers, group 0 adds them in group order and writes ONE partial: a third of the
-// bytes, in a fixed summation order.  All groups run the same number of stages (a group whose run is shorter multiplies
-// zero stages), so the one hardware barrier per stage is shared by the 12 waves.
-// Sub-tile skipping: a wave whose 32-row / 32-column sub-tile lies wholly beyond the problem (last M tile of conv3_1: 96 of
-// 128 rows; N = 388 / 772 / 1028 of the decoder: 4 of 128 columns in the last N tile) issues no MFMAs for it.
-template <int BN, int WN, int KG>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 3 : 1) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
+// (Round 3 measured and dropped, profiles/r03_kgroups_ab.txt: 768-thread workgroups = three 4-wave K groups owning the same
+// tile and combining through the stage buffers after the loop — a third of the 50 MB of partial sums per layer: neutral
+// where one round of such workgroups fills the chip (conv1 / conv2 / conv3 / deconv2), 8 % slower on conv3_1 at 80 % fill;
+// the shared per-stage barrier couples the 12 waves.  No MFMAs for sub-tiles beyond the last M / N tile: neutral.)
+template <int BN, int WN>
+__global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
   constexpr int BM = 128, WM = 64, NPL = 3, NT = 6, KS = 16;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves per K group");
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
   static_assert(BN == 128 || BN == 64, "swizzle forms");
   constexpr int A_PLANE = KS * BM, B_PLANE = KS * BN;            // elements
   constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
   constexpr int B_RPI = 512 / BN;                                // site rows per wave instruction: 4 (256-byte rows) / 8
   constexpr int B_NI = KS / B_RPI;                               // wave instructions per plane and stage: 4 / 2
   constexpr int B_SLOTS = BN / 8;
-  static_assert((KG - 1) * BM * BN * 4 <= KG * 2 * STAGE * 2, "the group hand-off fits the stage buffers");
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 
   const int lane = threadIdx.x & 63;
-  const int wall = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = KG == 1 ? 0 : wall >> 2;                       // K group of this wave
-  const int wid = wall & 3;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int taps = p.KH * p.KW;
   const int Cag = p.Ca >> 3;
@@ -1128,9 +1041,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 3 : 1) void igemm_pl_wgrad_dma_
   const int KT = (S + KS - 1) / KS;
   const int kt_per = (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;   // whole 32-site tiles per split, as the planner counts them
   const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
-  // this group's run of the block's stages; every group iterates `per` times (stages past g1 are zeros)
-  const int per = (max(kt1 - kt0, 0) + KG - 1) / KG;
-  const int g0 = kt0 + grp * per, g1 = min(kt1, g0 + per);
 
   // buffer descriptors as plain dwords (the LDS-DMA loads are inline asm: hipcc would otherwise wait vmcnt(0) in front of
   // every ds_read that follows a load into the same LDS array, i.e. drain the stage in flight)
@@ -1164,8 +1074,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 3 : 1) void igemm_pl_wgrad_dma_
   const int ldd2 = p.ldd * 2;
   const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
 
-  unsigned short* gsm = smem16 + grp * (2 * STAGE);              // this group's two stage buffers
-  const unsigned lds0 = lds_addr(gsm);
+  const unsigned lds0 = lds_addr(smem16);
   auto issue = [&](int kt, int buf) {
     const unsigned st = lds0 + (unsigned)(buf * STAGE * 2);      // byte address of the stage in LDS
     {
@@ -1209,25 +1118,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 3 : 1) void igemm_pl_wgrad_dma_
     const int c = wn * WN + j * 32 + 16 * (grp16 & 1) + 4 * (i16 & 3);
     b_rd[j] = NPL * A_PLANE + tr_swz<BN>(krow, c >> 3) + (c & 7);
   }
-  // 32-row / 32-column sub-tiles of this wave that hold any real row (tap, channel) / column: a prefix of each range
-  const int vi = p.skip ? min(TM, max(0, (Mg * 8 - (m0 + wm * WM) + 31) >> 5)) : TM;
-  const int vj = p.skip ? min(TN, max(0, (p.Cb - (n0 + wn * WN) + 31) >> 5)) : TN;
-  const bool full = vi == TM && vj == TN;
-
-  issue(g0 < g1 ? g0 : KT + 1, 0);
+  if (kt0 < kt1) issue(kt0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  // one stage: request stage kt+1, multiply stage kt, publish.  `guarded` (a compile-time flag; the blocks of the last M / N
-  // tile run their own copy of the loop) skips the sub-tiles beyond the problem.
-  auto stage = [&](int it, auto guarded) __attribute__((always_inline)) {
-    const int kt = g0 + it;
-    const int cur = it & 1;
-    // stage kt+1 -> the other buffer (every wave passed the barrier after its reads of that buffer); past the group's last
-    // stage the loads are all out of range (zeros: multiplied when the group's run is shorter than `per`, else never read)
-    issue(kt + 1 < g1 ? kt + 1 : KT + 1, cur ^ 1);
+  for (int kt = kt0; kt < kt1; kt++) {
+    const int cur = (kt - kt0) & 1;
+    // stage kt+1 -> the other buffer (every wave passed the barrier after its reads of that buffer); past the last stage the
+    // loads are all out of range (zeros into a buffer nobody reads)
+    issue(kt + 1 < kt1 ? kt + 1 : KT + 1, cur ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned short* st = gsm + cur * STAGE;
+    const unsigned short* st = smem16 + cur * STAGE;
     s16x8 av[TM][NPL], bv[TN][NPL];
 #pragma unroll
     for (int pl = 0; pl < NPL; pl++) {
@@ -1246,69 +1147,18 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 3 : 1) void igemm_pl_wgrad_dma_
         bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
     }
-    if constexpr (!decltype(guarded)::value) {
 #pragma unroll
-      for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
-    } else {
+    for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++)
-          if (i < vi && j < vj) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
-          }
-    }
+        for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
     // own loads landed + own LDS reads retired, then the barrier: stage kt+1 is complete and buffer `cur` is free (the
     // scheduling fences keep the MFMAs above and the next stage's loads below it)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-  };
-  if (full) {
-    for (int it = 0; it < per; it++) stage(it, std::false_type{});
-  } else {
-    for (int it = 0; it < per; it++) stage(it, std::true_type{});
-  }
-
-  if constexpr (KG > 1) {
-    // Every stage buffer is idle now (last barrier of the loop).  Groups 1 .. KG-1 park their accumulators in them —
-    // [group - 1][wave][sub-tile][4 x float4][lane]: 16-byte stores, lanes 16 bytes apart — and group 0 adds them in group
-    // order: the block's partial is (g0 + g1) + g2 whatever the timing.
-    float4* red = reinterpret_cast<float4*>(smem16);
-    constexpr int PER_WAVE = TM * TN * 4 * 64;                   // float4 per wave
-    if (grp > 0) {
-      float4* d = red + (size_t)((grp - 1) * 4 + wid) * PER_WAVE + lane;
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            d[((i * TN + j) * 4 + q) * 64] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-    }
-    __syncthreads();
-    if (grp > 0) return;
-#pragma unroll
-    for (int g = 1; g < KG; g++) {
-      const float4* s = red + (size_t)((g - 1) * 4 + wid) * PER_WAVE + lane;
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const float4 t = s[((i * TN + j) * 4 + q) * 64];
-            acc[i][j][4 * q] += t.x; acc[i][j][4 * q + 1] += t.y; acc[i][j][4 * q + 2] += t.z; acc[i][j][4 * q + 3] += t.w;
-          }
-          asm volatile("" ::: "memory");           // four 16-byte reads in flight at a time (hoisting all 64 spills)
-        }
-    }
   }
 
   float* o = p.nsplit > 1 ? p.partial + (size_t)split * taps * p.Ca_out * p.Cb : p.out;
@@ -1438,12 +1288,9 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b)
 struct PlPlan {
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
   int nsplit;
-  int kg;   // K groups per workgroup: 1, or 3 (768 threads; cfg 0 only)
 };
 
-inline int pl_smem_gather(int bm, int bn, int npl, int kg = 1) {   // + the pixel table + the split-K flag
-  return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl, kg) + bm * 4 + 16;
-}
+inline int pl_smem_gather(int bm, int bn, int npl) { return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl) + bm * 4 + 16; }   // + the pixel table + the split-K flag
 
 // blocks per CU by LDS (160 KB) and registers (<= 168: 3 waves per SIMD)
 inline int pl_blocks_per_cu(int bm, int bn, int npl) {
@@ -1452,9 +1299,8 @@ inline int pl_blocks_per_cu(int bm, int bn, int npl) {
   return byl < byr ? byl : byr;
 }
 
-inline PlPlan plan_pl_gather(const GatherGeom& p, int npl, bool allow_kg = true) {
+inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   PlPlan pl;
-  pl.kg = 1;
   const long M = (long)p.B * p.Hg * p.Wg;
   if (p.N <= 32) pl.cfg = 2;
   else if (p.N <= 64) pl.cfg = 1;
@@ -1472,13 +1318,6 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl, bool allow_kg = true)
   const int slots = 256 * pl_blocks_per_cu(bm, bn, npl);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
-  // K groups: when the layer splits anyway and one round of 768-thread workgroups (one per CU) fills enough of the chip
-  const unflow::Options& opt = unflow::options();
-  if (allow_kg && npl == 3 && opt.gather_kgroups && pl.cfg == 0 && pl.nsplit >= 2 && blocks <= 256) {
-    const int by_k = max(1, KT / (3 * max(1, opt.gather_kg_min_kt)));
-    const int ns3 = (int)min((long)by_k, 256 / blocks);
-    if (blocks * ns3 * 100 >= 256L * opt.gather_kg_min_fill) { pl.nsplit = ns3; pl.kg = 3; }
-  }
   return pl;
 }
 
@@ -1519,11 +1358,11 @@ inline void pl_gather_tiles2d(PlGatherParams& q) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NPL, bool F16, int KG = 1>
+template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
-  const int smem = pl_smem_gather(BM, BN, NPL, KG);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16, KG>),
+  const int smem = pl_smem_gather(BM, BN, NPL);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
   PlGatherParams q = p;
@@ -1531,15 +1370,12 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   pl_gather_tiles2d<BM>(q);
   const int grid = pl_grid(q);
   if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
-  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16, KG><<<grid, 256 * KG, smem, st>>>(q);
+  igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q);
   return launch_status();
 }
 
 template <int NPL, bool F16>
-int run_pl_gather_mode(PlGatherParams& p, int cfg, int kg, hipStream_t st) {
-  if constexpr (NPL == 3) {
-    if (cfg == 0 && kg == 3) return launch_pl_gather<128, 128, 64, 64, NPL, F16, 3>(p, st);
-  }
+int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
   switch (cfg) {
     case 0: return launch_pl_gather<128, 128, 64, 64, NPL, F16>(p, st);
     case 1: return launch_pl_gather<128, 64, 64, 32, NPL, F16>(p, st);
@@ -1600,7 +1436,6 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   // order 2 (M groups per XCD, M tile fastest inside) measured best or tied on every layer of FlowNetC 384x512 B=4 against
   // 0 and 1 (profiles/r02_xcd_order_per_layer.txt); option xcd_order forces one
   p.order = opt.xcd_order >= 0 && opt.xcd_order <= 2 ? opt.xcd_order : 2;
-  p.skip = opt.ntail_skip;
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
   PlPlan pl = plan_pl_gather(p, npl);
@@ -1628,8 +1463,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     // 0.69 ms of the step (no-reduce ablation): what they cost is the second pass over the partials, which
     // one block per tile does no faster than 256 CUs.  Kept as a tested alternative.
     const int fused = opt.fused_splitk;
-    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu &&
-                     (halo || pl.kg == 1);
+    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu;
     p.counters = p.fused_splitk ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pl_gather_slab_bytes(p, p.nsplit)) : nullptr;
   }
   int code;
@@ -1637,7 +1471,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
     else code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
   } else {
-    code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, pl.kg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, 1, st);
+    code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   }
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1 && !p.fused_splitk) {
@@ -1654,43 +1488,27 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
 
 inline int pl_wgrad_cfg(const WgradGeom& p) { return p.Cb <= 64 ? 1 : 0; }   // 0: 128x128, 1: 128x64
 
-// Split plan of a filter gradient.  kg = 1: nsplit x tiles 256-thread workgroups, as many as fit the chip in one round of
-// resident blocks (3 per CU).  kg = 3 (LDS-DMA kernel, option wgrad_kgroups): 768-thread workgroups, one per CU, whose three
-// K groups combine through LDS — a third of the partial sums — when the layer splits at least three ways anyway and
-// tiles x nsplit fills at least wgrad_kg_min_fill % of the CUs (the second stream's kernels take the rest).
-struct PlWgradPlan {
-  int nsplit, kg;
-};
-
-inline PlWgradPlan plan_pl_wgrad(const WgradGeom& p, int npl, bool allow_kg = true) {
-  const unflow::Options& opt = unflow::options();
+inline int plan_pl_wgrad(const WgradGeom& p, int npl) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int cfg = pl_wgrad_cfg(p);
   const int bn = cfg == 1 ? 64 : 128;
   const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
-  const int min_kt = max(1, opt.wgrad_min_kt);
+  const int min_kt = max(1, unflow::options().wgrad_min_kt);
   const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
   const int per_cu = min((160 * 1024) / (npl * (128 + bn) * BK * 2), cfg == 1 ? 4 : 3);
   // (Fewer blocks to shrink the partial sums — blocks x 64 KB whatever the layer, 50 MB at 768 blocks — lose more than the
   // traffic costs: 587 / 594 / 607 image-pairs/s at 256 / 384 / 512 blocks against ~620 at 768, profiles/r02_knob_sweep.txt.)
-  PlWgradPlan pl{fill_one_round(blocks, 256 * per_cu, max_by_k), 1};
-  if (allow_kg && npl == 3 && opt.wgrad_dma && opt.wgrad_kgroups && pl.nsplit >= 3 && blocks <= 256) {
-    const int by_k = max(1, KT / (3 * min_kt));
-    const int ns3 = (int)min((long)by_k, 256 / blocks);
-    if (blocks * ns3 * 100 >= 256L * opt.wgrad_kg_min_fill) pl = PlWgradPlan{ns3, 3};
-  }
-  return pl;
+  return fill_one_round(blocks, 256 * per_cu, max_by_k);
 }
 
 inline size_t pl_wgrad_partial_bytes(const WgradGeom& p, int ca_out, int nsplit) {
   const size_t n = (size_t)p.KH * p.KW * ca_out * p.Cb;
   return nsplit > 1 ? (size_t)nsplit * n * sizeof(float) + reduce_scratch_bytes(n, nsplit) : 0;
 }
-// workspace of the plan as run_pl_wgrad executes it (the kg = 1 plan never needs less than the kg = 3 one)
 inline size_t pl_wgrad_plan_bytes(const WgradGeom& p, int ca_out, int npl) {
-  return pl_wgrad_partial_bytes(p, ca_out, max(plan_pl_wgrad(p, npl, false).nsplit, plan_pl_wgrad(p, npl, true).nsplit));
+  return pl_wgrad_partial_bytes(p, ca_out, plan_pl_wgrad(p, npl));
 }
 
 template <int BM, int BN, int WM, int WN, int NPL, bool F16>
@@ -1706,27 +1524,25 @@ int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   return launch_status();
 }
 
-template <int BN, int WN, int KG>
+template <int BN, int WN>
 int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
-  const int smem = KG * 2 * 3 * (128 + BN) * 16 * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN, KG>),
+  const int smem = 2 * 3 * (128 + BN) * 16 * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   (void)attr;
   PlWgradParams q = p;
   q.mt = cdiv(Mp, 128); q.nt = cdiv(p.Cb, BN);
-  igemm_pl_wgrad_dma_kernel<BN, WN, KG><<<q.mt * q.nt * p.nsplit, 256 * KG, smem, st>>>(q);
+  igemm_pl_wgrad_dma_kernel<BN, WN><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
   return launch_status();
 }
 
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
   const unflow::Options& opt = unflow::options();
   p.xcd = opt.xcd_swizzle;
-  p.skip = opt.ntail_skip;
   p.cag_magic = p.Ca == 8 ? 0u : magic_u32((unsigned)(p.Ca >> 3));   // 2^32 / 1 does not fit: 0 marks 'no division'
   const size_t wsize = (size_t)p.KH * p.KW * p.Ca_out * p.Cb;
-  const PlWgradPlan plan = plan_pl_wgrad(p, npl);
-  int ns = plan.nsplit;
+  int ns = plan_pl_wgrad(p, npl);
   if (ns > 1 && (!ws || ws_bytes < pl_wgrad_partial_bytes(p, p.Ca_out, ns))) {
     ns = ws ? (int)min((size_t)REDUCE_FAN, ws_bytes / (wsize * sizeof(float))) : 1;
     if (ns < 1) ns = 1;
@@ -1736,9 +1552,7 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
   *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
   const int cfg = pl_wgrad_cfg(p);
   int code;
-  if (npl == 3 && opt.wgrad_dma && plan.kg == 3)
-    code = cfg == 1 ? launch_pl_wgrad_dma<64, 32, 3>(p, st) : launch_pl_wgrad_dma<128, 64, 3>(p, st);
-  else if (npl == 3 && opt.wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32, 1>(p, st) : launch_pl_wgrad_dma<128, 64, 1>(p, st);
+  if (npl == 3 && opt.wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32>(p, st) : launch_pl_wgrad_dma<128, 64>(p, st);
   else if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
   if (code != UNFLOW_OK) return code;
@@ -1849,7 +1663,7 @@ UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const 
 
 static int pl_gather_nsplit(const GatherGeom& g, int npl) {
   int bn;
-  return pl_halo_ok(g) ? plan_pl_halo(g, npl, &bn) : plan_pl_gather(g, npl, false).nsplit;   // (the K-group plan never splits more)
+  return pl_halo_ok(g) ? plan_pl_halo(g, npl, &bn) : plan_pl_gather(g, npl).nsplit;
 }
 
 UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes) {

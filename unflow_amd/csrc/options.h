@@ -18,12 +18,6 @@
   X(xcd_order, -1)        /* force work_decode order 0 / 1 / 2 (-1: per-kernel default) */                                \
   X(fused_splitk, 0)      /* n > 0: in-kernel split-K reduction for tiles with up to n slices */                          \
   X(wgrad_dma, 1)         /* LDS-DMA filter-gradient kernel (0: register-staged) */                                       \
-  X(wgrad_kgroups, 1)     /* 1: 768-thread filter-gradient blocks whose 3 K groups combine through LDS */                 \
-  X(wgrad_kg_min_fill, 75) /* ... used when they fill at least this % of the CUs in one round */                          \
-  X(gather_kgroups, 1)    /* 1: 768-thread gather workgroups (3 K groups) for the 128x128 layers that split K */          \
-  X(gather_kg_min_fill, 70) /* ... used when they fill at least this % of the CUs in one round */                         \
-  X(gather_kg_min_kt, 4)  /* ... with at least this many K32 tiles per K group */                                         \
-  X(ntail_skip, 1)        /* skip the MFMAs of 32-column sub-tiles that lie wholly beyond N */                            \
   X(corr_nb, 1)           /* narrow-band correlation forward kernel */                                                    \
   X(corr_wb, 1)           /* wide-band correlation forward kernel */                                                      \
   X(corr_bwd_b128, 1)     /* 16-byte band loads in the correlation backward */                                            \
