@@ -419,12 +419,15 @@ int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, con
                          int Cout, int k, int stride, int leaky, void* workspace, size_t workspace_bytes,
                          unflow_stream_t stream);
 /* w_pl: the `direct` planes of w (ld = round_up_8(Cout)); dx_pl receives channels [pl_lo, pl_hi) of dx (the range whose
- * values are final after this call, i.e. [act_lo, act_hi)). */
+ * values are final after this call, i.e. [act_lo, act_hi)).  The leaky-ReLU derivative of [act_lo, act_hi) is taken from
+ * act_src (the fp32 activation) or, when act_src is NULL, from the first plane of act_pl (the sign of the activation is the
+ * sign of its bf16 / fp16 leading plane).  Planes-only tensors: y (forward) / dx (data gradient, accumulate == 0) may be NULL
+ * when the corresponding planes are given — a tensor that only convolutions read need not exist in fp32. */
 int unflow_conv2d_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
                               const unflow_planes* w_pl, float* dx, int lddx, const unflow_planes* dx_pl, int pl_lo,
                               int pl_hi, int B, int H, int W, int Cin, int Cout, int k, int stride, int accumulate,
-                              const float* act_src, int ld_act, int act_lo, int act_hi, void* workspace,
-                              size_t workspace_bytes, unflow_stream_t stream);
+                              const float* act_src, int ld_act, const unflow_planes* act_pl, int act_lo, int act_hi,
+                              void* workspace, size_t workspace_bytes, unflow_stream_t stream);
 int unflow_conv2d_bwd_filter_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* dz, int lddz,
                                 const unflow_planes* dz_pl, float* dw, int B, int H, int W, int Cin, int Cout, int k,
                                 int stride, void* workspace, size_t workspace_bytes, unflow_stream_t stream);
@@ -437,8 +440,8 @@ int unflow_conv2d_transpose_fwd_pl(const float* x, int ldx, const unflow_planes*
 int unflow_conv2d_transpose_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
                                         const unflow_planes* w_pl, float* dx, int lddx, const unflow_planes* dx_pl,
                                         int pl_lo, int pl_hi, int B, int H, int W, int Cin, int Cout, int accumulate,
-                                        const float* act_src, int ld_act, int act_lo, int act_hi, void* workspace,
-                                        size_t workspace_bytes, unflow_stream_t stream);
+                                        const float* act_src, int ld_act, const unflow_planes* act_pl, int act_lo,
+                                        int act_hi, void* workspace, size_t workspace_bytes, unflow_stream_t stream);
 int unflow_conv2d_transpose_bwd_filter_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* dz, int lddz,
                                           const unflow_planes* dz_pl, float* dw, int B, int H, int W, int Cin, int Cout,
                                           void* workspace, size_t workspace_bytes, unflow_stream_t stream);

@@ -114,6 +114,25 @@ def concat_layout(parts):
     return d, pad4(off)
 
 
+class ActView(dict):
+    """name -> fp32 activation of a stage.  Tensors that only convolutions read (_Stage.planes_only) are not written in fp32
+    by the step: for those the values are rebuilt from the operand planes on access (hi + mid + lo is the fp32 value exactly;
+    fp16 mode: the rounded value) — for tests and tools, never on the step's path."""
+
+    def __init__(self, stage):
+        super().__init__()
+        self._stage = stage
+
+    def __getitem__(self, k):
+        st = self._stage
+        if k in st.planes_only:
+            pl = st.A[k].pl
+            C = st.A[k].t.shape[-1]
+            dt = torch.bfloat16 if pl.shape[0] == 3 else torch.float16
+            return pl.view(dt).float().sum(0)[..., :C].contiguous()
+        return super().__getitem__(k)
+
+
 class _Op:
     """One forward launch of a stage: a layer (src slice -> dst slice) or the correlation."""
     __slots__ = ('kind', 'l', 'src', 'dst')
@@ -316,7 +335,14 @@ class _Stage:
                     continue
                 is_flow = name.startswith('flow')
                 self.Gd[name] = L.PT.alloc((N, H // div, W // div, width), dev, 0 if is_flow else npl)
-        self.act = {k: v.t for k, v in self.A.items()}
+        # single-producer conv outputs that only convolutions consume (no flow head, no concat, no correlation fallback): they
+        # live as operand planes alone — no fp32 write in the forward pass, and the data gradient that needs the sign of
+        # the activation (leaky-ReLU derivative) takes it from the leading plane
+        self.planes_only = set()
+        if npl:
+            self.planes_only = {n for n in ('c1', 'c4', 'c5', 'c6') + (() if self.is_c else ('c3',)) if n in self.A}
+        self.act = ActView(self)
+        self.act.update({k: v.t for k, v in self.A.items()})
         self.grad = {k: v.t for k, v in self.Gd.items()}
         if self.full_res:      # the stage input is the first segment of concat0
             self.act['x0s'] = self.act['cat0'][..., :pad4(self.in_ch)]
@@ -360,10 +386,11 @@ class _Stage:
             if l.cout_p != l.cout:
                 y = L.PT(y.t.as_strided(y.t.shape[:3] + (l.cout_p,), y.t.stride(), y.t.storage_offset()),
                          None if y.pl is None else y.pl)
+            po = op.dst[0] in self.planes_only
             if l.kind == 'conv':
-                L.conv_fwd(x, l.w, l.wpl_t, l.b, y, l.stride, l.act)
+                L.conv_fwd(x, l.w, l.wpl_t, l.b, y, l.stride, l.act, planes_only=po)
             else:
-                L.deconv_fwd(x, l.w, l.wpl_d, l.b, y, l.act)
+                L.deconv_fwd(x, l.w, l.wpl_d, l.b, y, l.act, planes_only=po)
 
     # -------------------------------------------------------------- backward
     def backward(self, part=None):
@@ -436,10 +463,11 @@ class _Stage:
             # the loss wrote d flowN first (flow buffers): everything after it accumulates
             accumulate = (not first) or sb.startswith('flow')
             act_src = self.pt(op.src) if act_hi > act_lo else None
+            apl = sb in self.planes_only
             if l.kind == 'conv':
-                L.conv_bwd_data(dz, l.w, l.wpl_d, dx, l.stride, accumulate, act_src, act_lo, act_hi)
+                L.conv_bwd_data(dz, l.w, l.wpl_d, dx, l.stride, accumulate, act_src, act_lo, act_hi, act_planes=apl)
             else:
-                L.deconv_bwd_data(dz, l.w, l.wpl_t, dx, accumulate, act_src, act_lo, act_hi)
+                L.deconv_bwd_data(dz, l.w, l.wpl_t, dx, accumulate, act_src, act_lo, act_hi, act_planes=apl)
         if side is not None:
             flush()
             main.wait_stream(side)
@@ -658,7 +686,9 @@ class FlowNetEngine:
             st.alloc()
         last = self.stages[-1]
         # views used by the loss code, tests and tools: the trained (last) network
-        self.act = dict(last.act, x0=self.x0, im01=self.im01)
+        self.act = ActView(last)
+        self.act.update(last.act)
+        self.act.update(x0=self.x0, im01=self.im01)
         self.grad = last.grad
         # loss-side pyramid: one level per flow output of the last network (unsupervised.py:85-104)
         self.layer_weights = LAYER_WEIGHTS_FULL_RES if self.full_res else LAYER_WEIGHTS

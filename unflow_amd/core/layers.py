@@ -189,11 +189,15 @@ def planes_from_f32(x, out_pl, C=None):
           "planes_from_f32")
 
 
-def conv_fwd(x, w, w_pl, bias, y, stride, leaky):
-    """conv2d_fwd on PTs; w_pl: the layer's TRANSPOSED weight planes [P, k*k, Cout, round8(Cin)] (or None)."""
+def conv_fwd(x, w, w_pl, bias, y, stride, leaky, planes_only=False):
+    """conv2d_fwd on PTs; w_pl: the layer's TRANSPOSED weight planes [P, k*k, Cout, round8(Cin)] (or None).
+    planes_only: y lives as operand planes alone (its fp32 tensor is not written)."""
     x, y = _pt(x), _pt(y)
     xp, ldx, B, H, W, Cin = nhwc(x.t)
     yp, ldy, _, Ho, Wo, Cout = nhwc(y.t)
+    if planes_only:
+        assert y.pl is not None
+        yp = ptr(None)
     k = w.shape[0]
     assert tuple(w.shape) == (k, k, Cin, Cout) and w.is_contiguous() and (Ho, Wo) == out_hw(H, W, stride)
     wsp, wsn = _ws_pl(x.t.device, B, H, W, Cin, Cout, k, stride, _npl(x, y))
@@ -202,7 +206,20 @@ def conv_fwd(x, w, w_pl, bias, y, stride, leaky):
                                           stream()), "conv2d_fwd_pl")
 
 
-def conv_bwd_data(dz, w, w_pl, dx, stride, accumulate=False, act_src=None, act_lo=0, act_hi=0):
+def _act_args(act_src, act_planes):
+    """(fp32 pointer, ld, planes) of the activation whose sign gives the leaky-ReLU derivative: act_planes=True takes it
+    from the first operand plane of act_src (a tensor without an fp32 copy), else from its fp32 values."""
+    if act_src is None:
+        return ptr(None), 0, None
+    a = _pt(act_src)
+    if act_planes:
+        assert a.pl is not None
+        return ptr(None), 0, _lib.planes_of(a.pl)
+    ap, lda = nhwc(a.t)[:2]
+    return ap, lda, None
+
+
+def conv_bwd_data(dz, w, w_pl, dx, stride, accumulate=False, act_src=None, act_lo=0, act_hi=0, act_planes=False):
     """conv2d_bwd_data on PTs; w_pl: the DIRECT weight planes [P, k*k, Cin, round8(Cout)].  dx's planes receive the
     channels [act_lo, act_hi) (final after this call)."""
     dz, dx = _pt(dz), _pt(dx)
@@ -210,13 +227,11 @@ def conv_bwd_data(dz, w, w_pl, dx, stride, accumulate=False, act_src=None, act_l
     dxp, lddx, _, H, W, Cin = nhwc(dx.t)
     k = w.shape[0]
     assert tuple(w.shape) == (k, k, Cin, Cout)
-    ap, lda = (ptr(None), 0)
-    if act_src is not None:
-        ap, lda = nhwc(_pt(act_src).t)[:2]
+    ap, lda, apl = _act_args(act_src, act_planes)
     wsp, wsn = _ws_pl(dz.t.device, B, H, W, Cin, Cout, k, stride, _npl(dz, dx))
     check(_lib.lib().unflow_conv2d_bwd_data_pl(dzp, lddz, _lib.planes_of(dz.pl), ptr(w), _lib.planes_of(w_pl), dxp, lddx,
                                                _lib.planes_of(dx.pl), act_lo, act_hi, B, H, W, Cin, Cout, k, stride,
-                                               int(bool(accumulate)), ap, lda, act_lo, act_hi, wsp, wsn, stream()),
+                                               int(bool(accumulate)), ap, lda, apl, act_lo, act_hi, wsp, wsn, stream()),
           "conv2d_bwd_data_pl")
 
 
@@ -231,11 +246,14 @@ def conv_bwd_filter(x, dz, dw, stride):
                                                  W, Cin, Cout, k, stride, wsp, wsn, stream()), "conv2d_bwd_filter_pl")
 
 
-def deconv_fwd(x, w, w_pl, bias, y, leaky):
+def deconv_fwd(x, w, w_pl, bias, y, leaky, planes_only=False):
     """conv2d_transpose_fwd on PTs; w_pl: the DIRECT weight planes [P, 16, Cout, round8(Cin)]."""
     x, y = _pt(x), _pt(y)
     xp, ldx, B, H, W, Cin = nhwc(x.t)
     yp, ldy, _, Ho, Wo, Cout = nhwc(y.t)
+    if planes_only:
+        assert y.pl is not None
+        yp = ptr(None)
     assert tuple(w.shape) == (4, 4, Cout, Cin) and (Ho, Wo) == (2 * H, 2 * W)
     wsp, wsn = _ws_pl(x.t.device, B, 2 * H, 2 * W, Cin, Cout, 4, 2, _npl(x, y))
     check(_lib.lib().unflow_conv2d_transpose_fwd_pl(xp, ldx, _lib.planes_of(x.pl), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp,
@@ -243,19 +261,18 @@ def deconv_fwd(x, w, w_pl, bias, y, leaky):
                                                     stream()), "conv2d_transpose_fwd_pl")
 
 
-def deconv_bwd_data(dz, w, w_pl, dx, accumulate=False, act_src=None, act_lo=0, act_hi=0):
+def deconv_bwd_data(dz, w, w_pl, dx, accumulate=False, act_src=None, act_lo=0, act_hi=0, act_planes=False):
     """conv2d_transpose_bwd_data on PTs; w_pl: the TRANSPOSED weight planes [P, 16, Cin, round8(Cout)]."""
     dz, dx = _pt(dz), _pt(dx)
     dzp, lddz, B, Ho, Wo, Cout = nhwc(dz.t)
     dxp, lddx, _, H, W, Cin = nhwc(dx.t)
     assert tuple(w.shape) == (4, 4, Cout, Cin) and (Ho, Wo) == (2 * H, 2 * W)
-    ap, lda = (ptr(None), 0)
-    if act_src is not None:
-        ap, lda = nhwc(_pt(act_src).t)[:2]
+    ap, lda, apl = _act_args(act_src, act_planes)
     wsp, wsn = _ws_pl(dz.t.device, B, Ho, Wo, Cin, Cout, 4, 2, _npl(dz, dx))
     check(_lib.lib().unflow_conv2d_transpose_bwd_data_pl(dzp, lddz, _lib.planes_of(dz.pl), ptr(w), _lib.planes_of(w_pl), dxp,
                                                          lddx, _lib.planes_of(dx.pl), act_lo, act_hi, B, H, W, Cin, Cout,
-                                                         int(bool(accumulate)), ap, lda, act_lo, act_hi, wsp, wsn, stream()),
+                                                         int(bool(accumulate)), ap, lda, apl, act_lo, act_hi, wsp, wsn,
+                                                         stream()),
           "conv2d_transpose_bwd_data_pl")
 
 

@@ -41,7 +41,8 @@ struct PlGatherParams : GatherGeom {
   const float* bias;
   float* dst;
   float* partial;
-  const float* act_src;
+  const float* act_src;        // leaky-ReLU derivative taken from this fp32 activation (its sign), or
+  const unsigned short* act_pl;   // ... from the activation's FIRST operand plane (bf16 hi / fp16: same sign, 2 bytes per element)
   int lds, ldd, ld_act, act_lo, act_hi;
   int nsplit;
   int leaky, accumulate;
@@ -115,8 +116,12 @@ __device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (
   }
 }
 
-// bias / leaky-ReLU / accumulate / leaky derivative of four consecutive output channels, fp32 store + output planes
-__device__ __forceinline__ void epi_store4(const PlGatherParams& p, size_t px, int n, float4 v) {
+// sign test on a 16-bit plane element (bf16 hi plane or fp16): the value is > 0 (tf.maximum(0.1 x, x) took the x branch)
+__device__ __forceinline__ float leaky_grad_from_bits(unsigned h) { return ((h & 0x8000u) == 0u && (h & 0x7fffu) != 0u) ? 1.f : 0.1f; }
+
+// bias / leaky-ReLU / accumulate / leaky derivative of four consecutive output channels; stores the fp32 result when the
+// layer keeps one (dst may be NULL: tensors that only convolutions read live as operand planes alone) and returns it
+__device__ __forceinline__ float4 epi_value4(const PlGatherParams& p, size_t px, int n, float4 v) {
   if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
   if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
   float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
@@ -124,15 +129,39 @@ __device__ __forceinline__ void epi_store4(const PlGatherParams& p, size_t px, i
     const float4 e = *d;
     v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
   }
-  if (p.act_src && n + 3 >= p.act_lo && n < p.act_hi) {
-    const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
-    if (n >= p.act_lo && n < p.act_hi) v.x *= leaky_grad_from_out(a.x);
-    if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= leaky_grad_from_out(a.y);
-    if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= leaky_grad_from_out(a.z);
-    if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= leaky_grad_from_out(a.w);
+  if (n + 3 >= p.act_lo && n < p.act_hi) {
+    float gx = 1.f, gy = 1.f, gz = 1.f, gw = 1.f;
+    bool have = false;
+    if (p.act_src) {
+      const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
+      gx = leaky_grad_from_out(a.x); gy = leaky_grad_from_out(a.y); gz = leaky_grad_from_out(a.z); gw = leaky_grad_from_out(a.w);
+      have = true;
+    } else if (p.act_pl) {
+      const uint2 a = *reinterpret_cast<const uint2*>(p.act_pl + px * p.ld_act + n);
+      gx = leaky_grad_from_bits(a.x & 0xffffu); gy = leaky_grad_from_bits(a.x >> 16);
+      gz = leaky_grad_from_bits(a.y & 0xffffu); gw = leaky_grad_from_bits(a.y >> 16);
+      have = true;
+    }
+    if (have) {
+      if (n >= p.act_lo && n < p.act_hi) v.x *= gx;
+      if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= gy;
+      if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= gz;
+      if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= gw;
+    }
   }
-  *d = v;
-  store_planes4(p.pl, px, n, v);
+  if (p.dst) *d = v;
+  return v;
+}
+__device__ __forceinline__ void epi_store4(const PlGatherParams& p, size_t px, int n, float4 v) {
+  store_planes4(p.pl, px, n, epi_value4(p, px, n, v));
+}
+// eight consecutive channels n .. n+7 (n % 8 == 0 in the destination row): the fp32 halves as above, the planes as ONE
+// 16-byte store per plane (the epilogues are store-issue bound on layers with few K tiles per output: conv1, the 64-channel
+// decoder levels; a lane that owns 8 channels issues 5 stores where two 4-channel lanes issued 8)
+__device__ __forceinline__ void epi_store8(const PlGatherParams& p, size_t px, int n, float4 v0, float4 v1) {
+  v0 = epi_value4(p, px, n, v0);
+  v1 = epi_value4(p, px, n + 4, v1);
+  store_planes8(p.pl, px, n, v0, v1);
 }
 
 // Split-K without a second kernel (tiles with few slices): after its partial tile is stored, a block takes a ticket on its
@@ -220,6 +249,22 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
+      if (!to_partial) {
+        // final values: a lane owns 8 consecutive channels of a row (two 16-byte fp32 stores, one 16-byte store per plane)
+        constexpr int OPR = WN / 8, RPI8 = 64 / OPR;
+#pragma unroll
+        for (int it = 0; it < 32 / RPI8; it++) {
+          const int rr = it * RPI8 + lane / OPR, q = lane % OPR;
+          const float4 v0 = *reinterpret_cast<const float4*>(stg + rr * EP + 8 * q);
+          const float4 v1 = *reinterpret_cast<const float4*>(stg + rr * EP + 8 * q + 4);
+          const int px = pix[wm * WM + i * 32 + rr];
+          const int n = n0 + wn * WN + 8 * q;
+          if (px < 0 || n >= p.N) continue;
+          if (n + 8 <= p.N) epi_store8(p, (size_t)px, n, v0, v1);
+          else epi_store4(p, (size_t)px, n, v0);          // (N % 4 == 0: the first half is whole)
+        }
+        continue;
+      }
 #pragma unroll
       for (int it = 0; it < 32 / RPI; it++) {
         const int rr = it * RPI + lane / QPR, q = lane % QPR;
@@ -227,7 +272,7 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
         const int px = pix[wm * WM + i * 32 + rr];
         const int n = n0 + wn * WN + 4 * q;
         if (px < 0 || n >= p.N) continue;
-        if (to_partial) {
+        {
           float* dp = p.partial + ((size_t)split * npix_d + px) * p.N + n;
           if (p.fused_splitk) {   // write-through: the last arriver of the tile reads it from L2 / fabric (splitk_last_arriver)
             u32x4 t;
@@ -236,9 +281,7 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
           } else {
             *reinterpret_cast<float4*>(dp) = v;
           }
-          continue;
         }
-        epi_store4(p, (size_t)px, n, v);
       }
     }
     return;
@@ -262,8 +305,11 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
           if (p.leaky) v = leaky_relu(v);
           float* d = p.dst + (size_t)px * p.ldd + n;
           if (p.accumulate) v += *d;
-          if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
-          *d = v;
+          if (n >= p.act_lo && n < p.act_hi) {
+            if (p.act_src) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
+            else if (p.act_pl) v *= leaky_grad_from_bits(p.act_pl[(size_t)px * p.ld_act + n]);
+          }
+          if (p.dst) *d = v;
           store_planes(p.pl, (size_t)px, n, v);
         }
       }
@@ -772,8 +818,11 @@ __global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec
     if (p.leaky) v = leaky_relu(v);
     float* d = p.dst + px * p.ldd + n;
     if (p.accumulate) v += *d;
-    if (p.act_src && n >= p.act_lo && n < p.act_hi) v *= leaky_grad_from_out(p.act_src[px * p.ld_act + n]);
-    *d = v;
+    if (n >= p.act_lo && n < p.act_hi) {
+      if (p.act_src) v *= leaky_grad_from_out(p.act_src[px * p.ld_act + n]);
+      else if (p.act_pl) v *= leaky_grad_from_bits(p.act_pl[px * p.ld_act + n]);
+    }
+    if (p.dst) *d = v;
     store_planes(p.pl, px, n, v);
   }
 }
@@ -1452,9 +1501,11 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   }
   {
     const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
-                         reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0);
-    p.vec_epi = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0 &&
+                         reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0) |
+                         reinterpret_cast<uintptr_t>(p.act_pl) * 2;
+    p.vec_epi = p.N % 4 == 0 && (!p.dst || p.ldd % 4 == 0) && ((!p.act_src && !p.act_pl) || p.ld_act % 4 == 0) && (al & 15) == 0 &&
                 (!p.pl.n_planes || p.pl.ld % 4 == 0);
+    if (!p.dst && (!p.vec_epi || p.accumulate || !p.pl.n_planes)) return UNFLOW_ERR_UNSUPPORTED;   // planes-only output
   }
   {
     // option fused_splitk = n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
@@ -1476,11 +1527,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1 && !p.fused_splitk) {
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.partial) |
-                         reinterpret_cast<uintptr_t>(p.act_src) | (p.pl.n_planes ? reinterpret_cast<uintptr_t>(p.pl.base) * 2 : 0);
-    const bool vec = p.N % 4 == 0 && p.ldd % 4 == 0 && (!p.act_src || p.ld_act % 4 == 0) && (al & 15) == 0 &&
-                     (!p.pl.n_planes || p.pl.ld % 4 == 0);
-    pl_splitk_reduce_epilogue_kernel<<<stream_grid((long)(vec ? total / 4 : total)), 256, 0, st>>>(p, vec ? 1 : 0);
+    pl_splitk_reduce_epilogue_kernel<<<stream_grid((long)(p.vec_epi ? total / 4 : total)), 256, 0, st>>>(p, p.vec_epi);
     return launch_status();
   }
   return UNFLOW_OK;
@@ -1576,6 +1623,16 @@ inline PlaneOut plane_out(const unflow_planes* t, int lo, int hi) {
     o.n_planes = t->n_planes;
   }
   return o;
+}
+
+// source of the leaky-ReLU derivative of a data gradient: the fp32 activation if the caller has one, else the first operand
+// plane of the activation (same sign, a third of the bytes)
+inline void set_act(PlGatherParams& p, const float* act_src, int ld_act, const unflow_planes* act_pl) {
+  p.act_src = act_src; p.ld_act = ld_act; p.act_pl = nullptr;
+  if (!act_src && act_pl && act_pl->base) {
+    p.act_pl = reinterpret_cast<const unsigned short*>(act_pl->base);
+    p.ld_act = act_pl->ld;
+  }
 }
 
 }  // namespace
@@ -1721,15 +1778,15 @@ UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes
                                     const unflow_planes* w_pl, const float* bias, float* y, int ldy,
                                     const unflow_planes* y_pl, int B, int H, int W, int Cin, int Cout, int k, int stride,
                                     int leaky, void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
-  if (!y || (!x && !x_pl)) return UNFLOW_ERR_NULL;
+  if ((!y && !(y_pl && y_pl->base)) || (!x && !x_pl)) return UNFLOW_ERR_NULL;      // y == NULL: planes-only output
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return UNFLOW_ERR_SHAPE;
   const int Ci8 = (Cin + 7) & ~7;
   const bool rgb4 = rgb4_form(x_pl, W, Cin, k, stride) && Cout > 4 && planes_ok(w_pl, 28) && w_pl->ld == 32 &&
                     w_pl->n_planes == x_pl->n_planes;
   if (!rgb4 && (!use_planes(x_pl, Cin, w_pl, Cin, Cout) || w_pl->ld != Ci8))
-    return unflow_conv2d_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, k, stride, leaky, plane_out(y_pl, 0, Cout), workspace,
+    return !y ? UNFLOW_ERR_UNSUPPORTED : unflow_conv2d_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, k, stride, leaky, plane_out(y_pl, 0, Cout), workspace,
                                 workspace_bytes, stream);
-  if (ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  if (y && ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   build_conv_fwd(p, B, H, W, Ci8, Cout, k, stride);
   if (rgb4) {
@@ -1746,22 +1803,24 @@ UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes
 UNFLOW_API int unflow_conv2d_bwd_data_pl(const float* dz, int lddz, const unflow_planes* dz_pl, const float* w,
                                          const unflow_planes* w_pl, float* dx, int lddx, const unflow_planes* dx_pl,
                                          int pl_lo, int pl_hi, int B, int H, int W, int Cin, int Cout, int k, int stride,
-                                         int accumulate, const float* act_src, int ld_act, int act_lo, int act_hi,
-                                         void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
-  if (!dx || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
+                                         int accumulate, const float* act_src, int ld_act, const unflow_planes* act_pl,
+                                         int act_lo, int act_hi, void* workspace, size_t workspace_bytes,
+                                         unflow_stream_t stream) {
+  if ((!dx && !(dx_pl && dx_pl->base)) || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || (stride != 1 && stride != 2)) return UNFLOW_ERR_SHAPE;
   const int Co8 = (Cout + 7) & ~7;
   const bool pointwise32 = k == 1 && stride == 1 && Cout == 32;      // conv_redir: the streaming kernel of conv_igemm.hip
   if (pointwise32 || !use_planes(dz_pl, Cout, w_pl, Cout, Cout) || w_pl->ld != Co8)
-    return unflow_conv2d_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, k, stride, accumulate, act_src, ld_act, act_lo,
+    return (!dx || (!act_src && act_pl && act_hi > act_lo)) ? UNFLOW_ERR_UNSUPPORTED : unflow_conv2d_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, k, stride, accumulate, act_src, ld_act, act_lo,
                                      act_hi, plane_out(dx_pl, pl_lo, pl_hi), workspace, workspace_bytes, stream);
-  if (lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
+  if (dx && lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   const int bc = build_conv_dgrad(p, B, H, W, Cin, Co8, k, stride);
   if (bc != UNFLOW_OK) return bc;
   p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
-  p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_src = act_src; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
+  p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_lo = act_lo; p.act_hi = act_hi;
+  set_act(p, act_src, ld_act, act_pl);
   p.leaky = 0; p.accumulate = accumulate;
   p.pl = plane_out(dx_pl, pl_lo, pl_hi);
   return run_pl_gather(p, dz_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
@@ -1791,13 +1850,13 @@ UNFLOW_API int unflow_conv2d_transpose_fwd_pl(const float* x, int ldx, const unf
                                               const unflow_planes* w_pl, const float* bias, float* y, int ldy,
                                               const unflow_planes* y_pl, int B, int H, int W, int Cin, int Cout, int leaky,
                                               void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
-  if (!y || (!x && !x_pl)) return UNFLOW_ERR_NULL;
+  if ((!y && !(y_pl && y_pl->base)) || (!x && !x_pl)) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
   const int Ci8 = (Cin + 7) & ~7;
   if (!use_planes(x_pl, Cin, w_pl, Cin, Cout) || w_pl->ld != Ci8)
-    return unflow_conv2d_transpose_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, leaky, plane_out(y_pl, 0, Cout), workspace,
+    return !y ? UNFLOW_ERR_UNSUPPORTED : unflow_conv2d_transpose_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, leaky, plane_out(y_pl, 0, Cout), workspace,
                                           workspace_bytes, stream);
-  if (ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  if (y && ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   build_deconv_fwd(p, B, H, W, Ci8, Cout);
   p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
@@ -1811,20 +1870,21 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_data_pl(const float* dz, int lddz, co
                                                    const unflow_planes* w_pl, float* dx, int lddx,
                                                    const unflow_planes* dx_pl, int pl_lo, int pl_hi, int B, int H, int W,
                                                    int Cin, int Cout, int accumulate, const float* act_src, int ld_act,
-                                                   int act_lo, int act_hi, void* workspace, size_t workspace_bytes,
-                                                   unflow_stream_t stream) {
-  if (!dx || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
+                                                   const unflow_planes* act_pl, int act_lo, int act_hi, void* workspace,
+                                                   size_t workspace_bytes, unflow_stream_t stream) {
+  if ((!dx && !(dx_pl && dx_pl->base)) || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
   const int Co8 = (Cout + 7) & ~7;
   if (!use_planes(dz_pl, Cout, w_pl, Cout, Cout) || w_pl->ld != Co8 || Cin <= 4)
-    return unflow_conv2d_transpose_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, accumulate, act_src, ld_act, act_lo,
+    return (!dx || (!act_src && act_pl && act_hi > act_lo)) ? UNFLOW_ERR_UNSUPPORTED : unflow_conv2d_transpose_bwd_data_po(dz, lddz, w, dx, lddx, B, H, W, Cin, Cout, accumulate, act_src, ld_act, act_lo,
                                                act_hi, plane_out(dx_pl, pl_lo, pl_hi), workspace, workspace_bytes, stream);
-  if (lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
+  if (dx && lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   build_deconv_dgrad(p, B, H, W, Cin, Co8);
   p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
-  p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_src = act_src; p.ld_act = ld_act; p.act_lo = act_lo; p.act_hi = act_hi;
+  p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_lo = act_lo; p.act_hi = act_hi;
+  set_act(p, act_src, ld_act, act_pl);
   p.leaky = 0; p.accumulate = accumulate;
   p.pl = plane_out(dx_pl, pl_lo, pl_hi);
   return run_pl_gather(p, dz_pl->n_planes, workspace, workspace_bytes, as_stream(stream));

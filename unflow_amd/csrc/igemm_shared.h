@@ -173,6 +173,41 @@ __device__ __forceinline__ void store_planes4(const PlaneOut& o, size_t px, int 
   *reinterpret_cast<uint2*>(d + 2 * o.plane_stride) = make_uint2(cvt_pk_bf16(s0, s1), cvt_pk_bf16(s2, s3));
 }
 
+// eight consecutive channels n .. n+7 (16-byte aligned destination): one 16-byte store per plane
+__device__ __forceinline__ void store_planes8(const PlaneOut& o, size_t px, int n, const float4 a, const float4 b) {
+  if (o.n_planes == 0 || n + 7 < o.lo || n >= o.hi) return;
+  const size_t e = px * (size_t)o.ld + n;
+  if (n < o.lo || n + 8 > o.hi || (e & 7) != 0) {   // straddles the range / not 16-byte aligned: two 8-byte halves
+    store_planes4(o, px, n, a);
+    store_planes4(o, px, n + 4, b);
+    return;
+  }
+  unsigned short* d = o.base + e;
+  if (o.n_planes == 1) {
+    u32x4 h;
+    h.x = (unsigned)to_f16_bits(a.x) | ((unsigned)to_f16_bits(a.y) << 16);
+    h.y = (unsigned)to_f16_bits(a.z) | ((unsigned)to_f16_bits(a.w) << 16);
+    h.z = (unsigned)to_f16_bits(b.x) | ((unsigned)to_f16_bits(b.y) << 16);
+    h.w = (unsigned)to_f16_bits(b.z) | ((unsigned)to_f16_bits(b.w) << 16);
+    *reinterpret_cast<u32x4*>(d) = h;
+    return;
+  }
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float x = v[2 * i], y = v[2 * i + 1];
+    const unsigned hh = cvt_pk_bf16(x, y);
+    const float rx = x - __uint_as_float(hh << 16), ry = y - __uint_as_float(hh & 0xffff0000u);
+    const unsigned mm = cvt_pk_bf16(rx, ry);
+    const float sx = rx - __uint_as_float(mm << 16), sy = ry - __uint_as_float(mm & 0xffff0000u);
+    h[i] = hh; m[i] = mm; l[i] = cvt_pk_bf16(sx, sy);
+  }
+  *reinterpret_cast<u32x4*>(d) = h;
+  *reinterpret_cast<u32x4*>(d + o.plane_stride) = m;
+  *reinterpret_cast<u32x4*>(d + 2 * o.plane_stride) = l;
+}
+
 // ------------------------------------------------------------------ host side: geometry
 inline void same_pads(int in, int k, int s, int* before, int* out) {
   const int o = (in + s - 1) / s;
