@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the two secondary configs (BASELINE configs[3] CSS 768x1024 B=2 and configs[4] fp16 B=8: sub-processes)")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the second timing pass without the all-reduce")
+    ap.add_argument("--overlap-adam", action="store_true",
+                    help="one rank: keep the backward cuts and run each part's L2/Adam + weight re-split on a second stream "
+                         "under the remaining backward pass (what N > 1 does behind its all-reduce); default off (measured slower)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 (default): fp32-equivalent arithmetic (UNFLOW_CONV_MATH picks the kernels); f16: fp16 activations "
                          "and weights into the fp16 MFMA with fp32 accumulation (BASELINE configs[4], use --batch 8)")
@@ -132,7 +135,7 @@ def main():
     # forward + loss + backward as hipGraph replays; with more than one rank the backward pass is cut into parts, and each
     # part's gradients are all-reduced and Adam-updated on the communication stream under the rest of the backward pass
     # (unflow_amd/core/train.py).  One rank: one graph, one Adam launch.
-    runner = StepRunner(eng, world, use_graph=not args.no_graph, force_reducer=force_dist)
+    runner = StepRunner(eng, world, use_graph=not args.no_graph, force_reducer=force_dist, local_overlap=args.overlap_adam)
 
     def step():
         # input preparation is part of the step (unsupervised.py:29-31,67-68): next raw minibatch -> /255, mean

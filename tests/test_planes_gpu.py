@@ -108,13 +108,18 @@ CONV_CASES = [
     (1, 16, 32, 388, 64, 3, 1),    # 49 granules per tap: partial last chunk; N = 64 tile
     (1, 10, 40, 128, 96, 3, 1),    # tile tails in both directions (10 = 2.5 x 4, 40 = 1.25 x 32), N tail
     (1, 32, 32, 64, 64, 1, 1),     # 1x1: halo = tile
+    # halo kernel over four ACCUMULATING parity classes (source stride 2: forward of stride-2 convs)
+    (1, 38, 70, 40, 96, 3, 2),     # 3x3 s2: classes 2x2 / 2x1 / 1x2 / 1x1 taps, ragged 19 x 35 site grid, N tail
+    (2, 64, 128, 16, 64, 7, 2),    # 7x7 s2 (FlowNetS conv1-like, Cin 14 -> 16): classes 4x4 .. 3x3, half-filled chunk, N = 64 tile
+    (8, 96, 128, 128, 256, 5, 2),  # conv3 at the step's shape
 ]
 
 
 @pytest.mark.parametrize("P", [3, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_planes_vs_fp64(case, P, dev):
+def test_conv_planes_vs_fp64(case, P, dev, lib_option):
     from unflow_amd.core import layers as L
+    lib_option("halo_s2", 2)       # the accumulating-class halo form wherever it applies (by default only from 384 tiles up)
     B, H, W, Cin, Cout, k, stride = case
     g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
     x = torch.randn(B, H, W, Cin, generator=g)
@@ -228,13 +233,16 @@ DECONV_CASES = [
     (1, 24, 32, 772, 128),    # deconv3
     (1, 24, 32, 388, 64),     # deconv2
     (2, 12, 16, 76, 12),      # 3/8-width full_res deconv1: Cout 12
+    (2, 24, 64, 388, 64),     # data gradient through the halo kernel (accumulating 2x2-tap classes): 24 x 64 site grid
+    (1, 9, 40, 128, 40),      # ... ragged tiles
 ]
 
 
 @pytest.mark.parametrize("P", [3, 1])
 @pytest.mark.parametrize("case", DECONV_CASES)
-def test_deconv_planes_vs_fp64(case, P, dev):
+def test_deconv_planes_vs_fp64(case, P, dev, lib_option):
     from unflow_amd.core import layers as L
+    lib_option("halo_s2", 2)
     from oracle import model_ref as M
     B, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))

@@ -559,7 +559,7 @@ constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
 }
 
 template <int BN, int WM, int WN, int NPL, bool F16>
-__global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams p, int HPmax) {
+__global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherParams p, int HPmax) {
   constexpr int BM = 128;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -578,26 +578,37 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   int t, ntile, cls_id, split;
-  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id, split);
+  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.acc ? 1 : p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id,
+              split);
   if (t < 0) return;
   const int mtile_id = t;
-  const TapClass tc = p.cls[cls_id];
+  // Tap classes of this block.  Output-parity classes (data gradient of a stride-2 conv, conv_transpose forward) write
+  // different pixels: one class per block (cls_id).  ACCUMULATING classes (p.acc: forward of a stride-2 conv, data gradient
+  // of a conv_transpose — source stride 2) all add into the same output tile: on the four parity sub-lattices of the source
+  // (pixel pitch p.sp = 2) a stride-2 k x k conv is the sum of four stride-1 convs with ceil / floor (k/2)^2 taps, each
+  // served by its own halo; the block walks class after class (class-major, then chunk, then tap).
+  const int c_first = p.acc ? 0 : cls_id, c_last = p.acc ? p.ncls : cls_id + 1;
+  const TapClass tc = p.cls[c_first];           // (geometry of the pixel table; the first class to load / multiply)
   const int n0 = ntile * BN;
-  const int ntaps = tc.nty * tc.ntx;
   const int Cg = p.Cs >> 3;
   const int nchunk = (Cg + 3) >> 2;
   const int ch_per = (nchunk + p.nsplit - 1) / p.nsplit;
-  const int kt0 = split * ch_per * ntaps, kt1 = min(nchunk, (split + 1) * ch_per) * ntaps;
+  const int ch0 = split * ch_per, ch1 = min(nchunk, (split + 1) * ch_per);
+  int sumtaps = 0, mtx = 0;
+  for (int c = c_first; c < c_last; c++) {
+    sumtaps += p.cls[c].nty * p.cls[c].ntx;
+    mtx = max(mtx, p.cls[c].ntx);
+  }
+  const int T = max(ch1 - ch0, 0) * sumtaps;    // K tiles of this block
 
   // tile -> (image, tile row, tile column)
   const int txi = t % p.tiles_x; t /= p.tiles_x;
   const int tyi = t % p.tiles_y;
   const int b = t / p.tiles_y;
   const int y0 = tyi * TH, x0 = txi * TW;
-  // halo geometry of this class: source rows y0 + dmin_y .. + HR - 1
-  const int dmin_y = p.dstep > 0 ? tc.dy0 : tc.dy0 - (tc.nty - 1);
-  const int dmin_x = p.dstep > 0 ? tc.dx0 : tc.dx0 - (tc.ntx - 1);
-  const int HC = TW + tc.ntx - 1, HR = TH + tc.nty - 1, HP = HR * HC;
+  // halo image in LDS: HC pixels per row for every class of the block (the widest class's); halo pixel (hy, hx) = source
+  // pixel ((y0 + hy) * sp + dmin_y, (x0 + hx) * sp + dmin_x) of the class being loaded
+  const int HC = TW + mtx - 1;
 
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
@@ -607,16 +618,23 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   }
   const int kq = tid & 3;
   const int lds2 = p.lds * 2;
-  // this thread's halo granules: pixel hp = (tid >> 2) + 64 j, granule kq of the chunk
+  // this thread's halo granules: pixel hp = (tid >> 2) + 64 j, granule kq of the chunk — for the class being LOADED
   int h_off[NH];
+  TapClass ltc = tc;                            // load-side class
+  auto set_load_class = [&]() {
+    const int dmy = p.dstep > 0 ? ltc.dy0 : ltc.dy0 - (ltc.nty - 1);     // source offset of halo pixel (0, 0)
+    const int dmx = p.dstep > 0 ? ltc.dx0 : ltc.dx0 - (ltc.ntx - 1);
+    const int HRc = TH + ltc.nty - 1, HCc = TW + ltc.ntx - 1;
 #pragma unroll
-  for (int j = 0; j < NH; j++) {
-    const int hp = (tid >> 2) + 64 * j;
-    const int hy = hp / HC, hx = hp - hy * HC;
-    const int y = y0 + dmin_y + hy, x = x0 + dmin_x + hx;
-    const bool ok = hp < HP && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-    h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
-  }
+    for (int j = 0; j < NH; j++) {
+      const int hp = (tid >> 2) + 64 * j;
+      const int hy = hp / HC, hx = hp - hy * HC;
+      const int y = (y0 + hy) * p.sp + dmy, x = (x0 + hx) * p.sp + dmx;
+      const bool ok = hy < HRc && hx < HCc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+      h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
+    }
+  };
+  set_load_class();
   if (tid < BM) {
     const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
     pix[tid] = (yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px : -1;
@@ -631,10 +649,10 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   u32x4 rh[NH][NPL], rb[NB][NPL];
   // loads of the NEXT K tile (chunk ld_chunk, tap (ld_ty, ld_tx); advanced once per tile, no divisions in the loop):
   // weights always, the halo when the tile opens a chunk
-  int ld_chunk = kt0 / ntaps, ld_ty = 0, ld_tx = 0;
-  bool ld_live = kt0 < kt1;
+  int ld_c = c_first, ld_chunk = ch0, ld_ty = 0, ld_tx = 0;
+  bool ld_live = T > 0;
   auto load_b = [&](int i) {
-    const int widx = (tc.ky0 + ld_ty * p.kstep) * p.KW + tc.kx0 + ld_tx * p.kstep;
+    const int widx = (ltc.ky0 + ld_ty * p.kstep) * p.KW + ltc.kx0 + ld_tx * p.kstep;
     const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
     const int voff = ok ? b_row[i] + widx * p.N * p.Cs * 2 + ld_chunk * 64 : OOB_MARK;
 #pragma unroll
@@ -648,9 +666,15 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   };
   auto ld_advance = [&](int kk_next) {     // the loads now target tile kk_next + 1... called after tile kk_next's loads
     ld_tx++;
-    if (ld_tx == tc.ntx) { ld_tx = 0; ld_ty++; }
-    if (ld_ty == tc.nty) { ld_ty = 0; ld_chunk++; }
-    ld_live = kk_next + 1 < kt1;
+    if (ld_tx == ltc.ntx) { ld_tx = 0; ld_ty++; }
+    if (ld_ty == ltc.nty) { ld_ty = 0; ld_chunk++; }
+    if (ld_chunk == ch1 && ld_c + 1 < c_last) {          // next class (accumulating classes only)
+      ld_chunk = ch0;
+      ld_c++;
+      ltc = p.cls[ld_c];
+      set_load_class();
+    }
+    ld_live = kk_next + 1 < T;
   };
   auto swz = [](int row, int g) { return row * LDH + 8 * (g ^ ((row >> 2) & 3)); };
   auto store_b = [&]() {
@@ -695,16 +719,17 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
   for (int j = 0; j < NH; j++) load_h(j);
 #pragma unroll
   for (int i = 0; i < NB; i++) load_b(i);
-  ld_advance(kt0);
+  ld_advance(0);
   store_h();
   store_b();
   __syncthreads();
   constexpr int NGROUP = 2 * TM * NT;
   constexpr int NPIECE = NB + NH;
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
-  int ty = 0, tx = 0;                            // tap of the tile being multiplied (kt0 is a chunk boundary)
-  for (int kk = kt0; kk < kt1; kk++) {
-    const int hyi = (tc.dy0 + ty * p.dstep) - dmin_y, hxi = (tc.dx0 + tx * p.dstep) - dmin_x;
+  int ty = 0, tx = 0;                            // tap of the tile being multiplied, and the halo position of its class's tap (0, 0)
+  int c_hy0 = p.dstep > 0 ? 0 : tc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : tc.ntx - 1;
+  for (int kk = 0; kk < T; kk++) {
+    const int hyi = c_hy0 + ty * p.dstep, hxi = c_hx0 + tx * p.dstep;
     const int tapoff = (hyi * HC + hxi) * HPITCH;
     const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
     auto piece = [&](int step) {
@@ -778,7 +803,9 @@ __global__ __launch_bounds__(256) void igemm_pl_halo_kernel(const PlGatherParams
     store_b();
     if (new_chunk) store_h();
     __syncthreads();
-    ty = ld_ty; tx = ld_tx;
+    ty = ld_ty; tx = ld_tx;          // the tile just stored is the next one multiplied: its tap, its class's halo origin
+    c_hy0 = p.dstep > 0 ? 0 : ltc.nty - 1;
+    c_hx0 = p.dstep > 0 ? 0 : ltc.ntx - 1;
     ld_advance(kk + 1);
   }
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
@@ -1383,13 +1410,15 @@ inline size_t pl_gather_partial_bytes(const GatherGeom& p, int nsplit) {
 }
 
 // workgroups of a launch (q.mt, q.nt set): order 2 pads the M tiles to whole groups
+inline int pl_grid_classes(const GatherGeom& q) { return q.acc ? 1 : q.ncls; }   // accumulating classes share a block
+
 inline int pl_grid(PlGatherParams& q) {
   int mt = q.mt;
   if (q.order == 2) {
     q.mgroup = q.mt >= 16 ? cdiv(q.mt, 8) : q.mt;
     mt = cdiv(q.mt, q.mgroup) * q.mgroup;
   }
-  return mt * q.nt * q.ncls * q.nsplit;
+  return mt * q.nt * pl_grid_classes(q) * q.nsplit;
 }
 
 // 2-D site tiles of the plain gather kernels when they divide the site grid exactly (TW = min(32, Wg) sites wide)
@@ -1433,18 +1462,34 @@ int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
 }
 
 // ---- halo kernel: eligibility, plan, launch
+inline int pl_halo_pixels(const GatherGeom& p) {
+  int hp = 0, mty = 0, mtx = 0;
+  for (int c = 0; c < p.ncls; c++) {
+    hp = max(hp, (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1));
+    mty = max(mty, p.cls[c].nty); mtx = max(mtx, p.cls[c].ntx);
+  }
+  return p.acc ? (TH + mty - 1) * (TW + mtx - 1) : hp;      // accumulating classes share one halo image (widest row pitch)
+}
 inline bool pl_halo_ok(const GatherGeom& p) {
   const bool off = !unflow::options().halo;
   if (off || p.sm != 1 || (p.dstep != 1 && p.dstep != -1) || p.Hg < 2 * TH || p.Wg < TW || p.N <= 32) return false;
+  if (p.acc && (p.dstep != 1 || !unflow::options().halo_s2)) return false;
   for (int c = 0; c < p.ncls; c++)
-    if (p.cls[c].nty < 1 || p.cls[c].ntx < 1 || (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1) > 256) return false;
-  return true;
+    if (p.cls[c].nty < 1 || p.cls[c].ntx < 1) return false;
+  return pl_halo_pixels(p) <= 256;
 }
-inline int pl_halo_pixels(const GatherGeom& p) {
-  int hp = 0;
-  for (int c = 0; c < p.ncls; c++) hp = max(hp, (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1));
-  return hp;
+// The accumulating-class form of a source-stride-2 layer (build_conv_fwd_s2acc / build_deconv_dgrad_acc) against the plain
+// gather kernel: the halo kernel runs two 128 x 128 blocks per CU (the gather kernel three) and splits K only over whole
+// channel chunks, so it pays where the layer has tiles to spare — measured per layer on MI355X (profiles/r03_halo_s2_per_layer.txt):
+// conv2 fwd 243 -> 226 us (768 tiles), conv3 fwd 254 -> 244 (384), deconv2 dgrad 138 -> 131 (768), but conv4 fwd 98 -> 108
+// (192 tiles) and deconv3 dgrad 134 -> 141 (336).
+inline bool pl_halo_acc_pays(const GatherGeom& a) {
+  if (!a.acc || !pl_halo_ok(a)) return false;
+  const int bn = a.N <= 64 ? 64 : 128;
+  const long tiles = (long)a.B * cdiv(a.Hg, TH) * cdiv(a.Wg, TW) * cdiv(a.N, bn);
+  return tiles >= 384 || unflow::options().halo_s2 >= 2;      // (halo_s2 = 2: wherever the kernel applies — tests)
 }
+
 inline int pl_halo_smem(const GatherGeom& p, int bn, int npl) {
   return pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, npl, pl_halo_pixels(p)) + 128 * 4 + 16;
 }
@@ -1453,10 +1498,14 @@ inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
   *bn_out = bn;
   const int smem = pl_halo_smem(p, bn, npl);
   const int per_cu = min((160 * 1024) / smem, bn == 128 ? 2 : 3);
-  const long blocks = (long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) * cdiv(p.N, bn) * p.ncls;
+  const long blocks = (long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) * cdiv(p.N, bn) * pl_grid_classes(p);
   const int nchunk = ((p.Cs >> 3) + 3) >> 2;
-  int maxtaps = 0;
-  for (int c = 0; c < p.ncls; c++) maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
+  int maxtaps = 0, sumtaps = 0;
+  for (int c = 0; c < p.ncls; c++) {
+    maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
+    sumtaps += p.cls[c].nty * p.cls[c].ntx;
+  }
+  if (p.acc) maxtaps = sumtaps;                                       // a block walks every class
   const int max_by_k = max(1, min(16, nchunk * maxtaps / 16));      // >= 16 K tiles per split, whole chunks
   return min(nchunk, fill_one_round(blocks, 256 * per_cu, max_by_k));
 }
@@ -1474,7 +1523,7 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   PlGatherParams q = p;
   q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
   const int grid = pl_grid(q);
-  if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * pl_grid_classes(q) * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
   igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<grid, 256, smem, st>>>(q, hp);
   return launch_status();
 }
@@ -1733,6 +1782,8 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
   GatherGeom g{};
   build_conv_fwd(g, B, H, W, Ci8, Cout, k, stride);
   need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
+  if (stride == 2 && build_conv_fwd_s2acc(g, B, H, W, Ci8, Cout, k) && pl_halo_acc_pays(g))
+    need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
   GatherGeom d{};
   if ((stride == 1 || stride == 2) && build_conv_dgrad(d, B, H, W, Cin, Co8, k, stride) == UNFLOW_OK)
     need = max(need, pl_gather_partial_bytes(d, pl_gather_nsplit(d, n_planes)));
@@ -1752,6 +1803,8 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
     GatherGeom td{};
     build_deconv_dgrad(td, B, H / 2, W / 2, Cin, Co8);
     need = max(need, pl_gather_partial_bytes(td, pl_gather_nsplit(td, n_planes)));
+    build_deconv_dgrad_acc(td, B, H / 2, W / 2, Cin, Co8);
+    if (pl_halo_acc_pays(td)) need = max(need, pl_gather_partial_bytes(td, pl_gather_nsplit(td, n_planes)));
     WgradGeom tw{};
     build_deconv_wgrad(tw, B, H / 2, W / 2, Cin, Co8);
     need = max(need, pl_wgrad_plan_bytes(tw, Cout, n_planes));
@@ -1789,6 +1842,10 @@ UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes
   if (y && ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   build_conv_fwd(p, B, H, W, Ci8, Cout, k, stride);
+  if (stride == 2 && !rgb4) {       // source stride 2: the halo kernel over four accumulating parity classes, where it applies
+    GatherGeom a{};
+    if (build_conv_fwd_s2acc(a, B, H, W, Ci8, Cout, k) && pl_halo_acc_pays(a)) static_cast<GatherGeom&>(p) = a;
+  }
   if (rgb4) {
     p.Cs = 32; p.KW = 1; p.wtaps = 7; p.gpx = 2;
     p.cls[0].ntx = 1;
@@ -1881,6 +1938,11 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_data_pl(const float* dz, int lddz, co
   if (dx && lddx < Cin) return UNFLOW_ERR_UNSUPPORTED;
   PlGatherParams p{};
   build_deconv_dgrad(p, B, H, W, Cin, Co8);
+  {
+    GatherGeom a{};
+    build_deconv_dgrad_acc(a, B, H, W, Cin, Co8);
+    if (pl_halo_acc_pays(a)) static_cast<GatherGeom&>(p) = a;
+  }
   p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
   p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_lo = act_lo; p.act_hi = act_hi;

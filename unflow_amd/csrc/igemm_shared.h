@@ -30,6 +30,8 @@ struct GatherGeom {
   int Hd, Wd, so;
   int ncls;
   int wtaps;  // taps of the whole weight tensor (KH*KW)
+  int sp;     // halo kernel: pitch of the class's source pixels (1; 2 for the parity sub-lattices of a source-stride-2 layer)
+  int acc;    // halo kernel: 1 = the classes accumulate into ONE output tile (one block walks them all), 0 = one class per block
   TapClass cls[4];
 };
 
@@ -225,8 +227,25 @@ inline void build_conv_fwd(GatherGeom& p, int B, int H, int W, int Cin, int Cout
   same_pads(W, k, stride, &pl, &Wo);
   p.B = B; p.Hg = Ho; p.Wg = Wo; p.Hs = H; p.Ws = W; p.sm = stride;
   p.dstep = 1; p.kstep = 1; p.KW = k; p.Cs = Cin; p.N = Cout; p.wtaps = k * k;
-  p.Hd = Ho; p.Wd = Wo; p.so = 1; p.ncls = 1;
+  p.Hd = Ho; p.Wd = Wo; p.so = 1; p.ncls = 1; p.sp = 1; p.acc = 0;
   p.cls[0] = TapClass{k, k, -pt, -pl, 0, 0, 0, 0};
+}
+
+// The same layer for the halo kernel when stride == 2: source pixel 2*yg - pt + ky with ky = py + 2a is pixel (yg + a) of
+// the parity sub-lattice {2*y' + py - pt}, so the conv is the sum over the four (py, px) of a stride-1 conv with
+// ceil((k - py) / 2) x ceil((k - px) / 2) taps on its sub-lattice (pixel pitch 2): four ACCUMULATING tap classes.
+inline bool build_conv_fwd_s2acc(GatherGeom& p, int B, int H, int W, int Cin, int Cout, int k) {
+  if (k < 2) return false;
+  build_conv_fwd(p, B, H, W, Cin, Cout, k, 2);
+  const int pt = -p.cls[0].dy0, pl = -p.cls[0].dx0;
+  p.sm = 1; p.sp = 2; p.acc = 1; p.ncls = 4; p.kstep = 2; p.dstep = 1;
+  for (int c = 0; c < 4; c++) {
+    const int py = c >> 1, px = c & 1;
+    const int nty = (k - py + 1) / 2, ntx = (k - px + 1) / 2;
+    if (nty < 1 || ntx < 1) return false;
+    p.cls[c] = TapClass{nty, ntx, py - pt, px - pl, py, px, 0, 0};
+  }
+  return true;
 }
 
 inline int build_conv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
@@ -235,7 +254,7 @@ inline int build_conv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cou
   same_pads(W, k, stride, &pl, &Wo);
   p.B = B; p.Hs = Ho; p.Ws = Wo; p.sm = 1;
   p.dstep = -1; p.KW = k; p.Cs = Cout; p.N = Cin; p.wtaps = k * k;
-  p.Hd = H; p.Wd = W;
+  p.Hd = H; p.Wd = W; p.sp = 1; p.acc = 0;
   if (stride == 1) {
     p.Hg = H; p.Wg = W; p.so = 1; p.ncls = 1; p.kstep = 1;
     p.cls[0] = TapClass{k, k, pt, pl, 0, 0, 0, 0};
@@ -258,7 +277,7 @@ inline int build_conv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cou
 inline void build_deconv_fwd(GatherGeom& p, int B, int H, int W, int Cin, int Cout) {
   p.B = B; p.Hg = H; p.Wg = W; p.Hs = H; p.Ws = W; p.sm = 1;
   p.dstep = -1; p.kstep = 2; p.KW = 4; p.Cs = Cin; p.N = Cout; p.wtaps = 16;
-  p.Hd = 2 * H; p.Wd = 2 * W; p.so = 2; p.ncls = 4;
+  p.Hd = 2 * H; p.Wd = 2 * W; p.so = 2; p.ncls = 4; p.sp = 1; p.acc = 0;
   for (int c = 0; c < 4; c++) {
     const int py = c >> 1, px = c & 1;
     const int ky0 = (py + 1) & 1, kx0 = (px + 1) & 1;
@@ -269,8 +288,19 @@ inline void build_deconv_fwd(GatherGeom& p, int B, int H, int W, int Cin, int Co
 inline void build_deconv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cout) {
   p.B = B; p.Hg = H; p.Wg = W; p.Hs = 2 * H; p.Ws = 2 * W; p.sm = 2;
   p.dstep = 1; p.kstep = 1; p.KW = 4; p.Cs = Cout; p.N = Cin; p.wtaps = 16;
-  p.Hd = H; p.Wd = W; p.so = 1; p.ncls = 1;
+  p.Hd = H; p.Wd = W; p.so = 1; p.ncls = 1; p.sp = 1; p.acc = 0;
   p.cls[0] = TapClass{4, 4, -1, -1, 0, 0, 0, 0};
+}
+
+// ... for the halo kernel: dz pixel 2*iy - 1 + ky, ky = py + 2a: four accumulating 2 x 2-tap classes on the parity
+// sub-lattices of dz (see build_conv_fwd_s2acc)
+inline void build_deconv_dgrad_acc(GatherGeom& p, int B, int H, int W, int Cin, int Cout) {
+  build_deconv_dgrad(p, B, H, W, Cin, Cout);
+  p.sm = 1; p.sp = 2; p.acc = 1; p.ncls = 4; p.kstep = 2; p.dstep = 1;
+  for (int c = 0; c < 4; c++) {
+    const int py = c >> 1, px = c & 1;
+    p.cls[c] = TapClass{2, 2, py - 1, px - 1, py, px, 0, 0};
+  }
 }
 
 inline void build_conv_wgrad(WgradGeom& p, int B, int H, int W, int Cin, int Cout, int k, int stride) {
