@@ -241,7 +241,8 @@ def measure_roofline(eng, args):
     import torch
     from unflow_amd.core import layers as L
     gflop, _ = conv_family_gflop(eng)
-    names = ["conv_fwd", "conv_bwd_data", "conv_bwd_filter", "deconv_fwd", "deconv_bwd_data", "deconv_bwd_filter"]
+    names = ["conv_fwd", "conv_bwd_data", "conv_bwd_filter", "deconv_fwd", "deconv_bwd_data", "deconv_bwd_filter",
+             "flow_wgrad_batched"]
     orig = {n: getattr(L, n) for n in names}
     calls = []
 

@@ -408,6 +408,15 @@ int unflow_weight_planes_batched(int n, const float* const* w, const int* taps, 
 
 size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes);
 
+/* Every Cout = 2 filter gradient of a refinement decoder (flownet.py:89-131: flowN = conv k3 -> 2, flowN_upM =
+ * conv2d_transpose 2 -> 2) in one batch of two launches.  kind[i] 0: flowN head — x [B,H,W,Cin] (ldx), dz [B,H,W,2] (lddz),
+ * dw [3,3,Cin,2]; kind[i] 1: flowN_upM — x [B,H,W,2], dz [B,2H,2W,2], dw [4,4,2,2] (Cin[i] = 2).  n <= 16.
+ * UNFLOW_ERR_UNSUPPORTED when a layer has no strip form (W % 4 != 0): use the per-layer entry points then. */
+size_t unflow_flow_wgrad_batched_workspace_bytes(int n, const int* kind, const int* B, const int* H, const int* W, const int* Cin);
+int unflow_flow_wgrad_batched(int n, const int* kind, const float* const* x, const int* ldx, const float* const* dz,
+                              const int* lddz, float* const* dw, const int* B, const int* H, const int* W, const int* Cin,
+                              void* workspace, size_t workspace_bytes, unflow_stream_t stream);
+
 /* Test hook (host only, no GPU): the (M tile, N tile, parity class, K split) each workgroup of a gather / halo launch decodes from
  * its linear id — XCD-contiguous remap + work order 0 / 1 / 2 of csrc/conv_planes.hip — 4 ints per workgroup, M tile = -1 for
  * the padding workgroups of order 2.  Returns the grid size (out == NULL: query only). */

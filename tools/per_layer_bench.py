@@ -37,7 +37,8 @@ def main():
     eng.set_input(im1, im2)
     eng.fwd_bwd()
     torch.cuda.synchronize()
-    names = ["conv_fwd", "conv_bwd_data", "conv_bwd_filter", "deconv_fwd", "deconv_bwd_data", "deconv_bwd_filter"]
+    names = ["conv_fwd", "conv_bwd_data", "conv_bwd_filter", "deconv_fwd", "deconv_bwd_data", "deconv_bwd_filter",
+             "flow_wgrad_batched"]
     orig = {n: getattr(L, n) for n in names}
     calls = []
 
@@ -63,6 +64,23 @@ def main():
     tot_us = tot_gf = 0.0
     print("%-18s %-22s %-22s %5s %9s %8s" % ("pass", "in [B,H,W,C]", "out [B,H,W,C]", "k", "us", "TFLOP/s"))
     for n, fn, a, k in calls:
+        if n == "flow_wgrad_batched":       # all Cout = 2 filter gradients of the decoder: one batch
+            jobs = a[0]
+            gf = sum(2.0 * shape(j[2])[0] * shape(j[2])[1] * shape(j[2])[2] * (9 if j[0] == 'conv' else 4) * shape(j[1])[3] * 2
+                     for j in jobs) / 1e9
+            for _ in range(3):
+                fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn(*a, **k)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.reps
+            tot_us += us
+            tot_gf += gf
+            print("%-18s %-22s %-22s %5d %9.1f %8.1f" % ("flow_wgrad_batch", "%d layers" % len(jobs), "Cout=2", 0, us, gf / us * 1e3))
+            continue
         if n in ("conv_fwd", "deconv_fwd"):
             si, so = shape(a[0]), shape(a[4])
             w = a[1]

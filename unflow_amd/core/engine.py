@@ -429,6 +429,11 @@ class _Stage:
             if e.wgrad_sync_each:
                 main.wait_stream(side)
 
+        # the Cout = 2 layers (flow heads, 2 -> 2 flow upsamplers): their filter gradients leave as ONE batch as soon as the
+        # last of them has been visited (all their gradients are final then)
+        flow_jobs = []
+        n_flow = sum(1 for op, _, _, _ in self.bwd[lo:hi] if op.kind == 'layer' and op.l.cout <= 2) if e.batch_flow_wgrad else 0
+
         for op, first, act_lo, act_hi in self.bwd[lo:hi]:
             if op.kind == 'corr':
                 c3, g3, gout = self.pt(op.src), self.pt(op.src, True), self.pt(op.dst, True)
@@ -448,7 +453,12 @@ class _Stage:
             if e._bias_plan is None:
                 e._bias_jobs.append((dz.t, l))       # bias gradients: one batched column-sum launch at the end
             wg = (L.conv_bwd_filter, (x, dz, l.dw, l.stride)) if l.kind == 'conv' else (L.deconv_bwd_filter, (x, dz, l.dw))
-            if side is None or (e.wgrad_inline_tiny and l.cout <= 2):
+            if n_flow and l.cout <= 2:
+                flow_jobs.append((l.kind, x, dz, l.dw))
+                wg = (L.flow_wgrad_batched, (flow_jobs,)) if len(flow_jobs) == n_flow else None
+            if wg is None:
+                pass
+            elif side is None or (e.wgrad_inline_tiny and l.cout <= 2):
                 wg[0](*wg[1])
             else:
                 pending.append(wg)
@@ -509,6 +519,7 @@ class FlowNetEngine:
         # True: the Cout = 2 layers' filter gradients (flow heads, 2 -> 2 upsamplers: small latency-bound kernels) stay on the main
         # stream; False (default): they join the groups on the second stream like every other filter gradient
         self.wgrad_inline_tiny = False
+        self.batch_flow_wgrad = True      # all Cout = 2 filter gradients of a decoder in one batched launch pair
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
         if layout_only:
             self.n_planes = 0

@@ -285,3 +285,42 @@ def deconv_bwd_filter(x, dz, dw):
     check(_lib.lib().unflow_conv2d_transpose_bwd_filter_pl(xp, ldx, _lib.planes_of(x.pl), dzp, lddz, _lib.planes_of(dz.pl),
                                                            ptr(dw), B, H, W, Cin, Cout, wsp, wsn, stream()),
           "conv2d_transpose_bwd_filter_pl")
+
+
+def flow_wgrad_batched(jobs):
+    """Filter gradients of all Cout = 2 layers of a decoder in one batch (csrc/conv_igemm.hip: flow_wgrad_batched_kernel).
+    jobs: [(kind, x, dz, dw)] with kind 'conv' (flowN: x [B,H,W,Cin], dz [B,H,W,2], dw [3,3,Cin,2]) or 'deconv' (flowN_upM:
+    x [B,H,W,2], dz [B,2H,2W,2], dw [4,4,2,2]); x / dz may be PTs.  Falls back to the per-layer calls when a level has no
+    strip form."""
+    import ctypes
+    n = len(jobs)
+    if n == 0:
+        return
+    xs = [_pt(j[1]).t for j in jobs]
+    dzs = [_pt(j[2]).t for j in jobs]
+    kinds = (ctypes.c_int * n)(*[0 if j[0] == 'conv' else 1 for j in jobs])
+    dims = [nhwc(x) for x in xs]
+    Bs = (ctypes.c_int * n)(*[d[2] for d in dims])
+    Hs = (ctypes.c_int * n)(*[d[3] for d in dims])
+    Ws = (ctypes.c_int * n)(*[d[4] for d in dims])
+    Cs = (ctypes.c_int * n)(*[d[5] for d in dims])
+    lib = _lib.lib()
+    lib.unflow_flow_wgrad_batched_workspace_bytes.restype = ctypes.c_size_t
+    need = lib.unflow_flow_wgrad_batched_workspace_bytes(n, kinds, Bs, Hs, Ws, Cs)
+    if need == 0 or n > 16:
+        for kind, x, dz, dw in jobs:
+            if kind == 'conv':
+                conv_bwd_filter(x, dz, dw, 1)
+            else:
+                deconv_bwd_filter(x, dz, dw)
+        return
+    for (kind, x, dz, dw), xt, dzt in zip(jobs, xs, dzs):
+        assert dw.is_contiguous() and dzt.shape[-1] == 2
+        assert tuple(dw.shape) == ((3, 3, xt.shape[-1], 2) if kind == 'conv' else (4, 4, 2, 2))
+    ws = workspace(need, xs[0].device, slot=_WS_SLOT[0])
+    check(lib.unflow_flow_wgrad_batched(n, kinds, (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs]),
+                                        (ctypes.c_int * n)(*[x.stride(2) for x in xs]),
+                                        (ctypes.c_void_p * n)(*[d.data_ptr() for d in dzs]),
+                                        (ctypes.c_int * n)(*[d.stride(2) for d in dzs]),
+                                        (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in jobs]), Bs, Hs, Ws, Cs, ptr(ws),
+                                        csz(ws.numel() * 4), stream()), "flow_wgrad_batched")

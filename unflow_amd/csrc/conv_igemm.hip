@@ -1130,16 +1130,16 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
 // block = 4 waves x the same 64 channel quads; each wave walks its own strips, then the four register tiles are
 // summed through LDS in a fixed order (deterministic) and the block writes ONE partial.
 template <int S>
-__global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgradParams p, int strips_per_wave) {
-  __shared__ float red[72 * 64];
+__device__ __forceinline__ void head3_wgrad_strip_body(const SkinnyWgradParams& p, int strips_per_wave, int bx, int by,
+                                                       float* __restrict__ red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int Cq = p.Cin >> 2;
-  const int c4 = blockIdx.x * 64 + lane;
+  const int c4 = bx * 64 + lane;
   const bool active = c4 < Cq;
   const int cc = min(c4, Cq - 1);   // clamped: loads are unconditional, inactive lanes contribute zeros
   const int strips = p.W / S;
   const long nstrips = (long)p.B * p.H * strips;
-  const long s0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.y * 4 + wv) * strips_per_wave));
+  const long s0 = __builtin_amdgcn_readfirstlane((int)(((long)by * 4 + wv) * strips_per_wave));
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; t++)
@@ -1190,12 +1190,17 @@ __global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgra
     __syncthreads();
   }
   // partial layout [chunk][tap][Cin][2]: the quad's 8 values per tap are contiguous
-  float* o = p.partial + (size_t)blockIdx.y * 9 * p.Cin * 2;
+  float* o = p.partial + (size_t)by * 9 * p.Cin * 2;
   for (int e = threadIdx.x; e < 72 * 64; e += 256) {
     const int ln = e & 63, tj = e >> 6, t = tj >> 3, j = tj & 7;
-    const int cq = blockIdx.x * 64 + ln;
+    const int cq = bx * 64 + ln;
     if (cq < Cq) o[((size_t)t * p.Cin + cq * 4) * 2 + j] = red[e];
   }
+}
+template <int S>
+__global__ __launch_bounds__(256) void head3_wgrad_strip_kernel(const SkinnyWgradParams p, int strips_per_wave) {
+  __shared__ float red[72 * 64];
+  head3_wgrad_strip_body<S>(p, strips_per_wave, blockIdx.x, blockIdx.y, red);
 }
 
 // ------------------------------------------------------------------ 1x1 conv, 32 output channels: data gradient
@@ -1333,11 +1338,10 @@ __global__ void tiny_deconv_dgrad_kernel(const float* __restrict__ dz, int lddz,
 
 // dw[ky,kx,co,ci] partial sums per block -> partial[block][16*CO*CI]
 template <int CI, int CO>
-__global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __restrict__ x, int ldx,
-                                                                const float* __restrict__ dz, int lddz,
-                                                                float* __restrict__ partial, int B, int H, int W) {
+__device__ __forceinline__ void tiny_deconv_wgrad_body(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int lddz,
+                                                       float* __restrict__ partial, int B, int H, int W, int bx, int nblocks,
+                                                       float (*red)[16 * CO * CI]) {
   constexpr int NV = 16 * CO * CI;
-  __shared__ float red[4][NV];
   const int OH = 2 * H, OW = 2 * W;
   const long n = (long)B * H * W;
   float acc[16][CO][CI];
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __r
     for (int a = 0; a < CO; a++)
 #pragma unroll
       for (int c = 0; c < CI; c++) acc[t][a][c] = 0.f;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+  for (long e = bx * (long)blockDim.x + threadIdx.x; e < n; e += (long)nblocks * blockDim.x) {
     const int ix = (int)(e % W), iy = (int)((e / W) % H);
     const long b = e / ((long)W * H);
     float xv[CI];
@@ -1406,8 +1410,59 @@ __global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __r
   }
   __syncthreads();
   if (threadIdx.x < NV)
-    partial[(size_t)blockIdx.x * NV + threadIdx.x] =
+    partial[(size_t)bx * NV + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void tiny_deconv_wgrad_kernel(const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ dz, int lddz,
+                                                                float* __restrict__ partial, int B, int H, int W) {
+  __shared__ float red[4][16 * CO * CI];
+  tiny_deconv_wgrad_body<CI, CO>(x, ldx, dz, lddz, partial, B, H, W, blockIdx.x, gridDim.x, red);
+}
+
+// ---- every Cout = 2 filter gradient of a decoder in ONE launch (+ one launch for their partial sums) ----------------------
+// flowN (3x3, C -> 2) and flowN_upM (conv_transpose 2 -> 2): ~0.7 GFLOP in total, but nine layers x (kernel + one or two
+// partial-sum launches), each too small to fill the chip and 8-40 us long whatever its size.  All nine read data that is
+// final once the coarsest head's gradient is (the loss pyramid wrote d flowN, the 2 -> 2 data gradients added theirs), so
+// they run as one batch: a block finds its layer in a prefix table and runs that layer's body; <= 64 partials per layer,
+// summed in a fixed order by the second launch.
+constexpr int MAX_FLOW_WGRAD = 16;
+struct FlowWgradDesc {
+  SkinnyWgradParams p;      // head: x, dz, partial, dims; 2 -> 2: x = layer input (flow), dz = gradient of the 2H x 2W output
+  float* out;               // dw
+  int kind;                 // 0: head, strips of 8; 1: head, strips of 4; 2: conv_transpose 2 -> 2
+  int spw, colblocks, chunks, block0, wsz, rblock0;
+};
+struct FlowWgradBatch {
+  FlowWgradDesc d[MAX_FLOW_WGRAD];
+  int n;
+};
+__global__ __launch_bounds__(256) void flow_wgrad_batched_kernel(const FlowWgradBatch b) {
+  __shared__ float red[72 * 64];
+  int di = 0;
+  while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].block0) di++;
+  const FlowWgradDesc& d = b.d[di];
+  const int lb = blockIdx.x - d.block0;
+  if (d.kind == 2) {
+    tiny_deconv_wgrad_body<2, 2>(d.p.x, d.p.ldx, d.p.dz, d.p.lddz, d.p.partial, d.p.B, d.p.H, d.p.W, lb, d.chunks,
+                                 reinterpret_cast<float(*)[64]>(red));
+    return;
+  }
+  const int bx = lb % d.colblocks, by = lb / d.colblocks;
+  if (d.kind == 0) head3_wgrad_strip_body<8>(d.p, d.spw, bx, by, red);
+  else head3_wgrad_strip_body<4>(d.p, d.spw, bx, by, red);
+}
+__global__ __launch_bounds__(256) void flow_wgrad_sum_kernel(const FlowWgradBatch b) {
+  int di = 0;
+  while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].rblock0) di++;
+  const FlowWgradDesc& d = b.d[di];
+  const int e = (blockIdx.x - d.rblock0) * 256 + threadIdx.x;
+  if (e >= d.wsz) return;
+  float v = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < d.chunks; k++) v += d.p.partial[(size_t)k * d.wsz + e];
+  d.out[e] = v;
 }
 
 // Batched column sums (all bias gradients of a step in one launch): block -> (descriptor, 64-col tile, row chunk).
@@ -1981,6 +2036,77 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const
     if (code != UNFLOW_OK) return code;
   }
   if (dbias) return run_colsum(dz, lddz, (long)B * 4 * H * W, Cout, dbias, workspace, workspace_bytes, used, st);
+  return launch_status();
+}
+
+// Plan of one layer of the batch: <= 64 partials each (one fixed-order pass sums them), enough blocks over the whole batch
+// to fill the chip.  Returns false when the layer needs the per-layer path (no strip form).
+static bool flow_wgrad_plan(FlowWgradDesc& d, int kind_in, int B, int H, int W, int Cin) {
+  if (kind_in == 1) {                      // conv_transpose 2 -> 2 over an H x W input
+    d.kind = 2; d.colblocks = 1; d.spw = 0; d.wsz = 64;
+    d.chunks = (int)min((long)32, ((long)B * H * W + 255) / 256);
+    return true;
+  }
+  const int S = head_strip(B, H, W, 3, 2);
+  if (S != 8 && S != 4) return false;
+  d.kind = S == 8 ? 0 : 1;
+  d.colblocks = cdiv(Cin / 4, 64);
+  d.wsz = 9 * Cin * 2;
+  const long nstrips = (long)B * H * (W / S);
+  const long blocks = min((long)64, max((long)1, nstrips / 4));          // 4 waves per block, >= 1 strip per wave
+  const long spw = (nstrips + blocks * 4 - 1) / (blocks * 4);
+  d.spw = (int)spw;
+  d.chunks = (int)((nstrips + spw * 4 - 1) / (spw * 4));
+  return true;
+}
+
+UNFLOW_API size_t unflow_flow_wgrad_batched_workspace_bytes(int n, const int* kind, const int* B, const int* H, const int* W,
+                                                            const int* Cin) {
+  size_t need = 0;
+  for (int i = 0; i < n; i++) {
+    FlowWgradDesc d{};
+    if (!flow_wgrad_plan(d, kind[i], B[i], H[i], W[i], Cin[i])) return 0;
+    need += ((size_t)d.chunks * d.wsz * sizeof(float) + 255) & ~(size_t)255;
+  }
+  return need;
+}
+
+// kind[i] 0: flowN head (3x3, Cin -> 2, stride 1: x [B,H,W,Cin], dz [B,H,W,2], dw [3,3,Cin,2]);
+//         1: flowN_upM (conv_transpose 2 -> 2: x [B,H,W,2], dz [B,2H,2W,2], dw [4,4,2,2]).
+UNFLOW_API int unflow_flow_wgrad_batched(int n, const int* kind, const float* const* x, const int* ldx, const float* const* dz,
+                                         const int* lddz, float* const* dw, const int* B, const int* H, const int* W, const int* Cin,
+                                         void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
+  if (!kind || !x || !ldx || !dz || !lddz || !dw || !B || !H || !W || !Cin) return UNFLOW_ERR_NULL;
+  if (n <= 0) return UNFLOW_OK;
+  if (n > MAX_FLOW_WGRAD) return UNFLOW_ERR_UNSUPPORTED;
+  FlowWgradBatch b{};
+  b.n = n;
+  size_t off = 0;
+  int blocks = 0, rblocks = 0;
+  for (int i = 0; i < n; i++) {
+    FlowWgradDesc& d = b.d[i];
+    if (!x[i] || !dz[i] || !dw[i]) return UNFLOW_ERR_NULL;
+    if (B[i] <= 0 || H[i] <= 0 || W[i] <= 0 || Cin[i] <= 0) return UNFLOW_ERR_SHAPE;
+    if (kind[i] == 0 && (Cin[i] % 4 != 0 || ldx[i] % 4 != 0 || ldx[i] < Cin[i] || lddz[i] < 2)) return UNFLOW_ERR_UNSUPPORTED;
+    if (kind[i] == 1 && Cin[i] != 2) return UNFLOW_ERR_UNSUPPORTED;
+    if (!flow_wgrad_plan(d, kind[i], B[i], H[i], W[i], Cin[i])) return UNFLOW_ERR_UNSUPPORTED;
+    int pt, pl, ho, wo;
+    same_pads(H[i], 3, 1, &pt, &ho);
+    same_pads(W[i], 3, 1, &pl, &wo);
+    const size_t bytes = ((size_t)d.chunks * d.wsz * sizeof(float) + 255) & ~(size_t)255;
+    if (!workspace || off + bytes > workspace_bytes) return UNFLOW_ERR_WORKSPACE;
+    d.p = SkinnyWgradParams{x[i], ldx[i], dz[i], lddz[i], reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + off),
+                            B[i], H[i], W[i], Cin[i], pt, pl};
+    off += bytes;
+    d.out = dw[i];
+    d.block0 = blocks;
+    blocks += d.chunks * d.colblocks;
+    d.rblock0 = rblocks;
+    rblocks += cdiv(d.wsz, 256);
+  }
+  hipStream_t st = as_stream(stream);
+  flow_wgrad_batched_kernel<<<blocks, 256, 0, st>>>(b);
+  flow_wgrad_sum_kernel<<<rblocks, 256, 0, st>>>(b);
   return launch_status();
 }
 
