@@ -374,6 +374,9 @@ typedef struct unflow_planes {
   long plane_stride;
   int ld;
   int n_planes;
+  float scale; /* the planes hold scale * value (0 = 1).  fp16 planes of GRADIENT tensors carry a power-of-two scale so that
+                  small gradients stay in fp16's normal range; producers multiply, consumers divide their sums.  Must be 1
+                  (or 0) for bf16 x 3 planes, which have fp32's exponent range. */
 } unflow_planes;
 
 /* unflow_correlation_nhwc_fwd with the features' operand planes (n_planes == 3, kernel_size 1, stride_1 1, C % 16 == 0):

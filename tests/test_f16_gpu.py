@@ -11,7 +11,7 @@ from parity_util import images, oracle_step
 
 pytestmark = pytest.mark.gpu
 
-F16_TENSOR_TOL = 0.35     # PROVISIONAL (measured 0.31 on conv6_1 at 128x192 without gradient scaling): per-tensor gradient error of the fp16-operand mode vs the fp32 oracle, max-normalised
+F16_TENSOR_TOL = 3e-2     # stated: per-tensor gradient error of the fp16-operand mode vs the fp32 oracle, max-normalised
 
 
 @pytest.mark.parametrize("shape", [(1, 128, 192), (2, 384, 512)])
@@ -37,17 +37,33 @@ def test_f16_step_vs_fp32_oracle(shape, dev, monkeypatch):
     print("f16 %s: loss rel %.2e, EPE fw %.2e bw %.2e px, gradient cosine %.6f" % (shape, e_loss, e_fw, e_bw, cos))
     assert e_loss <= 1e-2 and e_fw <= 5e-2 and e_bw <= 5e-2
     assert cos > 0.99
-    # per tensor (a cosine over the flat gradient says nothing about a small tensor): max |d| / max |ref| of every tensor with
-    # >= 1024 elements within F16_TENSOR_TOL, the 2-channel flow heads / biases within 3x that
-    rows = []
-    for k in grads:
-        ref = grads[k].double() - (0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0)
-        d = (got[k].double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
-        rows.append((d, k, ref.numel()))
-    rows.sort(reverse=True)
-    for d, k, n in rows[:8]:
-        print("   f16 gradient %-48s n=%-9d max-rel %.2e" % (k, n, d))
-    bad = [(k, d) for d, k, n in rows if d > (F16_TENSOR_TOL if n >= 1024 else 3 * F16_TENSOR_TOL)]
+    # per tensor (a cosine over the flat gradient says nothing about a small tensor).  fp16 rounding moves a few leaky-ReLU
+    # units across the kink (derivative 1 <-> 0.1), which changes single gradient entries by up to a third of the tensor's
+    # maximum on the small deep layers whatever the arithmetic precision — so the bound is asserted against the oracle
+    # differentiated along the ENGINE's branches (parity_util.BranchAligned, as in the fp32 parity tests), and the plain
+    # comparison is printed.
+    from parity_util import BranchAligned, flownet_c_order
+    with BranchAligned(eng.act, flownet_c_order(B)) as al:
+        _, _, _, grads_al = oracle_step(tf_params, im1, im2, dtype=torch.float32)
+
+    def table(ref_grads):
+        rows = []
+        for k in ref_grads:
+            ref = ref_grads[k].double() - (0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0)
+            d = (got[k].double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+            rows.append((d, k, ref.numel()))
+        rows.sort(reverse=True)
+        return rows
+    plain, aligned = table(grads), table(grads_al)
+    print("   f16 %s: %d of %d leaky units flipped; worst tensor plain %.2e (%s), branch-aligned %.2e (%s)"
+          % (shape, al.flips, al.units, plain[0][0], plain[0][1], aligned[0][0], aligned[0][1]))
+    for d, k, n in aligned[:6]:
+        print("   f16 gradient (aligned) %-48s n=%-9d max-rel %.2e" % (k, n, d))
+    # stated bound at the benchmarked resolution (measured 2.0e-2); the 128 x 192 smoke shape sums 9x fewer pixels per
+    # gradient element, so fp16 rounding averages less there (measured 4.6e-2 on tensors >= 1024 elements): twice the bound;
+    # tensors below 1024 elements (2-element flow biases, 2 -> 2 upsamplers): 5x
+    tol = F16_TENSOR_TOL * (1.0 if H >= 384 else 2.0)
+    bad = [(k, d) for d, k, n in aligned if d > (tol if n >= 1024 else 5 * tol)]
     assert not bad, bad
 
 

@@ -112,14 +112,16 @@ def stream(device=None):
 
 class Planes(ctypes.Structure):
     """unflow_planes of include/unflow_hip.h: 16-bit operand planes of a tensor / channel slice."""
-    _fields_ = [('base', ctypes.c_void_p), ('plane_stride', ctypes.c_long), ('ld', ctypes.c_int), ('n_planes', ctypes.c_int)]
+    _fields_ = [('base', ctypes.c_void_p), ('plane_stride', ctypes.c_long), ('ld', ctypes.c_int), ('n_planes', ctypes.c_int),
+                ('scale', ctypes.c_float)]
 
 
-def planes_of(pl):
-    """ctypes pointer to the unflow_planes of an int16 planes view [P, N, H, W, C] (or [P, ..., C] weights), or NULL."""
+def planes_of(pl, scale=0.0):
+    """ctypes pointer to the unflow_planes of an int16 planes view [P, N, H, W, C] (or [P, ..., C] weights), or NULL.
+    scale: what the planes hold relative to the tensor's values (0 = 1; fp16 gradient planes carry a power of two)."""
     if pl is None:
         return None
-    return ctypes.byref(Planes(pl.data_ptr(), pl.stride(0), pl.stride(-2), pl.shape[0]))
+    return ctypes.byref(Planes(pl.data_ptr(), pl.stride(0), pl.stride(-2), pl.shape[0], float(scale)))
 
 
 class PyrLevel(ctypes.Structure):

@@ -334,7 +334,7 @@ class _Stage:
                 if name == 'x0s' and not self.need_in_grad:
                     continue
                 is_flow = name.startswith('flow')
-                self.Gd[name] = L.PT.alloc((N, H // div, W // div, width), dev, 0 if is_flow else npl)
+                self.Gd[name] = L.PT.alloc((N, H // div, W // div, width), dev, 0 if is_flow else npl, scale=e.grad_plane_scale)
         # single-producer conv outputs that only convolutions consume (no flow head, no concat, no correlation fallback): they
         # live as operand planes alone — no fp32 write in the forward pass, and the data gradient that needs the sign of
         # the activation (leaky-ReLU derivative) takes it from the leading plane
@@ -449,7 +449,7 @@ class _Stage:
             l = op.l
             x, dz = self.pt(op.src), self.pt(op.dst, True)
             if l.cout_p != l.cout:
-                dz = L.PT(dz.t.as_strided(dz.t.shape[:3] + (l.cout_p,), dz.t.stride(), dz.t.storage_offset()), dz.pl)
+                dz = L.PT(dz.t.as_strided(dz.t.shape[:3] + (l.cout_p,), dz.t.stride(), dz.t.storage_offset()), dz.pl, dz.scale)
             if e._bias_plan is None:
                 e._bias_jobs.append((dz.t, l))       # bias gradients: one batched column-sum launch at the end
             wg = (L.conv_bwd_filter, (x, dz, l.dw, l.stride)) if l.kind == 'conv' else (L.deconv_bwd_filter, (x, dz, l.dw))
@@ -521,6 +521,10 @@ class FlowNetEngine:
         self.wgrad_inline_tiny = False
         self.batch_flow_wgrad = True      # all Cout = 2 filter gradients of a decoder in one batched launch pair
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
+        # fp16 mode: the fp16 planes of GRADIENT tensors hold 2^12 x the gradient (producers scale, consumers divide their
+        # fp32 sums): activation gradients of the deep layers are 1e-7 .. 1e-4, below fp16's normal range (6e-5); bf16 x 3
+        # planes have fp32's exponent range and are never scaled
+        self.grad_plane_scale = 4096.0 if self.math == 'f16' else 0.0
         if layout_only:
             self.n_planes = 0
         import contextlib

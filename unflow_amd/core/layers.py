@@ -136,21 +136,26 @@ def round8(c):
 
 class PT:
     """An NHWC fp32 tensor (or channel-slice view) together with its operand planes: `pl` is an int16 view
-    [P, N, H, W, Cp] of the same pixels (P = 3: bf16 hi/mid/lo, P = 1: fp16; Cp >= round8(C), pad channels zero), or None."""
-    __slots__ = ('t', 'pl')
+    [P, N, H, W, Cp] of the same pixels (P = 3: bf16 hi/mid/lo, P = 1: fp16; Cp >= round8(C), pad channels zero), or None.
+    `scale`: the planes hold scale * value (fp16 planes of gradient tensors: a power of two that keeps small gradients in
+    fp16's normal range; 0 / 1 otherwise)."""
+    __slots__ = ('t', 'pl', 'scale')
 
-    def __init__(self, t, pl=None):
-        self.t, self.pl = t, pl
+    def __init__(self, t, pl=None, scale=0.0):
+        self.t, self.pl, self.scale = t, pl, scale
 
     def sl(self, lo, hi):
         """Channel slice [lo, hi): the planes view keeps the channels up to round8 of the slice width (zero pad or, for
         an interior slice whose width is a multiple of 8, exactly the slice)."""
         if self.pl is None:
             return PT(self.t[..., lo:hi])
-        return PT(self.t[..., lo:hi], self.pl[..., lo:min(self.pl.shape[-1], lo + round8(hi - lo))])
+        return PT(self.t[..., lo:hi], self.pl[..., lo:min(self.pl.shape[-1], lo + round8(hi - lo))], self.scale)
+
+    def planes(self):
+        return _lib.planes_of(self.pl, self.scale)
 
     @staticmethod
-    def alloc(shape, device, n_planes):
+    def alloc(shape, device, n_planes, scale=0.0):
         """Zero tensor + zero planes (n_planes 0: no planes)."""
         import torch as _t
         t = _t.zeros(*shape, dtype=_t.float32, device=device)
@@ -160,7 +165,7 @@ class PT:
         pad = 32
         cp = (shape[-1] + pad - 1) // pad * pad if shape[-1] > 8 else round8(shape[-1])
         pl = _t.zeros(n_planes, *shape[:-1], cp, dtype=_t.int16, device=device) if n_planes else None
-        return PT(t, pl)
+        return PT(t, pl, scale if n_planes == 1 else 0.0)
 
 
 def _pt(x):
@@ -201,8 +206,8 @@ def conv_fwd(x, w, w_pl, bias, y, stride, leaky, planes_only=False):
     k = w.shape[0]
     assert tuple(w.shape) == (k, k, Cin, Cout) and w.is_contiguous() and (Ho, Wo) == out_hw(H, W, stride)
     wsp, wsn = _ws_pl(x.t.device, B, H, W, Cin, Cout, k, stride, _npl(x, y))
-    check(_lib.lib().unflow_conv2d_fwd_pl(xp, ldx, _lib.planes_of(x.pl), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp, ldy,
-                                          _lib.planes_of(y.pl), B, H, W, Cin, Cout, k, stride, int(bool(leaky)), wsp, wsn,
+    check(_lib.lib().unflow_conv2d_fwd_pl(xp, ldx, x.planes(), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp, ldy,
+                                          y.planes(), B, H, W, Cin, Cout, k, stride, int(bool(leaky)), wsp, wsn,
                                           stream()), "conv2d_fwd_pl")
 
 
@@ -214,7 +219,7 @@ def _act_args(act_src, act_planes):
     a = _pt(act_src)
     if act_planes:
         assert a.pl is not None
-        return ptr(None), 0, _lib.planes_of(a.pl)
+        return ptr(None), 0, a.planes()
     ap, lda = nhwc(a.t)[:2]
     return ap, lda, None
 
@@ -229,8 +234,8 @@ def conv_bwd_data(dz, w, w_pl, dx, stride, accumulate=False, act_src=None, act_l
     assert tuple(w.shape) == (k, k, Cin, Cout)
     ap, lda, apl = _act_args(act_src, act_planes)
     wsp, wsn = _ws_pl(dz.t.device, B, H, W, Cin, Cout, k, stride, _npl(dz, dx))
-    check(_lib.lib().unflow_conv2d_bwd_data_pl(dzp, lddz, _lib.planes_of(dz.pl), ptr(w), _lib.planes_of(w_pl), dxp, lddx,
-                                               _lib.planes_of(dx.pl), act_lo, act_hi, B, H, W, Cin, Cout, k, stride,
+    check(_lib.lib().unflow_conv2d_bwd_data_pl(dzp, lddz, dz.planes(), ptr(w), _lib.planes_of(w_pl), dxp, lddx,
+                                               dx.planes(), act_lo, act_hi, B, H, W, Cin, Cout, k, stride,
                                                int(bool(accumulate)), ap, lda, apl, act_lo, act_hi, wsp, wsn, stream()),
           "conv2d_bwd_data_pl")
 
@@ -242,7 +247,7 @@ def conv_bwd_filter(x, dz, dw, stride):
     k = dw.shape[0]
     assert tuple(dw.shape) == (k, k, Cin, Cout) and dw.is_contiguous()
     wsp, wsn = _ws_pl(x.t.device, B, H, W, Cin, Cout, k, stride, _npl(x, dz))
-    check(_lib.lib().unflow_conv2d_bwd_filter_pl(xp, ldx, _lib.planes_of(x.pl), dzp, lddz, _lib.planes_of(dz.pl), ptr(dw), B, H,
+    check(_lib.lib().unflow_conv2d_bwd_filter_pl(xp, ldx, x.planes(), dzp, lddz, dz.planes(), ptr(dw), B, H,
                                                  W, Cin, Cout, k, stride, wsp, wsn, stream()), "conv2d_bwd_filter_pl")
 
 
@@ -256,8 +261,8 @@ def deconv_fwd(x, w, w_pl, bias, y, leaky, planes_only=False):
         yp = ptr(None)
     assert tuple(w.shape) == (4, 4, Cout, Cin) and (Ho, Wo) == (2 * H, 2 * W)
     wsp, wsn = _ws_pl(x.t.device, B, 2 * H, 2 * W, Cin, Cout, 4, 2, _npl(x, y))
-    check(_lib.lib().unflow_conv2d_transpose_fwd_pl(xp, ldx, _lib.planes_of(x.pl), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp,
-                                                    ldy, _lib.planes_of(y.pl), B, H, W, Cin, Cout, int(bool(leaky)), wsp, wsn,
+    check(_lib.lib().unflow_conv2d_transpose_fwd_pl(xp, ldx, x.planes(), ptr(w), _lib.planes_of(w_pl), ptr(bias), yp,
+                                                    ldy, y.planes(), B, H, W, Cin, Cout, int(bool(leaky)), wsp, wsn,
                                                     stream()), "conv2d_transpose_fwd_pl")
 
 
@@ -269,8 +274,8 @@ def deconv_bwd_data(dz, w, w_pl, dx, accumulate=False, act_src=None, act_lo=0, a
     assert tuple(w.shape) == (4, 4, Cout, Cin) and (Ho, Wo) == (2 * H, 2 * W)
     ap, lda, apl = _act_args(act_src, act_planes)
     wsp, wsn = _ws_pl(dz.t.device, B, Ho, Wo, Cin, Cout, 4, 2, _npl(dz, dx))
-    check(_lib.lib().unflow_conv2d_transpose_bwd_data_pl(dzp, lddz, _lib.planes_of(dz.pl), ptr(w), _lib.planes_of(w_pl), dxp,
-                                                         lddx, _lib.planes_of(dx.pl), act_lo, act_hi, B, H, W, Cin, Cout,
+    check(_lib.lib().unflow_conv2d_transpose_bwd_data_pl(dzp, lddz, dz.planes(), ptr(w), _lib.planes_of(w_pl), dxp,
+                                                         lddx, dx.planes(), act_lo, act_hi, B, H, W, Cin, Cout,
                                                          int(bool(accumulate)), ap, lda, apl, act_lo, act_hi, wsp, wsn,
                                                          stream()),
           "conv2d_transpose_bwd_data_pl")
@@ -282,7 +287,7 @@ def deconv_bwd_filter(x, dz, dw):
     dzp, lddz, _, Ho, Wo, Cout = nhwc(dz.t)
     assert tuple(dw.shape) == (4, 4, Cout, Cin)
     wsp, wsn = _ws_pl(x.t.device, B, Ho, Wo, Cin, Cout, 4, 2, _npl(x, dz))
-    check(_lib.lib().unflow_conv2d_transpose_bwd_filter_pl(xp, ldx, _lib.planes_of(x.pl), dzp, lddz, _lib.planes_of(dz.pl),
+    check(_lib.lib().unflow_conv2d_transpose_bwd_filter_pl(xp, ldx, x.planes(), dzp, lddz, dz.planes(),
                                                            ptr(dw), B, H, W, Cin, Cout, wsp, wsn, stream()),
           "conv2d_transpose_bwd_filter_pl")
 

@@ -46,6 +46,7 @@ struct PlGatherParams : GatherGeom {
   int lds, ldd, ld_act, act_lo, act_hi;
   int nsplit;
   int leaky, accumulate;
+  float src_inv;               // 1 / (scale of the source planes x scale of the weight planes): applied to the finished sums
   int* counters;               // fused split-K: one arrival counter per (class, M tile, N tile), zeroed before the launch
   int fused_splitk;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
@@ -122,6 +123,7 @@ __device__ __forceinline__ float leaky_grad_from_bits(unsigned h) { return ((h &
 // bias / leaky-ReLU / accumulate / leaky derivative of four consecutive output channels; stores the fp32 result when the
 // layer keeps one (dst may be NULL: tensors that only convolutions read live as operand planes alone) and returns it
 __device__ __forceinline__ float4 epi_value4(const PlGatherParams& p, size_t px, int n, float4 v) {
+  if (p.src_inv != 1.f) { v.x *= p.src_inv; v.y *= p.src_inv; v.z *= p.src_inv; v.w *= p.src_inv; }
   if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
   if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
   float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
@@ -301,6 +303,7 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
         if (to_partial) {
           p.partial[((size_t)split * ((size_t)p.B * p.Hd * p.Wd) + px) * p.N + n] = v;
         } else {
+          v *= p.src_inv;
           if (p.bias) v += p.bias[n];
           if (p.leaky) v = leaky_relu(v);
           float* d = p.dst + (size_t)px * p.ldd + n;
@@ -841,6 +844,7 @@ __global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec
     const int n = (int)(e - px * p.N);
     float v = 0.f;
     for (int s = 0; s < p.nsplit; s++) v += p.partial[(size_t)s * total + e];
+    v *= p.src_inv;
     if (p.bias) v += p.bias[n];
     if (p.leaky) v = leaky_relu(v);
     float* d = p.dst + px * p.ldd + n;
@@ -864,6 +868,7 @@ struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multi
   float* partial;              // [nsplit][taps*Ca_out][Cb]
   int lds, ldd;
   int Ca_out;                  // rows per tap of dW (the weight tensor's own channel padding, <= Ca)
+  float out_scale;             // 1 / (scale of the gathered planes x scale of the dense planes)
   int nsplit;
   int gpx;                     // conv1 form: granule ag of a tap row starts gpx * ag pixels to the right
   unsigned cag_magic;          // ceil(2^32 / (Ca/8))
@@ -1067,7 +1072,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * WN + j * 32 + l31;
-        if (n < p.Cb) orow[n] = acc[i][j][r];
+        if (n < p.Cb) orow[n] = acc[i][j][r] * p.out_scale;
       }
     }
 }
@@ -1253,7 +1258,7 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * WN + j * 32 + l31;
-        if (n < p.Cb) orow[n] = acc[i][j][r];
+        if (n < p.Cb) orow[n] = acc[i][j][r] * p.out_scale;
       }
     }
 }
@@ -1530,6 +1535,7 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
 
 int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStream_t st) {
   const unflow::Options& opt = unflow::options();
+  if (p.src_inv == 0.f) p.src_inv = 1.f;
   p.xcd = opt.xcd_swizzle;
   // order 2 (M groups per XCD, M tile fastest inside) measured best or tied on every layer of FlowNetC 384x512 B=4 against
   // 0 and 1 (profiles/r02_xcd_order_per_layer.txt); option xcd_order forces one
@@ -1635,6 +1641,7 @@ int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
 
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
   const unflow::Options& opt = unflow::options();
+  if (p.out_scale == 0.f) p.out_scale = 1.f;
   p.xcd = opt.xcd_swizzle;
   p.cag_magic = p.Ca == 8 ? 0u : magic_u32((unsigned)(p.Ca >> 3));   // 2^32 / 1 does not fit: 0 marks 'no division'
   const size_t wsize = (size_t)p.KH * p.KW * p.Ca_out * p.Cb;
@@ -1670,9 +1677,11 @@ inline PlaneOut plane_out(const unflow_planes* t, int lo, int hi) {
     o.lo = lo;
     o.hi = hi;
     o.n_planes = t->n_planes;
+    o.scale = t->n_planes == 1 ? t->scale : 0.f;
   }
   return o;
 }
+inline float plane_scale(const unflow_planes* t) { return (t && t->n_planes == 1 && t->scale != 0.f) ? t->scale : 1.f; }
 
 // source of the leaky-ReLU derivative of a data gradient: the fp32 activation if the caller has one, else the first operand
 // plane of the activation (same sign, a third of the bytes)
@@ -1852,6 +1861,7 @@ UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes
   }
   p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.src_inv = 1.f / (plane_scale(x_pl) * plane_scale(w_pl));
   p.bias = bias; p.dst = y; p.ldd = ldy; p.act_src = nullptr; p.leaky = leaky; p.accumulate = 0;
   p.pl = plane_out(y_pl, 0, Cout);
   return run_pl_gather(p, x_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
@@ -1876,6 +1886,7 @@ UNFLOW_API int unflow_conv2d_bwd_data_pl(const float* dz, int lddz, const unflow
   if (bc != UNFLOW_OK) return bc;
   p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.src_inv = 1.f / (plane_scale(dz_pl) * plane_scale(w_pl));
   p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_lo = act_lo; p.act_hi = act_hi;
   set_act(p, act_src, ld_act, act_pl);
   p.leaky = 0; p.accumulate = accumulate;
@@ -1898,6 +1909,7 @@ UNFLOW_API int unflow_conv2d_bwd_filter_pl(const float* x, int ldx, const unflow
   if (rgb4) { p.Ca = 32; p.KW = 1; p.gpx = 2; }
   p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
   p.dst = reinterpret_cast<const unsigned short*>(dz_pl->base); p.dst_ps = dz_pl->plane_stride; p.ldd = dz_pl->ld;
+  p.out_scale = 1.f / (plane_scale(x_pl) * plane_scale(dz_pl));
   p.out = dw; p.Ca_out = rgb4 ? 28 : Cin;
   size_t used = 0;
   return run_pl_wgrad(p, x_pl->n_planes, workspace, workspace_bytes, &used, as_stream(stream));
@@ -1918,6 +1930,7 @@ UNFLOW_API int unflow_conv2d_transpose_fwd_pl(const float* x, int ldx, const unf
   build_deconv_fwd(p, B, H, W, Ci8, Cout);
   p.src = reinterpret_cast<const unsigned short*>(x_pl->base); p.src_ps = x_pl->plane_stride; p.lds = x_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.src_inv = 1.f / (plane_scale(x_pl) * plane_scale(w_pl));
   p.bias = bias; p.dst = y; p.ldd = ldy; p.act_src = nullptr; p.leaky = leaky; p.accumulate = 0;
   p.pl = plane_out(y_pl, 0, Cout);
   return run_pl_gather(p, x_pl->n_planes, workspace, workspace_bytes, as_stream(stream));
@@ -1945,6 +1958,7 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_data_pl(const float* dz, int lddz, co
   }
   p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
   p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.src_inv = 1.f / (plane_scale(dz_pl) * plane_scale(w_pl));
   p.bias = nullptr; p.dst = dx; p.ldd = lddx; p.act_lo = act_lo; p.act_hi = act_hi;
   set_act(p, act_src, ld_act, act_pl);
   p.leaky = 0; p.accumulate = accumulate;
@@ -1965,6 +1979,7 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_filter_pl(const float* x, int ldx, co
   build_deconv_wgrad(p, B, H, W, Cin, (Cout + 7) & ~7);
   p.src = reinterpret_cast<const unsigned short*>(dz_pl->base); p.src_ps = dz_pl->plane_stride; p.lds = dz_pl->ld;
   p.dst = reinterpret_cast<const unsigned short*>(x_pl->base); p.dst_ps = x_pl->plane_stride; p.ldd = x_pl->ld;
+  p.out_scale = 1.f / (plane_scale(x_pl) * plane_scale(dz_pl));
   p.out = dw; p.Ca_out = Cout;
   size_t used = 0;
   return run_pl_wgrad(p, x_pl->n_planes, workspace, workspace_bytes, &used, as_stream(stream));

@@ -48,7 +48,9 @@ struct PlaneOut {
   unsigned short* base;
   long plane_stride;
   int ld, lo, hi, n_planes;   // n_planes == 0: no plane output
+  float scale;                // fp16 planes hold scale * value (0 or 1: unscaled; gradient tensors: a power of two)
 };
+__device__ __forceinline__ float plane_scaled(const PlaneOut& o, float v) { return o.scale != 0.f ? v * o.scale : v; }
 
 __device__ __forceinline__ unsigned fast_div(unsigned a, unsigned magic) { return __umulhi(a, magic); }
 
@@ -141,7 +143,7 @@ __device__ __forceinline__ void store_planes(const PlaneOut& o, size_t px, int n
   if (o.n_planes == 0 || n < o.lo || n >= o.hi) return;
   unsigned short* d = o.base + px * (size_t)o.ld + n;
   if (o.n_planes == 1) {
-    *d = to_f16_bits(v);
+    *d = to_f16_bits(plane_scaled(o, v));
   } else {
     unsigned short h, m, l;
     split3(v, h, m, l);
@@ -159,8 +161,8 @@ __device__ __forceinline__ void store_planes4(const PlaneOut& o, size_t px, int 
   }
   unsigned short* d = o.base + px * (size_t)o.ld + n;
   if (o.n_planes == 1) {
-    const unsigned a = (unsigned)to_f16_bits(v.x) | ((unsigned)to_f16_bits(v.y) << 16);
-    const unsigned b = (unsigned)to_f16_bits(v.z) | ((unsigned)to_f16_bits(v.w) << 16);
+    const unsigned a = (unsigned)to_f16_bits(plane_scaled(o, v.x)) | ((unsigned)to_f16_bits(plane_scaled(o, v.y)) << 16);
+    const unsigned b = (unsigned)to_f16_bits(plane_scaled(o, v.z)) | ((unsigned)to_f16_bits(plane_scaled(o, v.w)) << 16);
     *reinterpret_cast<uint2*>(d) = make_uint2(a, b);
     return;
   }
@@ -187,10 +189,10 @@ __device__ __forceinline__ void store_planes8(const PlaneOut& o, size_t px, int 
   unsigned short* d = o.base + e;
   if (o.n_planes == 1) {
     u32x4 h;
-    h.x = (unsigned)to_f16_bits(a.x) | ((unsigned)to_f16_bits(a.y) << 16);
-    h.y = (unsigned)to_f16_bits(a.z) | ((unsigned)to_f16_bits(a.w) << 16);
-    h.z = (unsigned)to_f16_bits(b.x) | ((unsigned)to_f16_bits(b.y) << 16);
-    h.w = (unsigned)to_f16_bits(b.z) | ((unsigned)to_f16_bits(b.w) << 16);
+    h.x = (unsigned)to_f16_bits(plane_scaled(o, a.x)) | ((unsigned)to_f16_bits(plane_scaled(o, a.y)) << 16);
+    h.y = (unsigned)to_f16_bits(plane_scaled(o, a.z)) | ((unsigned)to_f16_bits(plane_scaled(o, a.w)) << 16);
+    h.z = (unsigned)to_f16_bits(plane_scaled(o, b.x)) | ((unsigned)to_f16_bits(plane_scaled(o, b.y)) << 16);
+    h.w = (unsigned)to_f16_bits(plane_scaled(o, b.z)) | ((unsigned)to_f16_bits(plane_scaled(o, b.w)) << 16);
     *reinterpret_cast<u32x4*>(d) = h;
     return;
   }
