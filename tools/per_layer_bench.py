@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--flownet", default="C")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--filter", default="", help="only time calls whose 'pass in out' line contains one of these |-separated substrings")
     args = ap.parse_args()
     if args.dtype == "f16":
         os.environ["UNFLOW_CONV_MATH"] = "f16"
@@ -91,6 +92,8 @@ def main():
             si, so = shape(a[0]), shape(a[1])
             w = a[2]
         kk = w.shape[0]
+        if args.filter and not any(f in "%s %s %s" % (n, "x".join(map(str, si)), "x".join(map(str, so))) for f in args.filter.split("|")):
+            continue
         if n.startswith("conv"):
             gf = 2.0 * so[0] * so[1] * so[2] * kk * kk * si[3] * so[3] / 1e9
         else:

@@ -33,6 +33,31 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int LDH = BK;   // 16-bit elements per LDS row of the gather image (64 bytes)
 
+// Phase trace (diagnostic builds only: -DUNFLOW_PHASE_TRACE, tools/phase_trace.py): the waves of workgroup 0 stamp
+// s_memtime at the phase boundaries of their first 64 K tiles; never compiled into the shipped library.
+#ifdef UNFLOW_PHASE_TRACE
+__device__ unsigned long long g_phase_trace[8 * 8];          // [wave][phase 0..5 cycle sums, 6 = tiles]
+#define PHASE_DECL unsigned long long ph_prev = 0, ph_acc[7] = {0, 0, 0, 0, 0, 0, 0}
+// cycles since the previous stamp go to phase `slot` (slot 6: the start of a tile — counts it and takes what is left of the
+// loop tail into phase 5); sums stay in registers (a store per stamp would sit in every s_waitcnt vmcnt that follows)
+#define PHASE_STAMP(slot)                                                  \
+  do {                                                                     \
+    const unsigned long long ph_now = __builtin_readcyclecounter();        \
+    if ((slot) == 6) { if (ph_prev) ph_acc[5] += ph_now - ph_prev; ph_acc[6]++; } \
+    else ph_acc[slot] += ph_now - ph_prev;                                 \
+    ph_prev = ph_now;                                                      \
+  } while (0)
+#define PHASE_FLUSH                                                                                            \
+  do {                                                                                                         \
+    if (blockIdx.x == UNFLOW_PHASE_TRACE && (threadIdx.x & 63) == 0)                                           \
+      for (int ph_i = 0; ph_i < 7; ph_i++) g_phase_trace[(threadIdx.x >> 6) * 8 + ph_i] = ph_acc[ph_i];        \
+  } while (0)
+#else
+#define PHASE_DECL do { } while (0)
+#define PHASE_STAMP(slot) do { } while (0)
+#define PHASE_FLUSH do { } while (0)
+#endif
+
 struct PlGatherParams : GatherGeom {
   const unsigned short* src;   // source planes, channel 0 of the consumed slice; [pixel][lds] per plane
   long src_ps;                 // plane stride (elements)
@@ -731,7 +756,9 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
   int ty = 0, tx = 0;                            // tap of the tile being multiplied, and the halo position of its class's tap (0, 0)
   int c_hy0 = p.dstep > 0 ? 0 : tc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : tc.ntx - 1;
+  PHASE_DECL;
   for (int kk = 0; kk < T; kk++) {
+    PHASE_STAMP(6);
     const int hyi = c_hy0 + ty * p.dstep, hxi = c_hx0 + tx * p.dstep;
     const int tapoff = (hyi * HC + hxi) * HPITCH;
     const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
@@ -802,15 +829,27 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
         }
       }
     }
+    PHASE_STAMP(0);    // MFMA phase (fragment reads, 48 MFMAs, the next tile's loads issued)
     __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
+    PHASE_STAMP(1);    // barrier 1
+#ifdef UNFLOW_PHASE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_STAMP(2);    // the next tile's loads landed
+#endif
     store_b();
     if (new_chunk) store_h();
+#ifdef UNFLOW_PHASE_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    PHASE_STAMP(3);    // LDS stores
     __syncthreads();
+    PHASE_STAMP(4);    // barrier 2
     ty = ld_ty; tx = ld_tx;          // the tile just stored is the next one multiplied: its tap, its class's halo origin
     c_hy0 = p.dstep > 0 ? 0 : ltc.nty - 1;
     c_hx0 = p.dstep > 0 ? 0 : ltc.ntx - 1;
     ld_advance(kk + 1);
   }
+  PHASE_FLUSH;
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
   if (p.fused_splitk) {
     if (!splitk_last_arriver(p, (cls_id * p.mt + mtile_id) * p.nt + ntile, pix + BM)) return;
@@ -818,6 +857,10 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   }
 }
 
+// (Round 3 measured and dropped, profiles/r03_halo_tall_ab.txt: a 256-site (8 x 32) form of this kernel with 8 waves per
+// workgroup, the weight tile double-buffered (one barrier per tap) and half the weight bytes per MFMA — passes the same
+// tests, slower on every layer it applied to (conv2 forward +39 us, conv3 data gradient +56 us; step 607 vs 620 pairs/s):
+// one barrier domain of 8 waves stalls more than two independent 4-wave workgroups per CU.)
 // Fixed-order sum of the split-K partials + the epilogue (+ the output planes).  One float4 per thread.
 __global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec) {
   const size_t npix = (size_t)p.B * p.Hd * p.Wd;
@@ -857,6 +900,7 @@ __global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec
     store_planes(p.pl, px, n, v);
   }
 }
+
 
 // ------------------------------------------------------------------------------------------------ filter gradient
 struct PlWgradParams : WgradGeom {   // Ca: plane channels walked per tap (multiple of 8); Cb: columns of dW
@@ -1156,25 +1200,27 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
 
   const unsigned lds0 = lds_addr(smem16);
+  auto a_voff = [&](int kt) {
+    const unsigned sidx = (unsigned)(kt * KS + a_k);
+    const unsigned q = fast_div(sidx, magW);
+    const int xg = (int)(sidx - q * (unsigned)p.Wg);
+    const unsigned bb = fast_div(q, magH);
+    const int yg = (int)(q - bb * (unsigned)p.Hg);
+    const int yb = yg * p.sm, xb = xg * p.sm;
+    const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
+    return ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
+  };
+  auto b_voff = [&](int kt) {
+    const int sidx = kt * KS + b_k;
+    return (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
+  };
   auto issue = [&](int kt, int buf) {
     const unsigned st = lds0 + (unsigned)(buf * STAGE * 2);      // byte address of the stage in LDS
-    {
-      const unsigned sidx = (unsigned)(kt * KS + a_k);
-      const unsigned q = fast_div(sidx, magW);
-      const int xg = (int)(sidx - q * (unsigned)p.Wg);
-      const unsigned bb = fast_div(q, magH);
-      const int yg = (int)(q - bb * (unsigned)p.Hg);
-      const int yb = yg * p.sm, xb = xg * p.sm;
-      const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
-      const int voff = ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
-      const unsigned d = st + (unsigned)(4 * wid * BM * 2);
-      dma3(voff, src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
-    }
+    const unsigned d = st + (unsigned)(4 * wid * BM * 2);
+    dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
     if (wid < B_NI) {
-      const int sidx = kt * KS + b_k;
-      const int voff = (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
-      const unsigned d = st + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
-      dma3(voff, dst_rs[0], dst_rs[1], dst_rs[2], d, d + B_PLANE * 2, d + 2 * B_PLANE * 2);
+      const unsigned e = st + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
+      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], e, e + B_PLANE * 2, e + 2 * B_PLANE * 2);
     }
   };
 
@@ -1203,16 +1249,17 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  PHASE_DECL;
   for (int kt = kt0; kt < kt1; kt++) {
+    PHASE_STAMP(6);
     const int cur = (kt - kt0) & 1;
-    // stage kt+1 -> the other buffer (every wave passed the barrier after its reads of that buffer); past the last stage the
-    // loads are all out of range (zeros into a buffer nobody reads)
-    issue(kt + 1 < kt1 ? kt + 1 : KT + 1, cur ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
+    // this stage's fragment reads first, then stage kt+1 -> the other buffer (every wave passed the barrier after its reads
+    // of that buffer): the address arithmetic while the reads return, the loads between the first MFMA groups — a wave's
+    // issue port is idle while its MFMAs execute; past the last stage the loads are all out of range (zeros into a buffer
+    // nobody reads)
     const unsigned short* st = smem16 + cur * STAGE;
     s16x8 av[TM][NPL], bv[TN][NPL];
-#pragma unroll
-    for (int pl = 0; pl < NPL; pl++) {
+    auto read_a = [&](int pl) {
 #pragma unroll
       for (int i = 0; i < TM; i++) {
         const unsigned short* b0 = st + pl * A_PLANE + a_rd[i];
@@ -1220,6 +1267,8 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BM));
         av[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+    };
+    auto read_b = [&](int pl) {
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const unsigned short* b0 = st + pl * B_PLANE + b_rd[j];
@@ -1227,20 +1276,55 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * BN));
         bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; t++)
+    };
+    // fragment reads in the order the six terms want them (mfma_terms: A2 B0, A0 B2, A1 B1, ...)
+    read_a(2); read_b(0); read_a(0); read_b(2); read_a(1); read_b(1);
+    __builtin_amdgcn_sched_barrier(0);
+    PHASE_STAMP(4);    // fragment reads issued
+    // stage kt+1: addresses while the reads return, then the six loads spread between the first MFMA groups
+    const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;
+    const unsigned stn = lds0 + (unsigned)((cur ^ 1) * STAGE * 2);
+    const int voa = a_voff(ktn);
+    const int vob = b_voff(ktn);
+    const unsigned da = stn + (unsigned)(4 * wid * BM * 2);
+    const unsigned db = stn + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
+    auto group = [&](int t) {
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+    };
+    dma1(voa, src_rs[0], da);
+    dma1(voa, src_rs[1], da + A_PLANE * 2);
+    __builtin_amdgcn_sched_barrier(0);
+    PHASE_STAMP(0);
+    group(0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma1(voa, src_rs[2], da + 2 * A_PLANE * 2);
+    if (wid < B_NI) dma1(vob, dst_rs[0], db);
+    __builtin_amdgcn_sched_barrier(0);
+    group(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wid < B_NI) {
+      dma1(vob, dst_rs[1], db + B_PLANE * 2);
+      dma1(vob, dst_rs[2], db + 2 * B_PLANE * 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    group(2);
+    group(3);
+    group(4);
+    group(5);
     // own loads landed + own LDS reads retired, then the barrier: stage kt+1 is complete and buffer `cur` is free (the
     // scheduling fences keep the MFMAs above and the next stage's loads below it)
     __builtin_amdgcn_sched_barrier(0);
+    PHASE_STAMP(1);    // fragment reads + 24 MFMAs issued
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    PHASE_STAMP(2);    // own DMA landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PHASE_STAMP(3);    // barrier
   }
+  PHASE_FLUSH;
 
   float* o = p.nsplit > 1 ? p.partial + (size_t)split * taps * p.Ca_out * p.Cb : p.out;
   const int lh5 = lane >> 5, l31 = lane & 31;
@@ -1732,6 +1816,17 @@ UNFLOW_API int unflow_debug_work_order(int mt, int nt, int ncls, int nsplit, int
   return grid;
 }
 
+#ifdef UNFLOW_PHASE_TRACE
+UNFLOW_API int unflow_debug_phase_trace(unsigned long long* host_out, int clear) {      // [8 waves][8]: 6 phase sums, tiles
+  if (clear) {
+    static unsigned long long zero[8 * 8];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_trace), zero, sizeof(zero)) == hipSuccess ? UNFLOW_OK : UNFLOW_ERR_LAUNCH;
+  }
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_trace), sizeof(unsigned long long) * 8 * 8) == hipSuccess ? UNFLOW_OK
+                                                                                                                       : UNFLOW_ERR_LAUNCH;
+}
+#endif
+
 UNFLOW_API int unflow_planes_from_f32(const float* x, int ldx, long npix, int C, int C_fill, const unflow_planes* out,
                                       unflow_stream_t stream) {
   if (!x || !out || !out->base) return UNFLOW_ERR_NULL;
@@ -1776,9 +1871,10 @@ UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const 
   return launch_status();
 }
 
-static int pl_gather_nsplit(const GatherGeom& g, int npl) {
+static int pl_gather_nsplit(const GatherGeom& g, int npl) {      // (workspace sizing: the larger of the forms that may run)
   int bn;
-  return pl_halo_ok(g) ? plan_pl_halo(g, npl, &bn) : plan_pl_gather(g, npl).nsplit;
+  if (!pl_halo_ok(g)) return plan_pl_gather(g, npl).nsplit;
+  return plan_pl_halo(g, npl, &bn);
 }
 
 UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes) {

@@ -104,6 +104,18 @@ __device__ __forceinline__ void dma3(int voff, u32x4 r0, u32x4 r1, u32x4 r2, uns
       : "memory");
 }
 
+// one such load
+__device__ __forceinline__ void dma1(int voff, u32x4 r, unsigned d) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[d]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[r], 0 offen lds\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [v] "v"(voff), [r] "s"(r), [d] "s"(d)
+      : "memory");
+}
+
 // Workgroups are handed to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), so neighbouring tiles — which share
 // source rows (the vertical taps) — sit on different L2s.  This bijective remap of blockIdx.x gives every XCD a contiguous
 // run of tiles instead: its L2 then fetches each source row once, not once per XCD that holds one of the row's consumers.
