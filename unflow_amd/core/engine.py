@@ -393,7 +393,7 @@ class _Stage:
                 L.deconv_fwd(x, l.w, l.wpl_d, l.b, y, l.act, planes_only=po)
 
     # -------------------------------------------------------------- backward
-    def backward(self, part=None):
+    def backward(self, part=None, before_join=None):
         """part None: everything; k: the k-th slice of the backward list (default cuts: 0 = decoder + conv6_1..conv4 — 94 %
         of the parameters, whose gradients are final afterwards so that their all-reduce can start — 1 = conv3_1 ..
         conv1; set_parts() changes the cuts)."""
@@ -480,6 +480,9 @@ class _Stage:
                 L.deconv_bwd_data(dz, l.w, l.wpl_t, dx, accumulate, act_src, act_lo, act_hi, act_planes=apl)
         if side is not None:
             flush()
+        if before_join is not None:
+            before_join()            # HBM-bound work for the main stream while the filter gradients finish on the second
+        if side is not None:
             main.wait_stream(side)
 
 
@@ -958,13 +961,15 @@ class FlowNetEngine:
         part 0 / 1: the two halves used to overlap the data-parallel all-reduce (see grad_buckets)."""
         last_part = len(self.stages[-1].part_bounds) - 2
         with torch.cuda.device(self.dev):
-            self.stages[-1].backward(part)
-            if part in (None, last_part):
-                if self.train_all:
-                    for i in range(len(self.stages) - 1, 0, -1):
-                        self._stack_backward(self.stages[i], self.stages[i - 1])
-                        self.stages[i - 1].backward()
-                self._bias_grads()
+            # the batched bias gradients (column sums of every dz: HBM-bound) go out on the main stream once the last data
+            # gradient is queued, beside the tail of the filter gradients on the second stream
+            final = part in (None, last_part)
+            multi = self.train_all and len(self.stages) > 1
+            self.stages[-1].backward(part, self._bias_grads if final and not multi else None)
+            if final and multi:
+                for i in range(len(self.stages) - 1, 0, -1):
+                    self._stack_backward(self.stages[i], self.stages[i - 1])
+                    self.stages[i - 1].backward(None, self._bias_grads if i == 1 else None)
 
     def _stack_backward(self, st, prev):
         """d loss / d (flow2 of the previous network) through the stage input of `st` (train_all).  The previous
