@@ -61,6 +61,12 @@ def main():
            timeit(lambda: check(lib.unflow_image_warp_fwd(ptr(im), 3, ptr(flow_iid), cf(1.0), ptr(out3), ptr(None), 0, N, H, W, 3, st))))
     report("backward_warp_fwd C=3", npx * 32,
            timeit(lambda: check(lib.unflow_backward_warp_fwd(ptr(im), ptr(flow), ptr(out3), N, H, W, 3, st))))
+    # the same op on a locally constant field (a translation): the rate of the gather itself, without the extra cache lines a
+    # spatially varying field makes every wave touch (the field above changes by ~8 px across a wave's 64 pixels)
+    flow_c = torch.full_like(flow, 2.5)
+    report("backward_warp_fwd C=3, constant flow (2.5, 2.5)", npx * 32,
+           timeit(lambda: check(lib.unflow_backward_warp_fwd(ptr(im), ptr(flow_c), ptr(out3), N, H, W, 3, st))))
+    del flow_c
     dfl = torch.empty_like(flow)
     gout = torch.rand(N, H, W, 3, generator=g).to(dev)
     # backward wrt flow: read dout (3), image (3 via taps), flow (2), write dflow (2): (3C+... ) = 40 B/px

@@ -29,6 +29,18 @@ static inline int stream_grid(long work_items, int block = 256) {
   return (int)g;
 }
 
+// Workgroups go to the 8 XCDs round-robin by linear id (MI355X_MICROARCH.md), so a grid-stride pass over an image puts
+// neighbouring row segments on different L2s, and every row that a gather / stencil kernel shares between two workgroups
+// (the second tap row of a bilinear warp, the window rows of the census) is fetched from HBM by both.  This bijection of
+// blockIdx.x gives each XCD a contiguous run of virtual block ids: rows are shared inside one L2 except at the 8 seams
+// (the warps: 4.4 -> see profiles/r03_bench_ops_16x768x1024.jsonl).
+__device__ __forceinline__ unsigned xcd_block() {
+  const unsigned n = gridDim.x, b = blockIdx.x;
+  if (n < 16) return b;
+  const unsigned xcd = b & 7, idx = b >> 3, q = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float leaky_relu(float v) { return fmaxf(0.1f * v, v); }
 // tf.maximum(0.1*x, x): gradient 1 where x > 0 (output > 0), else 0.1 (ties go to the 0.1*x branch).
 __device__ __forceinline__ float leaky_grad_from_out(float y) { return y > 0.f ? 1.f : 0.1f; }
@@ -62,6 +74,38 @@ __device__ __forceinline__ Pix decode_pix(unsigned i, unsigned W, unsigned H) {
   p.x = (int)(i - r * W);
   p.n = (int)(r / H);
   p.y = (int)(r - (unsigned)p.n * H);
+  return p;
+}
+
+// Walk of an [N, H, W] image by 64 x 4 pixel tiles for the gather kernels (256-thread blocks): a wave owns 64 consecutive
+// pixels of one row (its streamed loads / stores stay whole 256- / 768-byte runs), the four waves of a block four consecutive
+// rows, and a block walks DOWN a 64-pixel column strip (tiles ordered row-fastest, a contiguous run of them per block) —
+// the tap rows a bilinear footprint shares between neighbouring output rows then meet in the CU's L1, in the same pass or
+// the next, instead of travelling from L2 twice (tools/microbench/hbm_stream.hip: the second tap row costs a row-major
+// walk 25 % of its rate).  Loop: for (t = tile_first(T); t < tile_last(T); t++) with T = tile_count(W, H, N).
+struct TilePix {
+  int x, y, n;
+  unsigned i;      // linear pixel index (n * H + y) * W + x
+  bool ok;
+};
+constexpr unsigned TILE_WL = 6, TILE_HL = 8 - TILE_WL;       // log2 of the tile width / height (256 pixels)
+__device__ __forceinline__ unsigned tile_count(unsigned W, unsigned H, unsigned N) {
+  return ((W + (1u << TILE_WL) - 1) >> TILE_WL) * ((H + (1u << TILE_HL) - 1) >> TILE_HL) * N;
+}
+__device__ __forceinline__ unsigned tile_first(unsigned T) { return blockIdx.x * ((T + gridDim.x - 1) / gridDim.x); }
+__device__ __forceinline__ unsigned tile_last(unsigned T) {
+  const unsigned e = (blockIdx.x + 1) * ((T + gridDim.x - 1) / gridDim.x);
+  return e < T ? e : T;
+}
+__device__ __forceinline__ TilePix tile_pix(unsigned t, unsigned W, unsigned H) {
+  const unsigned c = threadIdx.x & ((1u << TILE_WL) - 1), r = threadIdx.x >> TILE_WL;
+  const unsigned tx = (W + (1u << TILE_WL) - 1) >> TILE_WL, ty = (H + (1u << TILE_HL) - 1) >> TILE_HL;
+  const unsigned q = t / ty, by = t - q * ty;
+  const unsigned n = q / tx, bx = q - n * tx;
+  TilePix p;
+  p.x = (int)((bx << TILE_WL) + c); p.y = (int)((by << TILE_HL) + r); p.n = (int)n;
+  p.ok = (unsigned)p.x < W && (unsigned)p.y < H;
+  p.i = (n * H + (unsigned)p.y) * W + (unsigned)p.x;
   return p;
 }
 

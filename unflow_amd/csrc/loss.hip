@@ -53,21 +53,25 @@ __device__ __forceinline__ Taps iw_taps(int px, int py, float u, float v, int H,
   return t;
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __global__ void warp_gray_fwd_kernel(const float* __restrict__ im, int ld, const float* __restrict__ flow,
                                      float fscale, float* __restrict__ out, int shift, int N, int H, int W) {
-  const unsigned npx = (unsigned)N * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const Pix pp = decode_pix(i, W, H);
+  const unsigned T = tile_count(W, H, N);
+  for (unsigned tile = tile_first(T), tile_end = tile_last(T); tile < tile_end; tile++) {
+    const TilePix pp = tile_pix(tile, W, H);
+    if (!pp.ok) continue;
+    const unsigned i = pp.i;
     const int px = pp.x, py = pp.y, n = pp.n;
     const long sb = (long)((n + shift) % N) * H * W;
-    const float2 f = reinterpret_cast<const float2*>(flow)[i];
+    const f32x2_t fv = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(flow) + i);   // streamed once
+    const float2 f = make_float2(fv.x, fv.y);
     const Taps t = iw_taps(px, py, f.x * fscale, f.y * fscale, H, W);
     const float *pa = im + (sb + t.ia) * ld, *pb = im + (sb + t.ib) * ld, *pc = im + (sb + t.ic) * ld,
                 *pd = im + (sb + t.id) * ld;
     float c[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) c[k] = ((t.wa * pa[k] + t.wb * pb[k]) + t.wc * pc[k]) + t.wd * pd[k];
-    out[i] = gray255(c[0], c[1], c[2]);
+    __builtin_nontemporal_store(gray255(c[0], c[1], c[2]), out + i);
   }
 }
 
@@ -132,9 +136,11 @@ __device__ __forceinline__ void warp_gray_bwd_pixel(float dg, const float* __res
 __global__ void warp_gray_bwd_kernel(const float* __restrict__ dgray, const float* __restrict__ im, int ld,
                                      const float* __restrict__ flow, float fscale, float* __restrict__ dflow, int acc,
                                      int shift, int N, int H, int W) {
-  const unsigned npx = (unsigned)N * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const Pix pp = decode_pix(i, W, H);
+  const unsigned T = tile_count(W, H, N);
+  for (unsigned tile = tile_first(T), tile_end = tile_last(T); tile < tile_end; tile++) {
+    const TilePix pp = tile_pix(tile, W, H);
+    if (!pp.ok) continue;
+    const unsigned i = pp.i;
     warp_gray_bwd_pixel(dgray[i], im, ld, flow, fscale, dflow, acc, shift, N, H, W, i, pp.x, pp.y, pp.n);
   }
 }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restric
                                                           const float* __restrict__ mask, int n_mask,
                                                           float* __restrict__ wgt_out, float* __restrict__ loss_acc,
                                                           float scale, int D, int N, int H, int W) {
-  ternary_fwd_body(g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, blockIdx.x, gridDim.x);
+  ternary_fwd_body(g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, xcd_block(), gridDim.x);
 }
 
 // Gather form: d/dG2(q) = sum_e f(q, q+e) * (Wt(q+e) + Wt(q)), see DESIGN.md (census backward).
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restric
                                                           int N, int H, int W, const float* __restrict__ im, int ld,
                                                           const float* __restrict__ flow, float fscale,
                                                           float* __restrict__ dflow, int acc, int shift) {
-  ternary_bwd_body(g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, blockIdx.x);
+  ternary_bwd_body(g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, xcd_block());
 }
 
 UNFLOW_API int unflow_ternary_fwd(const float* gray1, const float* gray2w, const float* mask, int n_mask,
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(256) void mask_terms_kernel(const float* __restrict
   __shared__ float red[4];
   const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+  for (unsigned i = xcd_block() * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
     const Pix pp = decode_pix(i, W, H);
     const int x = pp.x, y = pp.y, n = pp.n;
     const long pix = (long)y * W + x;
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(256) void photometric_kernel(const float* __restric
   __shared__ float red[4];
   const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+  for (unsigned i = xcd_block() * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
     const Pix pp = decode_pix(i, W, H);
     const int px = pp.x, py = pp.y, n = pp.n;
     const long sb = (long)((n + shift) % N) * H * W;
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(256) void smooth_1st_kernel(const float* __restrict
   __shared__ float red[4];
   const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+  for (unsigned i = xcd_block() * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
     const Pix pp = decode_pix(i, W, H);
     const int x = pp.x, y = pp.y;
     const float2* f = reinterpret_cast<const float2*>(flow) + (i - ((long)y * W + x));
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(256) void gradient_loss_fwd_kernel(const float* __r
   __shared__ float red[4];
   const unsigned npx = (unsigned)N * H * W;
   float local = 0.f;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+  for (unsigned i = xcd_block() * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
     const Pix pp = decode_pix(i, W, H);
     const int x = pp.x, y = pp.y;
     const long n = pp.n;

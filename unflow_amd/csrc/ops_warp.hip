@@ -48,53 +48,56 @@ __device__ __forceinline__ void st_nt_px(float* p, const float (&s)[CT ? CT : 1]
   }
 }
 
+// One pixel's four taps: addresses, weights, in-range masks.
+struct BwPix {
+  const float *p_tl, *p_tr, *p_bl, *p_br;
+  float w_tl, w_tr, w_bl, w_br;
+  bool m_tl, m_tr, m_bl, m_br;
+};
+__device__ __forceinline__ BwPix bw_pix(const float* img, const TilePix& pp, float2 f, int H, int W, int CC) {
+  const BwTaps t = bw_sample(pp.x, pp.y, f.x, f.y);
+  const float* base = img + (long)pp.n * H * W * CC;
+  const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 >= -1 && t.x0 < W - 1;
+  const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 >= -1 && t.y0 < H - 1;
+  // branch-free taps: addresses clamped into the image, out-of-range VALUES replaced by 0 (the reference
+  // skips them, :44-67; adding w*0 is the same number and keeps the four-term order)
+  const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0, -1), W - 2) + 1;
+  const int ya = min(max(t.y0, 0), H - 1), yc = min(max(t.y0, -1), H - 2) + 1;
+  BwPix q;
+  q.p_tl = base + (size_t)(ya * W + xa) * CC;
+  q.p_tr = base + (size_t)(ya * W + xb) * CC;
+  q.p_bl = base + (size_t)(yc * W + xa) * CC;
+  q.p_br = base + (size_t)(yc * W + xb) * CC;
+  q.m_tl = xl && yt; q.m_tr = xr && yt; q.m_bl = xl && yb; q.m_br = xr && yb;
+  q.w_tl = t.wl * t.wt; q.w_tr = t.wr * t.wt; q.w_bl = t.wl * t.wb; q.w_br = t.wr * t.wb;
+  return q;
+}
+__device__ __forceinline__ float bw_mix(const BwPix& q, float v_tl, float v_tr, float v_bl, float v_br) {
+  float s = 0.f;
+  s += q.m_tl ? q.w_tl * v_tl : 0.f;
+  s += q.m_tr ? q.w_tr * v_tr : 0.f;
+  s += q.m_bl ? q.w_bl * v_bl : 0.f;
+  s += q.m_br ? q.w_br * v_br : 0.f;
+  return s;
+}
+
 template <int CT>
 __global__ void backward_warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ flow,
                                          float* __restrict__ out, int B, int H, int W, int C) {
-  const unsigned npx = (unsigned)B * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const Pix pp = decode_pix(i, W, H);
-    const int px = pp.x, py = pp.y;
-    const long b = pp.n;
-    const float2 f = ld_nt2(flow + 2 * (size_t)i);
-    const BwTaps t = bw_sample(px, py, f.x, f.y);
-    const float* base = img + b * H * W * C;
-    const bool xl = t.x0 >= 0 && t.x0 < W, xr = t.x0 >= -1 && t.x0 < W - 1;
-    const bool yt = t.y0 >= 0 && t.y0 < H, yb = t.y0 >= -1 && t.y0 < H - 1;
-    // branch-free taps: addresses clamped into the image, out-of-range VALUES replaced by 0 (the reference
-    // skips them, :44-67; adding w*0 is the same number and keeps the four-term order)
-    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0, -1), W - 2) + 1;
-    const int ya = min(max(t.y0, 0), H - 1), yc = min(max(t.y0, -1), H - 2) + 1;
+  const unsigned T = tile_count(W, H, B);
+  for (unsigned tile = tile_first(T), tile_end = tile_last(T); tile < tile_end; tile++) {
+    const TilePix tp = tile_pix(tile, W, H);
+    if (!tp.ok) continue;
+    const unsigned i = tp.i;
     const int CC = CT ? CT : C;
-    const float* p_tl = base + (size_t)(ya * W + xa) * CC;
-    const float* p_tr = base + (size_t)(ya * W + xb) * CC;
-    const float* p_bl = base + (size_t)(yc * W + xa) * CC;
-    const float* p_br = base + (size_t)(yc * W + xb) * CC;
-    const bool m_tl = xl && yt, m_tr = xr && yt, m_bl = xl && yb, m_br = xr && yb;
-    const float w_tl = t.wl * t.wt, w_tr = t.wr * t.wt, w_bl = t.wl * t.wb, w_br = t.wr * t.wb;
+    const BwPix a = bw_pix(img, tp, ld_nt2(flow + 2 * (size_t)i), H, W, CC);
     if constexpr (CT != 0) {
       float r[CT ? CT : 1];
 #pragma unroll
-      for (int c = 0; c < CT; c++) {
-        const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
-        float s = 0.f;
-        s += m_tl ? w_tl * v_tl : 0.f;
-        s += m_tr ? w_tr * v_tr : 0.f;
-        s += m_bl ? w_bl * v_bl : 0.f;
-        s += m_br ? w_br * v_br : 0.f;
-        r[c] = s;
-      }
+      for (int c = 0; c < CT; c++) r[c] = bw_mix(a, a.p_tl[c], a.p_tr[c], a.p_bl[c], a.p_br[c]);
       st_nt_px<CT>(out + (size_t)i * CT, r);
     } else {
-      for (int c = 0; c < CC; c++) {
-        const float v_tl = p_tl[c], v_tr = p_tr[c], v_bl = p_bl[c], v_br = p_br[c];
-        float s = 0.f;
-        s += m_tl ? w_tl * v_tl : 0.f;
-        s += m_tr ? w_tr * v_tr : 0.f;
-        s += m_bl ? w_bl * v_bl : 0.f;
-        s += m_br ? w_br * v_br : 0.f;
-        out[(size_t)i * CC + c] = s;
-      }
+      for (int c = 0; c < C; c++) out[(size_t)i * C + c] = bw_mix(a, a.p_tl[c], a.p_tr[c], a.p_bl[c], a.p_br[c]);
     }
   }
 }
@@ -103,9 +106,11 @@ template <int CT>
 __global__ void backward_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ img,
                                          const float* __restrict__ flow, float* __restrict__ dflow, int B,
                                          int H, int W, int C) {
-  const unsigned npx = (unsigned)B * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const Pix pp = decode_pix(i, W, H);
+  const unsigned T = tile_count(W, H, B);
+  for (unsigned tile = tile_first(T), tile_end = tile_last(T); tile < tile_end; tile++) {
+    const TilePix pp = tile_pix(tile, W, H);
+    if (!pp.ok) continue;
+    const unsigned i = pp.i;
     const int px = pp.x, py = pp.y;
     const long b = pp.n;
     const float2 f = ld_nt2(flow + 2 * (size_t)i);
@@ -215,9 +220,11 @@ template <int CT>
 __global__ void image_warp_fwd_kernel(const float* __restrict__ im, int ld_im, const float* __restrict__ flow,
                                       float fscale, float* __restrict__ out, int* __restrict__ idx4, int shift,
                                       int B, int H, int W, int C) {
-  const unsigned npx = (unsigned)B * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const Pix pp = decode_pix(i, W, H);
+  const unsigned T = tile_count(W, H, B);
+  for (unsigned tile = tile_first(T), tile_end = tile_last(T); tile < tile_end; tile++) {
+    const TilePix pp = tile_pix(tile, W, H);
+    if (!pp.ok) continue;
+    const unsigned i = pp.i;
     const int px = pp.x, py = pp.y, b = pp.n;
     const int bs = (b + shift) % B;
     const float2 f = ld_nt2(flow + 2 * (size_t)i);
@@ -249,9 +256,11 @@ __global__ void image_warp_bwd_kernel(const float* __restrict__ dout, const floa
                                       const float* __restrict__ flow, float fscale, float* __restrict__ d_im,
                                       float* __restrict__ d_flow, int acc_flow, int shift, int B, int H, int W,
                                       int C) {
-  const unsigned npx = (unsigned)B * H * W;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const Pix pp = decode_pix(i, W, H);
+  const unsigned T = tile_count(W, H, B);
+  for (unsigned tile = tile_first(T), tile_end = tile_last(T); tile < tile_end; tile++) {
+    const TilePix pp = tile_pix(tile, W, H);
+    if (!pp.ok) continue;
+    const unsigned i = pp.i;
     const int px = pp.x, py = pp.y, b = pp.n;
     const int bs = (b + shift) % B;
     const float2 f = reinterpret_cast<const float2*>(flow)[i];
