@@ -53,7 +53,7 @@ const char* unflow_status_string(int status);
 int unflow_version(void);
 
 /* Library options (csrc/options.h lists them with their defaults): integer switches that select kernels and split
- * planning — e.g. "conv_math_fp32", "halo", "wgrad_kgroups".  They replace what the reference fixes at build time
+ * planning — e.g. "conv_math_fp32", "halo", "gather_max_split".  They replace what the reference fixes at build time
  * through its JIT compile flags (src/e2eflow/ops.py:21-48); set them once after loading the library, before the first
  * launch (a later change applies to the launches planned after it).  UNFLOW_ERR_UNSUPPORTED: no such option.
  * unflow_option_names: the names, '\n'-separated. */
