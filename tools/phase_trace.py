@@ -65,6 +65,24 @@ def main():
             print("  wave %d: %d tiles, %.0f cycles per tile: " % (wv, n, tot) +
                   ", ".join("%s %.0f (%.0f%%)" % (nm, v, 100 * v / tot) for nm, v in zip(names, ph) if nm))
 
+    if os.environ.get("PHASE_TRACE_DEEP"):
+        # conv6_1 forward (8 x 6 x 8 x 1024 -> 1024): the plain gather kernel, 18 K tiles per workgroup
+        Bd, Hd, Wd, Cd = 8, 6, 8, 1024
+        Xd = L.PT.alloc((Bd, Hd, Wd, Cd), dev, 3)
+        Xd.t.copy_(torch.randn(Bd, Hd, Wd, Cd, generator=g))
+        L.planes_from_f32(Xd.t, Xd.pl)
+        wd = (torch.randn(3, 3, Cd, Cd, generator=g) / (9 * Cd) ** 0.5).to(dev)
+        dd = torch.zeros(3, 9, Cd, Cd, dtype=torch.int16, device=dev)
+        td = torch.zeros(3, 9, Cd, Cd, dtype=torch.int16, device=dev)
+        _lib.check(_lib.lib().unflow_weight_planes_batched(1, (ctypes.c_void_p * 1)(wd.data_ptr()), (ctypes.c_int * 1)(9),
+                                                          (ctypes.c_int * 1)(Cd), (ctypes.c_int * 1)(Cd),
+                                                          (ctypes.c_void_p * 1)(dd.data_ptr()), (ctypes.c_void_p * 1)(td.data_ptr()), 3,
+                                                          _lib.stream()), "wp")
+        Yd = L.PT.alloc((Bd, Hd, Wd, Cd), dev, 3)
+        bd = torch.zeros(Cd, device=dev)
+        trace("gather kernel, conv6_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(Xd, wd, td, bd, Yd, 1, True),
+              ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
+        return
     trace("halo kernel, conv3_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),
           ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
     trace("LDS-DMA filter gradient, conv3_1 (24 MFMAs per wave and stage):", lambda: L.conv_bwd_filter(X, DZ, dw, 1),

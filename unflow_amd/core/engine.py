@@ -374,7 +374,7 @@ class _Stage:
                 c3, out = self.pt(op.src), self.pt(op.dst)
                 C = op.src[2] - op.src[1]
                 h8, w8 = e.H // 8, e.W // 8
-                c3pl = _lib.planes_of(c3.pl if e.n_planes == 3 else None)     # bf16 planes: the matrix-core path
+                c3pl = _lib.planes_of(self._corr_planes(c3, refresh=True))   # bf16 x 3 planes: the matrix-core path
                 check(_lib.lib().unflow_correlation_nhwc_fwd_pl(ptr(c3.t), ptr(c3.t), c3.t.stride(2), c3pl, c3pl, B,
                                                                 ptr(out.t), out.t.stride(2), N, C, h8, w8, 1, 20, 20, 1, 2,
                                                                 e.stream()), "correlation")
@@ -393,6 +393,22 @@ class _Stage:
                 L.deconv_fwd(x, l.w, l.wpl_d, l.b, y, l.act, planes_only=po)
 
     # -------------------------------------------------------------- backward
+    def _corr_planes(self, c3, refresh=False):
+        """The bf16 x 3 operand planes of the correlation's feature maps.  bf16x3 mode: the planes conv3 wrote.  fp16 mode: the
+        correlation stays fp32-equivalent (its kernels take bf16 x 3 planes only), so the fp32 features are split once per
+        forward pass into a side buffer — the planes kernels instead of the fp32-MFMA ones (B = 8: 284 + 547 us)."""
+        e = self.eng
+        if e.n_planes == 3:
+            return c3.pl
+        if e.n_planes != 1:
+            return None
+        if getattr(self, '_c3_b3', None) is None:
+            n, h, w, c = c3.t.shape
+            self._c3_b3 = torch.zeros(3, n, h, w, (c + 7) // 8 * 8, dtype=torch.int16, device=c3.t.device)
+        if refresh:
+            L.planes_from_f32(c3.t, self._c3_b3)
+        return self._c3_b3
+
     def backward(self, part=None, before_join=None):
         """part None: everything; k: the k-th slice of the backward list (default cuts: 0 = decoder + conv6_1..conv4 — 94 %
         of the parameters, whose gradients are final afterwards so that their all-reduce can start — 1 = conv3_1 ..
@@ -440,7 +456,7 @@ class _Stage:
                 C = op.src[2] - op.src[1]
                 h8, w8 = e.H // 8, e.W // 8
                 assert first
-                c3pl = _lib.planes_of(c3.pl if e.n_planes == 3 else None)     # bf16 planes: feature operand by LDS-DMA
+                c3pl = _lib.planes_of(self._corr_planes(c3))                 # bf16 x 3 planes: feature operand by LDS-DMA
                 check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(gout.t), gout.t.stride(2), ptr(c3.t), ptr(c3.t),
                                                                 c3.t.stride(2), c3pl, c3pl, B, ptr(g3.t), ptr(None),
                                                                 g3.t.stride(2), 1, N, C, h8, w8, 1, 20, 20, 1, 2, e.stream()),

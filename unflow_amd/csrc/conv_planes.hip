@@ -527,7 +527,9 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   constexpr int NGROUP = 2 * TM * NT;        // MFMA groups per tile between which the load pieces are placed
   constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
 
+  PHASE_DECL;
   for (int kt = kt0; kt < kt1; kt++) {
+    PHASE_STAMP(6);
     live = kt + 1 < kt1;
 #pragma unroll
     for (int slab = 0; slab < 2; slab++) {
@@ -554,10 +556,19 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
         }
       }
     }
+    PHASE_STAMP(0);   // MFMA phase (fragment reads, the MFMAs, the next tile's loads issued)
     __syncthreads();  // every wave is done reading this tile
+    PHASE_STAMP(1);
+#ifdef UNFLOW_PHASE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_STAMP(2);   // the next tile's loads landed
+#endif
     store_tile();     // (last iteration: zeros, never read)
+    PHASE_STAMP(3);
     __syncthreads();
+    PHASE_STAMP(4);
   }
+  PHASE_FLUSH;
 
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
   if (p.fused_splitk) {
