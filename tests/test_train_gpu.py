@@ -8,6 +8,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -201,3 +202,45 @@ def test_losses_mirrors_vs_oracle(dev):
     ref = M.second_order_loss(flow.double()).item()
     assert abs(got - ref) <= 2e-5 * abs(ref)
     assert torch.equal(LS.create_outgoing_mask(flow), M.create_outgoing_mask(flow))
+
+
+@pytest.mark.gpu
+def test_trainer_run_saves_checkpoints_and_resumes_identically(tmp_path):
+    """Trainer.run (train.py:116-145) end to end: 4 steps in chunks of 2 with a TF checkpoint-V2 bundle after each chunk; a second
+    trainer that starts from the first chunk's checkpoint (weights + Adam slots restored, bias correction restarted, input shifted)
+    ends with bit-identical parameters."""
+    import shutil
+    from unflow_amd.core.train import Trainer
+    from unflow_amd.core import tf_checkpoint as T
+    dev = torch.device("cuda:0")
+    params = dict(flownet='S', learning_rate=1e-4, decay_interval=100000, save_interval=2, display_interval=1)
+    g = torch.Generator().manual_seed(5)
+    frames = [(torch.rand(1, 64, 64, 3, generator=g) * 255, torch.rand(1, 64, 64, 3, generator=g) * 255) for _ in range(4)]
+
+    def batches(iter_offset):
+        k = iter_offset
+        while True:
+            yield frames[k % 4][0].to(dev), frames[k % 4][1].to(dev)
+            k += 1
+
+    ck_a, ck_b = str(tmp_path / "a"), str(tmp_path / "b")
+    tr = Trainer(1, 64, 64, params, device=dev, seed=3, augment=False, use_graph=False)
+    log = tr.run(0, 4, batches, ck_a)
+    assert [i for i, _ in log] == [1, 2, 3, 4] and all(np.isfinite(l) for _, l in log)
+    assert tr.checkpoint_step(ck_a) == 4
+    ent = T.checkpoint_entries(os.path.join(ck_a, 'model.ckpt-4'))[1]
+    assert 'flownet_s/conv1/weights' in ent and 'flownet_s/conv1/weights/Adam_1' in ent and 'global_step' in ent
+    final = tr.engine.export_tf_params()
+    # resume from the checkpoint of the first chunk
+    os.makedirs(ck_b)
+    for f in os.listdir(ck_a):
+        if 'model.ckpt-2' in f:
+            shutil.copy(os.path.join(ck_a, f), ck_b)
+    with open(os.path.join(ck_b, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "model.ckpt-2"\n')
+    tr2 = Trainer(1, 64, 64, params, device=dev, seed=99, augment=False, use_graph=False)     # different initialisation
+    tr2.run(0, 4, batches, ck_b)
+    assert tr2.checkpoint_step(ck_b) == 4
+    got = tr2.engine.export_tf_params()
+    for k in final:
+        assert torch.equal(final[k], got[k]), k

@@ -72,7 +72,7 @@ class Layer:
     """One conv / conv_transpose variable pair.  in_map: [(physical lo, tf lo, n)] — where the reference's input channels
     live in the (padded, segment-aligned) physical input of the layer; cout_p >= cout is the physical output width
     (pad columns keep zero weights / bias and receive exactly zero gradient)."""
-    __slots__ = ('name', 'kind', 'k', 'cin', 'cout', 'stride', 'act', 'cin_p', 'cout_p', 'in_map', 'w', 'b', 'dw', 'db',
+    __slots__ = ('name', 'kind', 'k', 'cin', 'cout', 'stride', 'act', 'cin_p', 'cout_p', 'in_map', 'w', 'b', 'dw', 'db', 'mw', 'vw', 'mb', 'vb',
                  'wpl_d', 'wpl_t')
 
     def __init__(self, name, kind, k, cin, cout, stride, act, in_map=None, cin_p=None):
@@ -583,10 +583,12 @@ class FlowNetEngine:
             n = int(torch.Size(l.wshape()).numel())
             l.w = self.P[off:off + n].view(l.wshape())
             l.dw = self.G[off:off + n].view(l.wshape())
+            l.mw, l.vw = self.M[off:off + n].view(l.wshape()), self.V[off:off + n].view(l.wshape())   # Adam slots
             off += n
         for l in self.layers:
             l.b = self.P[off:off + l.cout_p]
             l.db = self.G[off:off + l.cout_p]
+            l.mb, l.vb = self.M[off:off + l.cout_p], self.V[off:off + l.cout_p]
             off += l.cout_p
         # operand planes of the weights (csrc/conv_planes.hip): direct [P][tap][R][round8(Cc)], transposed
         # [P][tap][Cc][round8(R)] of W[tap][R][Cc]; one flat int16 buffer, refreshed by one batched launch
@@ -701,6 +703,34 @@ class FlowNetEngine:
 
     def export_tf_params(self):
         return self._export('w', 'b')
+
+    def export_tf_adam_slots(self):
+        """Adam's first / second moments under the names tf.train.AdamOptimizer gives its slot variables:
+        '<variable>/Adam' and '<variable>/Adam_1' (what the reference's Saver writes next to the weights: slim's
+        get_variables_to_restore(include=[scope]) matches them by prefix, train.py:33-38)."""
+        out = OrderedDict()
+        for suffix, (wa, ba) in (('/Adam', ('mw', 'mb')), ('/Adam_1', ('vw', 'vb'))):
+            for k, v in self._export(wa, ba).items():
+                out[k + suffix] = v
+        return out
+
+    def load_tf_adam_slots(self, tf_slots):
+        """Inverse of export_tf_adam_slots; variables without slots in `tf_slots` keep zero moments."""
+        self.M.zero_()
+        self.V.zero_()
+        for suffix, (wa, ba) in (('/Adam', ('mw', 'mb')), ('/Adam_1', ('vw', 'vb'))):
+            for l in self.layers:
+                kw, kb = l.name + '/weights' + suffix, l.name + '/biases' + suffix
+                if kw in tf_slots:
+                    w = tf_slots[kw].to(self.dev, torch.float32)
+                    dst = getattr(l, wa)
+                    for plo, tlo, n in l.in_map:
+                        if l.kind == 'conv':
+                            dst[:, :, plo:plo + n, :l.cout] = w[:, :, tlo:tlo + n, :]
+                        else:
+                            dst[:, :, :l.cout, plo:plo + n] = w[:, :, :, tlo:tlo + n]
+                if kb in tf_slots:
+                    getattr(l, ba)[:l.cout].copy_(tf_slots[kb].to(self.dev, torch.float32))
 
     def export_tf_grads(self):
         """Gradients of the data loss (the L2-regulariser gradient 0.0004*w is fused into adam_step)."""

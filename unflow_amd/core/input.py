@@ -11,6 +11,7 @@
     vectors scaled by the size ratio — what eval uses before flow_error_avg / outlier_pct (eval_gui.py:68-93).
 
 PNG decoding uses only the standard library (zlib): 16-bit RGB, non-interlaced, the five PNG filters."""
+import os
 import struct
 import zlib
 from collections import OrderedDict
@@ -242,3 +243,190 @@ def resize_output_flow(t, height, width, channels=2):
     _, old_h, old_w, _ = t.shape
     r = resize_bilinear_tf1(t, height, width)
     return torch.stack([r[..., 0] * (width / old_w), r[..., 1] * (height / old_h)], dim=3)
+
+
+# ------------------------------------------------------------------------------------- raw-frame input (core/input.py:37-218)
+def frame_name_to_num(name):
+    """frame_name_to_num (input.py:37-41): '0000012.png' -> 12, '000.png' -> 0."""
+    stripped = name.split('.')[0].lstrip('0')
+    return 0 if stripped == '' else int(stripped)
+
+
+def encode_png8_rgb(arr):
+    """uint8 [H,W,3] -> PNG bytes (filter 0, one IDAT): the writer for the input-pipeline fixtures and tests."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    raw = b''.join(b'\x00' + a[y].tobytes() for y in range(h))
+
+    def chunk(t, b):
+        return struct.pack('>I', len(b)) + t + b + struct.pack('>I', zlib.crc32(t + b) & 0xffffffff)
+    return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 2, 0, 0, 0)) +
+            chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
+def read_png_image(path):
+    """read_png_image (input.py:208-218) for one file: decode_png(channels=3) cast to float32, [H,W,3]."""
+    with open(path, 'rb') as f:
+        a = decode_png(f.read())
+    if a.ndim == 2:
+        a = np.repeat(a[:, :, None], 3, axis=2)
+    return a[:, :, :3].astype(np.float32)
+
+
+def resize_image_with_crop_or_pad(a, height, width):
+    """tf.image.resize_image_with_crop_or_pad on [H,W,C]: central crop and / or symmetric zero padding (the extra row /
+    column of an odd difference goes to the bottom / right, as in TF)."""
+    h, w = a.shape[:2]
+    if h > height:
+        o = (h - height) // 2
+        a = a[o:o + height]
+    if w > width:
+        o = (w - width) // 2
+        a = a[:, o:o + width]
+    h, w = a.shape[:2]
+    if h < height or w < width:
+        top, left = (height - h) // 2, (width - w) // 2
+        out = np.zeros((height, width) + a.shape[2:], dtype=a.dtype)
+        out[top:top + h, left:left + w] = a
+        a = out
+    return a
+
+
+class RawPairBatches:
+    """What tf.train.batch over a string_input_producer(shuffle=False, num_epochs=None) yields (input.py:186-205): the pair
+    list is walked in order, cyclically, `batch_size` examples per call; every example is read, cropped with ONE random
+    window for both frames (augment.random_crop, augment.py:113-134) or reshaped, and normalised.  next() returns
+    (image_1, image_2) as float32 arrays [B,H,W,3]."""
+
+    def __init__(self, pairs, batch_size, dims, needs_crop, normalize, mean, stddev, seed):
+        self.pairs, self.batch_size, self.dims = list(pairs), batch_size, tuple(dims)
+        self.needs_crop, self.normalize = needs_crop, normalize
+        self.mean, self.stddev = np.asarray(mean, dtype=np.float32), np.float32(stddev)
+        self.pos = 0
+        self.rng = np.random.RandomState(seed)
+
+    def __iter__(self):
+        return self
+
+    def _example(self, fn1, fn2):
+        a, b = read_png_image(fn1), read_png_image(fn2)
+        h, w = self.dims
+        if self.needs_crop:
+            lim_h, lim_w = min(a.shape[0], b.shape[0]), min(a.shape[1], b.shape[1])
+            oy = int(self.rng.randint(0, lim_h - h + 1))
+            ox = int(self.rng.randint(0, lim_w - w + 1))
+            a, b = a[oy:oy + h, ox:ox + w], b[oy:oy + h, ox:ox + w]
+        else:
+            a, b = a.reshape(h, w, 3), b.reshape(h, w, 3)
+        if self.normalize:
+            a, b = (a - self.mean) / self.stddev, (b - self.mean) / self.stddev
+        return a, b
+
+    def __next__(self):
+        im1, im2 = [], []
+        for _ in range(self.batch_size):
+            a, b = self._example(*self.pairs[self.pos % len(self.pairs)])
+            self.pos += 1
+            im1.append(a)
+            im2.append(b)
+        return np.stack(im1).astype(np.float32), np.stack(im2).astype(np.float32)
+
+
+class Input:
+    """core/input.py:44-205 of the reference without the TF queue runners: the same pair lists (sorted listing, sequence /
+    pair stepping, skipped-frame filter, seeded shuffle, swapped pairs, `shift` for resuming), the same preprocessing, batches as
+    numpy arrays.  `data` needs get_raw_dirs() and, for the test inputs, current_dir (the reference's Data classes)."""
+    mean = [104.920005, 110.1753, 114.785955]
+    stddev = 1 / 0.0039216
+
+    def __init__(self, data, batch_size, dims, *, num_threads=1, normalize=True, skipped_frames=False):
+        assert len(dims) == 2
+        self.data = data
+        self.dims = dims
+        self.batch_size = batch_size
+        self.num_threads = num_threads          # kept for signature parity; reading is synchronous here
+        self.normalize = normalize
+        self.skipped_frames = skipped_frames
+
+    def get_normalization(self):
+        return self.mean, self.stddev
+
+    def _normalize_image(self, image):
+        return (image - np.asarray(self.mean, dtype=np.float32)) / np.float32(self.stddev)
+
+    def _preprocess_image(self, image):
+        h, w = self.dims
+        image = resize_image_with_crop_or_pad(image, h, w).reshape(h, w, 3)
+        return self._normalize_image(image) if self.normalize else image
+
+    def raw_pairs(self, swap_images=True, sequence=True, shift=0, seed=0, skip=0):
+        """The ordered example list of input_raw (input.py:121-184): [(first file, second file), ...]."""
+        import random
+        if not isinstance(skip, list):
+            skip = [skip]
+        filenames = []
+        for dir_path in self.data.get_raw_dirs():
+            files = sorted(os.listdir(dir_path))
+            if sequence:
+                steps = [1 + s for s in skip]
+                stops = [len(files) - s for s in steps]
+            else:
+                steps = [2]
+                stops = [len(files)]
+                assert len(files) % 2 == 0
+            for step, stop in zip(steps, stops):
+                for i in range(0, stop, step):
+                    if self.skipped_frames and sequence:
+                        assert step == 1
+                        if frame_name_to_num(files[i]) + 1 != frame_name_to_num(files[i + 1]):
+                            continue
+                    filenames.append((os.path.join(dir_path, files[i]), os.path.join(dir_path, files[i + 1])))
+        random.seed(seed)
+        random.shuffle(filenames)
+        extended = []
+        for fn1, fn2 in filenames:
+            extended.append((fn1, fn2))
+            if swap_images:
+                extended.append((fn2, fn1))
+        shift = shift % len(extended)
+        # np.roll of the reference acts on the FLATTENED [n, 2] string array (input.py:173): an odd shift also swaps the roles
+        # of first and second file; reproduced literally
+        flat = [f for pair in extended for f in pair]
+        flat = flat[-shift:] + flat[:-shift] if shift else flat
+        return [(flat[2 * i], flat[2 * i + 1]) for i in range(len(extended))]
+
+    def input_raw(self, swap_images=True, sequence=True, needs_crop=True, shift=0, seed=0, center_crop=False, skip=0):
+        """input_raw (input.py:121-205): an iterator of (image_1, image_2) batches [B,H,W,3] float32.  `shift`: examples to skip
+        at the start — the reference resumes training with shift = batch_size * iterations done (train.py / run.py)."""
+        pairs = self.raw_pairs(swap_images=swap_images, sequence=sequence, shift=shift, seed=seed, skip=skip)
+        print("Training on {} frame pairs.".format(len(pairs) // (2 if swap_images else 1)))
+        return RawPairBatches(pairs, self.batch_size, self.dims, needs_crop, self.normalize, self.mean, self.stddev, seed)
+
+    def test_pairs(self, image_dir, hold_out_inv=None):
+        """_input_images (input.py:76-108): consecutive files of a directory are pairs; hold_out_inv keeps the first n pairs
+        of the seed-0 shuffle."""
+        import random
+        image_dir = os.path.join(self.data.current_dir, image_dir)
+        files = sorted(os.listdir(image_dir))
+        assert len(files) % 2 == 0, 'expected pairs of images'
+        pairs = [(os.path.join(image_dir, files[2 * i]), os.path.join(image_dir, files[2 * i + 1])) for i in range(len(files) // 2)]
+        if hold_out_inv is not None:
+            random.seed(0)
+            random.shuffle(pairs)
+            pairs = pairs[:hold_out_inv]
+        return pairs
+
+    def input_test(self, image_dir, hold_out_inv=None):
+        """_input_test (input.py:110-116): batches of (image_1, image_2, input_shape), one epoch, a smaller final batch allowed."""
+        pairs = self.test_pairs(image_dir, hold_out_inv)
+        for b0 in range(0, len(pairs), self.batch_size):
+            im1, im2, shp = [], [], []
+            for fn1, fn2 in pairs[b0:b0 + self.batch_size]:
+                a, b = read_png_image(fn1), read_png_image(fn2)
+                shp.append(np.asarray(a.shape, dtype=np.int32))
+                im1.append(self._preprocess_image(a))
+                im2.append(self._preprocess_image(b))
+            yield np.stack(im1).astype(np.float32), np.stack(im2).astype(np.float32), np.stack(shp)

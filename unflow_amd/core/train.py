@@ -1,6 +1,7 @@
 """Mirror of the hot-path parts of src/e2eflow/core/train.py: the training op (get_train_and_loss_ops :147-185:
 AdamOptimizer + towers + average_gradients :388-422), the learning-rate schedule (:225-244) and the loop body
-(:247-251).  Checkpoint restore, evaluation and TF summaries (:23-65, :265-385) are out of scope.
+(:247-251), Trainer.run / train with checkpoint save and resume (:116-145, :186-262; TF checkpoint-V2 bundles written and
+read by core/tf_checkpoint.py).  Evaluation and TF summaries (:265-385) are out of scope.
 
 One process per GPU.  A training step is
 
@@ -18,6 +19,8 @@ instead of opening the next forward pass.  With one rank there is no exchange: o
 on one rank — StepRunner(local_overlap=True): the HBM-bound Adam + re-split of the deep layers beside the backward pass of the shallow
 ones — measured 2.7 % SLOWER on MI355X, 544 vs 559 pairs/s: the streaming blocks take CU slots from conv launches that are
 sized to fill the chip in exactly one round.)"""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -165,6 +168,84 @@ class Trainer:
         self.augment = augment
         self.generator = torch.Generator().manual_seed(1000003 * (seed + 1) + self.rank)   # per-rank augmentation draws
         self.iteration = 0
+
+    # ---------------------------------------------------------------------------------------------- train.py:116-145, 247-262
+    def checkpoint_step(self, ckpt_dir):
+        """global_step of the latest checkpoint of a directory ('model.ckpt-<step>', train.py:124-127), or None."""
+        from . import tf_checkpoint as T
+        ckpt = T.latest_checkpoint(ckpt_dir)
+        return None if ckpt is None else int(os.path.basename(ckpt).split('-')[-1])
+
+    def save(self, ckpt_dir, global_step):
+        """saver.save(sess, ckpt_dir/model.ckpt, global_step) (train.py:260-261): a TF checkpoint-V2 bundle under the reference's
+        variable names + the directory's `checkpoint` state file.  Rank 0 writes."""
+        from .input import save_checkpoint
+        if self.rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            tensors = self.engine.export_tf_params()
+            tensors.update(self.engine.export_tf_adam_slots())      # '<var>/Adam', '<var>/Adam_1': in the Saver's scope too
+            save_checkpoint(os.path.join(ckpt_dir, 'model.ckpt-%d' % global_step), tensors, global_step)
+
+    def restore(self, ckpt_dir):
+        """restore_networks from the latest checkpoint of ckpt_dir, every network of the spec from the same file (the `ckpt is not
+        None` branch of train.py:40-44)."""
+        from . import tf_checkpoint as T
+        from .input import restore_networks
+        ckpt = T.latest_checkpoint(ckpt_dir)
+        if ckpt is not None:
+            restore_networks(self.engine, self.params, [ckpt] * len(self.engine.spec))
+            names = [k for k in T.checkpoint_entries(ckpt)[1] if k.endswith('/Adam') or k.endswith('/Adam_1')]
+            slots = {k: torch.from_numpy(v) for k, v in T.read_checkpoint(ckpt, names).items()}
+            self.engine.load_tf_adam_slots(slots)
+        return ckpt
+
+    def run(self, min_iter, max_iter, train_batch_fn, ckpt_dir, eval_fn=None):
+        """Trainer.run (train.py:116-145): train (at most) from min_iter + 1 to max_iter in chunks of params['save_interval']
+        steps, a checkpoint after every chunk.  A checkpoint found in ckpt_dir must carry a global_step within [min_iter, max_iter];
+        training then continues from global_step + 1.  train_batch_fn(iter_offset) returns an iterator of (im1, im2) batches
+        already shifted by iter_offset steps (the reference builds its input queue with shift = batch_size * iter_offset);
+        eval_fn(i), if given, runs after each chunk (self.eval(1) of the reference).  Returns the list of (iteration, loss) at the
+        display interval."""
+        save_interval = self.params['save_interval']
+        global_step = self.checkpoint_step(ckpt_dir)
+        if global_step is not None:
+            assert global_step >= min_iter, 'training stage not reached'
+            start_iter = global_step + 1
+            if start_iter > max_iter:
+                print('-- train: max_iter reached')
+                return []
+            self.restore(ckpt_dir)
+        else:
+            start_iter = min_iter + 1
+        print('-- training from i = {} to {}'.format(start_iter, max_iter))
+        assert (max_iter - start_iter + 1) % save_interval == 0
+        log = []
+        for i in range(start_iter, max_iter + 1, save_interval):
+            log += self.train(i, i + save_interval - 1, i - (min_iter + 1), train_batch_fn, ckpt_dir)
+            if eval_fn is not None:
+                eval_fn(i + save_interval - 1)
+        return log
+
+    def train(self, start_iter, max_iter, iter_offset, train_batch_fn, ckpt_dir):
+        """Trainer.train (train.py:186-262): steps start_iter .. max_iter with the learning rate of decay_iters = local_i +
+        iter_offset (learning_rate_at), the loss printed at i == 1 and every display_interval, one checkpoint at the end."""
+        batches = iter(train_batch_fn(iter_offset))
+        display = self.params.get('display_interval', 100)
+        # every train() call of the reference builds a fresh graph and runs global_variables_initializer before the restore
+        # (train.py:186-218, 40): beta1_power / beta2_power are not in the Saver's scope, so Adam's bias correction restarts at
+        # t = 1 with every chunk while the moments continue — reproduced
+        self.engine.step_count = 0
+        log = []
+        for local_i, i in enumerate(range(start_iter, max_iter + 1)):
+            self.iteration = local_i + iter_offset
+            im1, im2 = next(batches)
+            loss = self.train_step(im1, im2)
+            if i == 1 or i % display == 0:
+                loss = float(loss)
+                log.append((i, loss))
+                print("-- train: i = {}, loss = {}".format(i, loss))
+        self.save(ckpt_dir, max_iter)
+        return log
 
     def train_step(self, im1, im2, augment=None):
         """sess.run([train_op, loss_]) (train.py:247-251): returns the loss tensor (device, no sync).  `augment`: None = the

@@ -34,3 +34,54 @@ def downsample(tensor, num):
         return downsample_ops(tensor, num)
     like = torch.empty(1, int(height / num), int(width / num), 1)
     return resize_area(tensor, like)
+
+
+# ------------------------------------------------------------------------------------------------- config.ini (util.py:37-85)
+def config_dict(config_path='../config.ini'):
+    """config_dict (src/e2eflow/util.py:37-62): the ini file as {section: {key: value}} with the reference's coercion order —
+    int, then float, then ConfigParser boolean ('yes' / 'true' / 'on' / '1' ...), else the string."""
+    import configparser
+    config = configparser.ConfigParser()
+    config.read(config_path)
+    d = {}
+    for section_key in config.sections():
+        section = config[section_key]
+        sd = {}
+        for key in section:
+            val = section[key]
+            try:
+                sd[key] = int(val)
+            except ValueError:
+                try:
+                    sd[key] = float(val)
+                except ValueError:
+                    try:
+                        sd[key] = section.getboolean(key)
+                    except ValueError:
+                        sd[key] = val
+        d[section_key] = sd
+    return d
+
+
+def convert_input_strings(config_dct, dirs):
+    """convert_input_strings (util.py:65-85), in place: the comma lists 'manual_decay_iters' / 'manual_decay_lrs' become lists
+    (and fix num_iters to their sum); 'finetune' = comma-separated experiment names becomes the list of their latest
+    checkpoint prefixes — looked up under dirs['checkpoints']/<name>, then dirs['log']/ex/<name>, as the reference does with
+    tf.train.get_checkpoint_state (here: the 'checkpoint' state file read by core/tf_checkpoint.py)."""
+    import os
+    from . import tf_checkpoint as T
+    if 'manual_decay_iters' in config_dct and 'manual_decay_lrs' in config_dct:
+        iters_lst = [int(i) for i in str(config_dct['manual_decay_iters']).split(',')]
+        lrs_lst = [float(x) for x in str(config_dct['manual_decay_lrs']).split(',')]
+        config_dct['manual_decay_iters'] = iters_lst
+        config_dct['manual_decay_lrs'] = lrs_lst
+        config_dct['num_iters'] = sum(iters_lst)
+    if 'finetune' in config_dct:
+        finetune = []
+        for name in str(config_dct['finetune']).split(','):
+            ckpt = T.latest_checkpoint(os.path.join(dirs['checkpoints'], name))
+            if ckpt is None:
+                ckpt = T.latest_checkpoint(os.path.join(dirs['log'], 'ex', name))
+            assert ckpt, "Could not load experiment " + name
+            finetune.append(ckpt)
+        config_dct['finetune'] = finetune
