@@ -64,6 +64,71 @@ def test_bucketed_nccl_world1_step_is_bit_identical_to_the_plain_step(dev):
     assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+_GLOO2_CHILD = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from unflow_amd.core.engine import FlowNetEngine, DEFAULT_PARAMS
+from unflow_amd.core.train import StepRunner
+dev = torch.device("cuda:0")            # both ranks share the one GPU of the box: RCCL refuses that, gloo moves CUDA tensors
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 2
+H, W = 128, 192
+g = torch.Generator().manual_seed(11)
+# global minibatch of 2 pairs per step; rank r trains on pair r
+steps = [((torch.rand(2, H, W, 3, generator=g) * 255), (torch.rand(2, H, W, 3, generator=g) * 255)) for _ in range(3)]
+eng = FlowNetEngine(1, H, W, params=dict(DEFAULT_PARAMS, flownet='C'), device=dev, seed=7)
+run = StepRunner(eng, world, use_graph=True)
+assert run.nparts == 3 and run.reducer.world == 2
+losses = []
+for a, b in steps:
+    losses.append(run.step(a[rank:rank + 1].to(dev), b[rank:rank + 1].to(dev), 1e-4).item())
+torch.cuda.synchronize()
+# (1) every rank holds the same parameters and moments, bit for bit
+for t in (eng.P, eng.M, eng.V):
+    ref = t.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(ref, t), "rank %%d diverged" %% rank
+# (2) they are what ONE process computes on the concatenated minibatch (mean over replicas of the per-replica gradient =
+#     gradient of the mean loss: average_gradients, train.py:388-422), up to fp32 summation order
+if rank == 0:
+    one = FlowNetEngine(2, H, W, params=dict(DEFAULT_PARAMS, flownet='C'), device=dev, seed=7)
+    r1 = StepRunner(one, 1, use_graph=True)
+    l1 = [r1.step(a.to(dev), b.to(dev), 1e-4).item() for a, b in steps]
+    torch.cuda.synchronize()
+    d = (one.P - eng.P).abs()
+    moved = (one.P - FlowNetEngine(2, H, W, params=dict(DEFAULT_PARAMS, flownet='C'), device=dev, seed=7).P).abs().max().item()
+    assert moved > 1e-4                                            # three Adam steps of 1e-4 did move the weights
+    frac_close = (d <= 2e-6).float().mean().item()
+    assert frac_close > 0.999 and d.max().item() <= 3.1e-4, (frac_close, d.max().item())
+    print("GLOO2_OK", frac_close, d.max().item(), losses, l1)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_on_one_gpu_over_gloo_match_each_other_and_the_single_process_step(dev, tmp_path):
+    """The N > 1 path of StepRunner (three backward parts, bucketed all-reduce + Adam + weight re-split on the communication
+    stream) with TWO real ranks.  The build session has one GPU and RCCL refuses two ranks on one device, so the ranks share
+    cuda:0 and exchange over gloo: same host code, same kernels, same stream choreography; only the transport differs."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "child.py"
+    script.write_text(_GLOO2_CHILD % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:] + e[-3000:]
+    assert "GLOO2_OK" in outs[0][0], outs[0][0][-2000:] + outs[0][1][-2000:]
+
+
 def test_trainer_forwards_train_all_and_trains_the_first_network(dev):
     """ADVICE r1: Trainer dropped train_all (stacks silently trained only the last network) and full_res."""
     from unflow_amd.core.train import Trainer
