@@ -116,7 +116,12 @@ def main():
         if os.environ.get("NCCL_DEBUG", "").upper() == "INFO":      # the comm record quotes RCCL's algorithm / protocol lines
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/unflow_rccl_%h_%p.log")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # UNFLOW_DIST_BACKEND=gloo: test knob — several ranks on ONE GPU (RCCL refuses that); same code path, other transport
+        backend = os.environ.get("UNFLOW_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
