@@ -1490,6 +1490,10 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
     const long b128 = ((M + 127) / 128) * ((p.N + 127) / 128) * p.ncls;
     if (b128 * max_by_k < 384) pl.cfg = 2;  // cannot fill half the chip with 128x128 tiles: smaller tiles
   }
+  // a K loop of a few tiles (FlowNetC's first layer: 7) is all prologue and epilogue: more, smaller workgroups in flight
+  // (conv1 forward 98 -> 91 us)
+  if (pl.cfg == 1 && KT <= 8) pl.cfg = 2;
+  if (unflow::options().gather_cfg >= 0 && unflow::options().gather_cfg <= 2 && p.N <= 64) pl.cfg = unflow::options().gather_cfg;   // A/B
   const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
   const int slots = 256 * pl_blocks_per_cu(bm, bn, npl);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;

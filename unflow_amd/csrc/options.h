@@ -15,6 +15,7 @@
   X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
   X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \
   X(halo_s2, 1)           /* halo kernel also for source-stride-2 layers (four accumulating parity classes) */            \
+  X(gather_cfg, -1)       /* force the tile config of the plain gather kernel for N <= 64 layers (1: 128 x 64, 2: 64 x 64) */   \
   X(xcd_swizzle, 1)       /* XCD-contiguous work order */                                                                 \
   X(xcd_order, -1)        /* force work_decode order 0 / 1 / 2 (-1: per-kernel default) */                                \
   X(fused_splitk, 0)      /* n > 0: in-kernel split-K reduction for tiles with up to n slices */                          \
