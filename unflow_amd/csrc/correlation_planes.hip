@@ -550,6 +550,7 @@ struct CorrBwdPlParams {
   int off, nA, T;
   int vr, joff;   // narrow-band mode: see CorrPlParams
   unsigned dout_bytes;   // bytes of dout up to its last band entry (0: larger than 1 GiB, dword gathers only)
+  size_t dout_total;     // the same, always (shared band loads: single-dword buffer loads, clamped to 1 GiB by make_rsrc)
   int rot;               // rotated displacement-row order
 };
 
@@ -571,6 +572,13 @@ __device__ __forceinline__ void corr_split8(const float (&v)[8], u32x4& hi, u32x
   }
 }
 
+// SHARE (C a multiple of 256: the four waves of a workgroup are the four 64-channel groups of ONE (sample, class, site tile,
+// row) and walk the same items): the band operand of an item — 32 x 32 values of dout, the same for every channel group — is
+// fetched ONCE per workgroup, four values per thread, and handed to the waves through LDS (two barriers per item), instead
+// of by each wave for itself with 32-line gathers.  Round 3 ablation (profiles/r03_corr_ablation.txt): the per-wave band
+// loads were 61 of the kernel's 172 us at the step's shape, 246 of 756 us at the 81-channel one.
+constexpr int BAND_PITCH = 36;                       // floats per band row in LDS (144 B: conflict-free 16-byte reads of 32 rows)
+template <bool SHARE>
 __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   constexpr int TILE = 3 * 32 * 64;                 // elements per wave: 3 planes x 32 sites x 64 channels
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   const int role_lo = p.fuse ? 0 : (int)blockIdx.y, role_hi = p.fuse ? 1 : (int)blockIdx.y;
   unsigned short* tile = lds + wid * TILE;
   const unsigned tile_addr = lds_addr(tile);
+  float* band = reinterpret_cast<float*>(lds + 4 * TILE);      // SHARE: [32][BAND_PITCH] floats behind the four tiles
 
   const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
   u32x4 f0_rs[3], f1_rs[3];
@@ -665,6 +674,7 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   // aligned; entries outside the band masked afterwards) — 4 instructions per item instead of 16 on the address path that
   // bounds this kernel.  A run that would start before / end after the buffer (first / last site only) takes the dword path.
   const __amdgpu_buffer_rsrc_t dout_rs = make_rsrc(p.dout, p.dout_bytes);
+  const __amdgpu_buffer_rsrc_t dout_rs_all = make_rsrc(p.dout, p.dout_total);
   auto load_band = [&](float (&av)[2][8]) {
     const int role = it_role;
     const size_t srow = ((size_t)nd * p.oh + oy) * p.ow;
@@ -712,16 +722,64 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   };
 
   constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  // SHARE: thread t fetches Band[a][b .. b+3] with (a, b) = (t / 8, 4 (t % 8)); role 0: a = own site row, b = contracted site
+  // (four consecutive offsets of one site: consecutive floats); role 1: a = contracted site, b = own site (consecutive
+  // offsets again).  Values outside the band / the image are zero.
+  const int sh_a = (int)(threadIdx.x >> 3), sh_b = (int)(threadIdx.x & 7) << 2;
+  float breg[4];
+  int bmask = 0;
+  auto load_band_shared = [&]() {
+    const int role = it_role;
+    const size_t srow = ((size_t)nd * p.oh + oy) * p.ow;
+    const int site = (role == 0 ? i0 : k0) + sh_a;            // the site whose dout row is read
+    const int ox = q + p.s2 * site;
+    const bool site_ok = (unsigned)ox < (unsigned)p.ow;
+    // offsets of the four values: role 0: o = (k0 + b + e) - (i0 + a); role 1: o = (i0 + b + e) - (k0 + a)
+    const int o0 = role == 0 ? (k0 + sh_b) - (i0 + sh_a) : (i0 + sh_b) - (k0 + sh_a);
+    const long base = (long)(srow + (site_ok ? ox : 0)) * p.ld_dout + it_pi * p.gw + p.r + o0;   // float index of value 0
+    bmask = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) bmask |= (site_ok && o0 + e >= -p.r && o0 + e <= p.r) ? (1 << e) : 0;
+    // the four values are consecutive floats: one dword-aligned 16-byte load unless the run would start before / end after
+    // the tensor (first / last site only), masked afterwards
+    const bool inb = base >= 0 && (base + 4) * 4 <= (long)p.dout_total;
+    if (__all(bmask == 0 || inb)) {
+      const u32x4 v = buf_ld16(dout_rs_all, bmask ? (int)(base * 4) : OOB_MARK);
+#pragma unroll
+      for (int e = 0; e < 4; e++) breg[e] = __uint_as_float(v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const bool ok = (bmask >> e) & 1;
+        breg[e] = buf_ld1(dout_rs_all, ok ? (int)((base + e) * 4) : OOB_MARK, 0);
+      }
+    }
+  };
+  auto store_band_shared = [&]() {
+    if (it_role == 0) {
+      float4 v = make_float4((bmask & 1) ? breg[0] : 0.f, (bmask & 2) ? breg[1] : 0.f, (bmask & 4) ? breg[2] : 0.f,
+                             (bmask & 8) ? breg[3] : 0.f);
+      *reinterpret_cast<float4*>(band + sh_a * BAND_PITCH + sh_b) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) band[(sh_b + e) * BAND_PITCH + sh_a] = ((bmask >> e) & 1) ? breg[e] : 0.f;
+    }
+  };
   float av0[2][8], av1[2][8];
   bool have = next_item();
   if (have) {
     issue_tile();
-    load_band(av0);
+    if constexpr (SHARE) load_band_shared(); else load_band(av0);
   }
   int par = 0;
   while (have) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this item's tile (and band values) have landed
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SHARE) {
+      __builtin_amdgcn_s_barrier();                            // every wave has read the previous item's band
+      __builtin_amdgcn_sched_barrier(0);
+      store_band_shared();
+    }
     s16x8 bv[2][2][3];
 #pragma unroll
     for (int sl = 0; sl < 2; sl++)
@@ -736,17 +794,31 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: the tile may be overwritten
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SHARE) {
+      __builtin_amdgcn_s_barrier();                            // the item's band is complete in LDS
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        const float4 lo = *reinterpret_cast<const float4*>(band + l31 * BAND_PITCH + 16 * sl + 8 * h);
+        const float4 hi = *reinterpret_cast<const float4*>(band + l31 * BAND_PITCH + 16 * sl + 8 * h + 4);
+        av0[sl][0] = lo.x; av0[sl][1] = lo.y; av0[sl][2] = lo.z; av0[sl][3] = lo.w;
+        av0[sl][4] = hi.x; av0[sl][5] = hi.y; av0[sl][6] = hi.z; av0[sl][7] = hi.w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // request the next item (tile by DMA, band values by plain loads into the other register set)
     const bool more = next_item();
     if (more) {
       issue_tile();
-      if (par == 0) load_band(av1); else load_band(av0);
+      if constexpr (SHARE) load_band_shared();
+      else if (par == 0) load_band(av1); else load_band(av0);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sl = 0; sl < 2; sl++) {
       u32x4 ap[3];
-      if (par == 0) corr_split8(av0[sl], ap[0], ap[1], ap[2]); else corr_split8(av1[sl], ap[0], ap[1], ap[2]);
+      if (SHARE || par == 0) corr_split8(av0[sl], ap[0], ap[1], ap[2]); else corr_split8(av1[sl], ap[0], ap[1], ap[2]);
 #pragma unroll
       for (int tt = 0; tt < 6; tt++)
 #pragma unroll
@@ -870,12 +942,18 @@ int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const 
   { const int e = unflow::options().corr_bwd_rot; p.rot = e >= 0 ? (e != 0) : (p.joff != 0); }
   const size_t dbytes = (((size_t)B * g.oh * g.ow - 1) * (size_t)ld_dout + (size_t)g.gw * g.gw) * 4;
   p.dout_bytes = dbytes < ((size_t)1 << 30) && corr_bwd_b128_enabled() ? (unsigned)dbytes : 0u;
-  const int smem = 4 * 3 * 32 * 64 * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  (void)attr;
+  p.dout_total = dbytes;
+  const bool share = (C / 64) % 4 == 0 && dbytes < ((size_t)1 << 30) && unflow::options().corr_bwd_share;
+  const int smem = 4 * 3 * 32 * 64 * 2 + (share ? 32 * BAND_PITCH * 4 : 0);
+  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel<false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 32 * 64 * 2);
+  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel<true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      4 * 3 * 32 * 64 * 2 + 32 * BAND_PITCH * 4);
+  (void)attr0; (void)attr1;
   const long jobs = (long)(C / 64) * B * p.nA * g.s2 * H;
   dim3 grid((unsigned)((jobs + 3) / 4), fuse ? 1 : 2);
-  corr_bwd_pl_kernel<<<grid, 256, smem, st>>>(p);
+  if (share) corr_bwd_pl_kernel<true><<<grid, 256, smem, st>>>(p);
+  else corr_bwd_pl_kernel<false><<<grid, 256, smem, st>>>(p);
   return launch_status();
 }

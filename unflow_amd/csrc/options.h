@@ -24,7 +24,8 @@
   X(corr_wb, 1)           /* wide-band correlation forward kernel */                                                      \
   X(corr_bwd_b128, 1)     /* 16-byte band loads in the correlation backward */                                            \
   X(corr_bwd_rot, -1)     /* rotated displacement-row order in the correlation backward (-1: narrow band only) */         \
-  X(corr_bwd_planes, 1)   /* correlation backward from the feature planes */
+  X(corr_bwd_planes, 1)   /* correlation backward from the feature planes */                                              \
+  X(corr_bwd_share, 1)    /* ... with the band operand fetched once per workgroup (C a multiple of 256) */
 
 namespace unflow {
 struct Options {
