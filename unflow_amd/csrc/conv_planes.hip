@@ -1358,6 +1358,246 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
     }
 }
 
+// ------------------------------------------------------------------------------------------------ filter gradient, ping-pong form
+// The two waves a SIMD holds in the kernels above belong to different workgroups and meet at the matrix pipe by chance: both
+// in their MFMA phase (one waits) or both in their load phase (the pipe idles) — 60 % utilisation in the closed-queue model of
+// DESIGN.md §4.1d.  Here they belong to ONE workgroup of 8 waves (256 x 128 tile, wave tile 64 x 64 as before) and are
+// scheduled against each other: group 0 multiplies stage s while group 1 reads its fragments of stage s and issues the
+// LDS-DMA of stage s + 2, then they swap; one workgroup barrier per slot keeps the two groups one slot apart (the 8-phase
+// GEMM template of cdna_hip_programming.md §5, reduced to two phases).  Three stage buffers (3 x 36 KB): the DMA of stage
+// s + 2 overwrites stage s - 1, whose last reads retired two slots earlier.  One workgroup per CU.
+//   slot t (ends with a barrier):   group 0: A(t/2) on even t, B((t-1)/2) on odd t;   group 1: the same one slot later
+//   A(x): fragment reads of stage x -> registers; DMA of stage x+2; wait: reads retired, DMA of stage x+1 landed (vmcnt = own
+//         loads of stage x+2 still in flight)            B(x): 24 MFMAs at raised priority
+// BN = 128: wave tile 64 x 64 (4 x 2 waves); BN = 256: wave tile 128 x 64 (2 x 4 waves: 48 MFMAs against 36 fragment reads and
+// 6 loads per stage instead of 24 : 24 : 4.5)
+template <int BN>
+__global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgradParams p, int grp_mode) {
+  constexpr int BM = 256, WM = BN == 256 ? 128 : 64, WN = 64, NPL = 3, NT = 6, KS = 16;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_HALF = KS * 128;                                 // one 128-row half of an operand plane (tr_swz<128> image)
+  constexpr int A_PLANE = 2 * A_HALF, B_PLANE = KS * BN;           // elements
+  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  constexpr int NSTAGE = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 .. 7
+  // ping-pong group and the wave's index inside it; which waves share a SIMD is the hardware's choice: grp_mode picks the
+  // pairing (0: waves w and w + 4, 1: waves 2k and 2k + 1)
+  const int grp = grp_mode == 0 ? (wid >> 2) : (wid & 1);
+  const int idx = grp_mode == 0 ? (wid & 3) : (wid >> 1);
+  // wave tile: BN = 128: M quarter idx (64 rows), N half grp;  BN = 256: M half grp (128 rows), N quarter idx (64 columns)
+  const int wmq = BN == 256 ? 2 * grp : idx, wn = BN == 256 ? idx : grp;
+  const int taps = p.KH * p.KW;
+  const int Cag = p.Ca >> 3;
+  const int Mg = taps * Cag;
+  int v = xcd_remap(blockIdx.x, gridDim.x, p.xcd);
+  const int mtile = v % p.mt; v /= p.mt;
+  const int ntile = v % p.nt;
+  const int split = v / p.nt;
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int S = p.B * p.Hg * p.Wg;
+  const int KT = (S + KS - 1) / KS;
+  const int kt_per = (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;
+  const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
+  const int n = max(kt1 - kt0, 0);
+
+  u32x4 src_rs[NPL], dst_rs[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = raw_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
+    dst_rs[pl] = raw_rsrc(p.dst + pl * p.dst_ps, (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
+  }
+  // DMA roles (by wave id, independent of the groups): wave w loads site rows 4 (w & 3) .. + 3 of M half w >> 2 of the
+  // gathered operand; waves 0 .. 3 also load the dense operand's site rows 4 w .. + 3
+  const int dh = wid >> 2, dq = wid & 3;
+  const int a_k = 4 * dq + (lane >> 4);
+  const int a_slot = lane & 15;
+  const int a_g = ((((a_slot >> 1) ^ ((a_k & 3) << 1)) << 1) | (a_slot & 1));
+  const int mg = (m0 >> 3) + 16 * dh + a_g;
+  const bool m_ok = mg < Mg;
+  const unsigned tap = p.cag_magic ? fast_div((unsigned)mg, p.cag_magic) : (unsigned)mg;
+  const int ag = mg - (int)tap * Cag;
+  const int ky = (int)tap / p.KW, kx = (int)tap - ky * p.KW;
+  const int dy = p.dy0 + ky, dx = p.dx0 + kx + p.gpx * ag;
+  const int lds2 = p.lds * 2;
+  const int a_lane_off = (dy * p.Ws + (p.dx0 + kx)) * lds2 + ag * 16;
+  const int b_k = 4 * dq + (lane >> 4);
+  const int b_slot = lane & 15;
+  const int b_g = ((((b_slot >> 1) ^ ((b_k & 3) << 1)) << 1) | (b_slot & 1));
+  const int nbq = (n0 >> 3) + (BN == 256 ? 16 * dh : 0) + b_g;
+  const bool b_ok = nbq * 8 < p.Cb;
+  const int b_lane_off = nbq * 16;
+  const int ldd2 = p.ldd * 2;
+  const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
+  const unsigned lds0 = lds_addr(smem16);
+  auto a_voff = [&](int kt) {
+    const unsigned sidx = (unsigned)(kt * KS + a_k);
+    const unsigned q = fast_div(sidx, magW);
+    const int xg = (int)(sidx - q * (unsigned)p.Wg);
+    const unsigned bb = fast_div(q, magH);
+    const int yg = (int)(q - bb * (unsigned)p.Hg);
+    const int yb = yg * p.sm, xb = xg * p.sm;
+    const bool ok = m_ok && (int)bb < p.B && (unsigned)(yb + dy) < (unsigned)p.Hs && (unsigned)(xb + dx) < (unsigned)p.Ws;
+    return ok ? (((int)bb * p.Hs + yb) * p.Ws + xb) * lds2 + a_lane_off : OOB_MARK;
+  };
+  auto b_voff = [&](int kt) {
+    const int sidx = kt * KS + b_k;
+    return (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
+  };
+  auto issue = [&](int x) {                      // stage x of this block (kt0 + x) -> buffer x % 3; past the end: zeros
+    const int kt = x < n ? kt0 + x : KT + 1;
+    const unsigned st = lds0 + (unsigned)((x % NSTAGE) * STAGE * 2);
+    const unsigned da = st + (unsigned)((dh * A_HALF + 4 * dq * 128) * 2);
+    dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], da, da + A_PLANE * 2, da + 2 * A_PLANE * 2);
+    if (BN == 256 || wid < 4) {                  // (BN = 256: the dense operand is two 128-column halves like the gathered one)
+      const unsigned db = st + (unsigned)((NPL * A_PLANE + (BN == 256 ? dh * A_HALF : 0) + 4 * dq * 128) * 2);
+      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], db, db + B_PLANE * 2, db + 2 * B_PLANE * 2);
+    }
+  };
+  auto wait_older = [&]() {                      // everything but this wave's most recent issue() has landed
+    if (BN == 256 || wid < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int i16 = lane & 15, grp16 = lane >> 4, lh = grp16 >> 1;
+  const int krow = 8 * lh + (i16 >> 2);
+  int a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const int c = (BN == 256 ? 0 : (wmq & 1) * 64) + i * 32 + 16 * (grp16 & 1) + 4 * (i16 & 3);      // row inside the 128-row half
+    a_rd[i] = (wmq >> 1) * A_HALF + tr_swz<128>(krow, c >> 3) + (c & 7);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int c = (BN == 256 ? (wn & 1) : wn) * WN + j * 32 + 16 * (grp16 & 1) + 4 * (i16 & 3);     // column inside the 128-column half
+    b_rd[j] = NPL * A_PLANE + (BN == 256 ? (wn >> 1) * A_HALF : 0) + tr_swz<128>(krow, c >> 3) + (c & 7);
+  }
+
+  // fragments of ONE 64-row half of the wave tile at a time (BN = 256: the 128 x 64 wave tile is two such halves, which share
+  // the dense operand's fragments): a stage is HALVES x (read slot, multiply slot)
+  constexpr int HALVES = TM / 2;
+  s16x8 av[2][NPL], bv[TN][NPL];
+  auto read_frags = [&](int x, int half) {
+    const unsigned short* st = smem16 + (x % NSTAGE) * STAGE;
+    auto read_a = [&](int pl) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const unsigned short* b0 = st + pl * A_PLANE + a_rd[2 * half + i];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * 128));
+        av[i][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    auto read_b = [&](int pl) {
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const unsigned short* b0 = st + pl * B_PLANE + b_rd[j];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(b0 + 4 * 128));
+        bv[j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    if (half == 0) { read_a(2); read_b(0); read_a(0); read_b(2); read_a(1); read_b(1); }
+    else { read_a(2); read_a(0); read_a(1); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the loads of stage x + 2, spread over the read slots of stage x: the gathered operand in the first, the dense one in the
+  // last (one slot: both)
+  auto issue_part = [&](int x, int part) {
+    const int kt = x < n ? kt0 + x : KT + 1;
+    const unsigned st = lds0 + (unsigned)((x % NSTAGE) * STAGE * 2);
+    if (part == 0 || HALVES == 1) {
+      const unsigned da = st + (unsigned)((dh * A_HALF + 4 * dq * 128) * 2);
+      dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], da, da + A_PLANE * 2, da + 2 * A_PLANE * 2);
+    }
+    if ((part == HALVES - 1) && (BN == 256 || wid < 4)) {
+      const unsigned db = st + (unsigned)((NPL * A_PLANE + (BN == 256 ? dh * A_HALF : 0) + 4 * dq * 128) * 2);
+      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], db, db + B_PLANE * 2, db + 2 * B_PLANE * 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto multiply = [&](int half) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          if (half == 0) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+          else mfma_terms<NPL, false>(av[i], bv[j], acc[(TM > 2 ? 2 : 0) + i][j], t);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (n > 0) {
+    issue(0);
+    issue(1);
+    wait_older();                                // stage 0 landed (stage 1 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // group 1 runs the same slot sequence one barrier later (and group 0 takes the last barrier alone)
+    auto slot_end = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (grp == 1) slot_end();
+#pragma unroll 1
+    for (int x = 0; x < n; x++) {
+      // (the fragment reads are NOT waited for before the slot's barrier: they return while the other group starts its
+      // read slot; the MFMAs wait for them by register dependence.  Their buffer is restaged three stages later.)
+      read_frags(x, 0);
+      issue_part(x + 2, 0);
+      if (HALVES == 1) wait_older();
+      slot_end();
+      multiply(0);
+      slot_end();
+      if (HALVES == 2) {
+        read_frags(x, 1);
+        issue_part(x + 2, 1);
+        wait_older();
+        slot_end();
+        multiply(1);
+        slot_end();
+      }
+    }
+    if (grp == 0) slot_end();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-fill loads past the last stage
+  }
+
+  float* o = p.nsplit > 1 ? p.partial + (size_t)split * taps * p.Ca_out * p.Cb : p.out;
+  const int lh5 = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wmq * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh5;
+      const int mgr = m >> 3;
+      if (mgr >= Mg) continue;
+      const unsigned tp = p.cag_magic ? fast_div((unsigned)mgr, p.cag_magic) : (unsigned)mgr;
+      const int a = (mgr - (int)tp * Cag) * 8 + (m & 7);
+      if (a >= p.Ca_out) continue;
+      float* orow = o + ((size_t)tp * p.Ca_out + a) * p.Cb;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int nn = n0 + wn * WN + j * 32 + l31;
+        if (nn < p.Cb) orow[nn] = acc[i][j][r] * p.out_scale;
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ plane producers
 // fp32 [npix][ldx] (C channels used) -> planes [npix][ldp] with channels C .. Cp-1 zero-filled (Cp a multiple of 4, >= C)
 __global__ void planes_from_f32_kernel(const float* __restrict__ x, int ldx, long npix, int C, int Cp, PlaneOut o) {
@@ -1689,8 +1929,28 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
 
 inline int pl_wgrad_cfg(const WgradGeom& p) { return p.Cb <= 64 ? 1 : 0; }   // 0: 128x128, 1: 128x64
 
+// ping-pong form (igemm_pl_wgrad_pp_kernel): bf16 x 3 planes, N > 64, at least one full 256-row tile
+// Measured per layer (FlowNetC 384 x 512, B = 4, profiles/r03_wgrad_pingpong_per_layer.txt): wins where a workgroup runs many
+// stages and N > 128 (conv3_1 260 -> 238 us, the 1028 -> 256 deconv 109 -> 94); loses on the 6 x 8 / 12 x 16 layers (a
+// split leaves 1-3 stages per workgroup: nothing to pipeline) and is neutral-to-worse with the 64 x 64 wave tile (N <= 128).
+// Option wgrad_pp: 0 off, 1 on by this rule, 3 everywhere it can run (tests), 2 / 4 the same with waves 2k / 2k+1 paired.
+inline bool pl_wgrad_pp_ok(const WgradGeom& p, int npl) {
+  const int o = unflow::options().wgrad_pp;
+  if (o <= 0 || npl != 3 || p.Cb <= 64 || p.KH * p.KW * p.Ca < 256) return false;
+  if (o >= 3) return true;
+  return p.Cb > 128 && (long)p.B * p.Hg * p.Wg >= 6144;
+}
+inline int pl_wgrad_pp_bn(const WgradGeom& p) { return p.Cb > 128 ? 256 : 128; }
+
 inline int plan_pl_wgrad(const WgradGeom& p, int npl) {
   const int Mp = p.KH * p.KW * p.Ca;
+  if (pl_wgrad_pp_ok(p, npl)) {
+    const long blocks = (long)cdiv(Mp, 256) * cdiv(p.Cb, pl_wgrad_pp_bn(p));
+    const long S = (long)p.B * p.Hg * p.Wg;
+    const int KT = (int)((S + BK - 1) / BK);
+    const int min_kt = max(1, unflow::options().wgrad_min_kt);
+    return fill_one_round(blocks, 256, min(256, KT / min_kt > 0 ? KT / min_kt : 1));      // one workgroup per CU
+  }
   const int cfg = pl_wgrad_cfg(p);
   const int bn = cfg == 1 ? 64 : 128;
   const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
@@ -1738,6 +1998,19 @@ int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
   return launch_status();
 }
 
+template <int BN>
+int launch_pl_wgrad_pp(const PlWgradParams& p, hipStream_t st) {
+  const int Mp = p.KH * p.KW * p.Ca;
+  const int smem = 3 * 3 * (256 + BN) * 16 * 2;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_pp_kernel<BN>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)attr;
+  PlWgradParams q = p;
+  q.mt = cdiv(Mp, 256); q.nt = cdiv(p.Cb, BN);
+  igemm_pl_wgrad_pp_kernel<BN><<<q.mt * q.nt * p.nsplit, 512, smem, st>>>(q, (unflow::options().wgrad_pp & 1) ? 0 : 1);
+  return launch_status();
+}
+
 int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* used, hipStream_t st) {
   const unflow::Options& opt = unflow::options();
   if (p.out_scale == 0.f) p.out_scale = 1.f;
@@ -1754,7 +2027,8 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
   *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
   const int cfg = pl_wgrad_cfg(p);
   int code;
-  if (npl == 3 && opt.wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32>(p, st) : launch_pl_wgrad_dma<128, 64>(p, st);
+  if (pl_wgrad_pp_ok(p, npl)) code = pl_wgrad_pp_bn(p) == 256 ? launch_pl_wgrad_pp<256>(p, st) : launch_pl_wgrad_pp<128>(p, st);
+  else if (npl == 3 && opt.wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32>(p, st) : launch_pl_wgrad_dma<128, 64>(p, st);
   else if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
   if (code != UNFLOW_OK) return code;

@@ -20,6 +20,7 @@
   X(xcd_order, -1)        /* force work_decode order 0 / 1 / 2 (-1: per-kernel default) */                                \
   X(fused_splitk, 0)      /* n > 0: in-kernel split-K reduction for tiles with up to n slices */                          \
   X(wgrad_dma, 1)         /* LDS-DMA filter-gradient kernel (0: register-staged) */                                       \
+  X(wgrad_pp, 1)          /* ping-pong filter-gradient kernel (8 waves): 1 where it pays, 3 wherever eligible, 0 off */                                           \
   X(corr_nb, 1)           /* narrow-band correlation forward kernel */                                                    \
   X(corr_wb, 1)           /* wide-band correlation forward kernel */                                                      \
   X(corr_bwd_b128, 1)     /* 16-byte band loads in the correlation backward */                                            \
