@@ -85,8 +85,12 @@ def main():
         return
     trace("halo kernel, conv3_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),
           ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
-    trace("LDS-DMA filter gradient, conv3_1 (24 MFMAs per wave and stage):", lambda: L.conv_bwd_filter(X, DZ, dw, 1),
-          ["issue dma", "24 mfma (+ read wait)", "wait dma", "barrier", "issue reads", "loop tail"])
+    if _lib.get_option("wgrad_pp") > 0:
+        trace("ping-pong filter gradient, conv3_1 (2 x 24 MFMAs per wave and stage):", lambda: L.conv_bwd_filter(X, DZ, dw, 1),
+              ["read slot 0", "barrier", "24 mfma", "barrier", "read slot 1 + barrier", "24 mfma + barrier"])
+    else:
+        trace("LDS-DMA filter gradient, conv3_1 (24 MFMAs per wave and stage):", lambda: L.conv_bwd_filter(X, DZ, dw, 1),
+              ["issue dma", "24 mfma (+ read wait)", "wait dma", "barrier", "issue reads", "loop tail"])
 
 
 if __name__ == "__main__":

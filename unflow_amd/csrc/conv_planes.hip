@@ -577,6 +577,226 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ gather kernel, ping-pong form
+// Two 4-wave INSTANCES of the 128 x 128 gather tile in one workgroup of 8 waves (neighbouring M tiles, the same N tile /
+// class / K split, so both walk the same K tiles and share the weight tile), scheduled against each other like the
+// filter-gradient kernel above: while instance 0 runs the 48 MFMAs of K tile t, instance 1 reads ITS fragments of tile t
+// from LDS into registers, stores tile t + 1 (global loads issued one slot pair earlier) and issues the loads of tile
+// t + 2; then they swap.  One workgroup barrier per slot.  A tiles are private and double-buffered, the weight tile is shared
+// and double-buffered (each instance stores half of it; the other half arrives one slot later, a full slot before its first
+// reader).  LDS rows are unpadded (64 B) with the XOR swizzle alone: 6 x 24.6 KB = 147 KB, one workgroup per CU.
+template <int NPL, bool F16>
+__global__ __launch_bounds__(512, 1) void igemm_pl_gather_pp_kernel(const PlGatherParams p) {
+  constexpr int BM = 128, BN = 128, WM = 64, WN = 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDP = 32;                        // row pitch (elements): no padding
+  constexpr int A_PLANE = BM * LDP, B_PLANE = BN * LDP;
+  constexpr int A_TILE = NPL * A_PLANE, B_TILE = NPL * B_PLANE;
+  constexpr int AR = BM / 64;
+  constexpr int NT = NPL == 3 ? 6 : 1;
+  static_assert(NPL == 3 && !F16, "bf16 x 3 only");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  const int inst = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+  unsigned short* Abase = smem16 + inst * 2 * A_TILE;          // [buffer][plane][row][32]
+  unsigned short* Bbase = smem16 + 4 * A_TILE;                 // [buffer][plane][row][32], shared
+  int* pix = reinterpret_cast<int*>(smem16 + 4 * A_TILE + 2 * B_TILE) + inst * BM;
+
+  const int wm = wid >> 1, wn = wid & 1;
+  int mpair, ntile, cls_id, split;
+  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, mpair, ntile, cls_id, split);
+  if (mpair < 0) return;                         // (padding workgroup of order 2: both instances leave)
+  const int mtile = 2 * mpair + inst;
+  const TapClass tc = p.cls[cls_id];
+  const int M = p.B * p.Hg * p.Wg;
+  const int mt_real = p.tw_log ? p.B * p.tiles_y * p.tiles_x : (M + BM - 1) / BM;
+  const bool tile_ok = mtile < mt_real;          // an odd tile count leaves the last instance without a tile: it runs on zeros
+  const int m0 = mtile * BM, n0 = ntile * BN;
+  const int ntaps = tc.nty * tc.ntx;
+  const int Cg = p.Cs >> 3;
+  const int Kg = ntaps * Cg;
+  const int KT = (Kg + 3) >> 2;
+  const int kt_per = (KT + p.nsplit - 1) / p.nsplit;
+  const int kt0 = split * kt_per;
+  const int kt1 = min(KT, kt0 + kt_per);
+  const int T = max(kt1 - kt0, 0);
+
+  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Cs)) * 2);
+    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
+  }
+  const int kq = tid & 3;
+  const int lds2 = p.lds * 2;
+  auto site_of = [&](int r, int& b, int& yg, int& xg) -> bool {
+    if (!tile_ok) return false;
+    if (p.tw_log) {
+      int t = mtile;
+      const int txi = t % p.tiles_x; t /= p.tiles_x;
+      const int tyi = t % p.tiles_y;
+      b = t / p.tiles_y;
+      yg = tyi * (BM >> p.tw_log) + (r >> p.tw_log);
+      xg = (txi << p.tw_log) + (r & ((1 << p.tw_log) - 1));
+      return true;
+    }
+    const int m = m0 + r;
+    xg = m % p.Wg;
+    const int t = m / p.Wg;
+    yg = t % p.Hg;
+    b = t / p.Hg;
+    return m < M;
+  };
+  int a_yx[AR], a_lin[AR];
+#pragma unroll
+  for (int i = 0; i < AR; i++) {
+    int b, yg, xg;
+    if (site_of((tid >> 2) + 64 * i, b, yg, xg)) {
+      const int y = yg * p.sm, x = xg * p.sm;
+      a_yx[i] = (y << 16) | x;
+      a_lin[i] = (b * p.Hs * p.Ws + y * p.Ws + x) * lds2;
+    } else {
+      a_yx[i] = 0;
+      a_lin[i] = OOB_MARK;
+    }
+  }
+  if (tid < BM) {
+    int b, yg, xg, v = -1;
+    if (site_of(tid, b, yg, xg)) v = (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px;
+    pix[tid] = v;
+  }
+  // this instance's half of the weight tile: rows 64 inst + tid / 4
+  const int b_r = 64 * inst + (tid >> 2);
+  const int b_row = n0 + b_r < p.N ? (n0 + b_r) * p.Cs * 2 : OOB_MARK;
+
+  const int adv_t = 4 / Cg, adv_c = 4 - adv_t * Cg;
+  const unsigned ntx_magic = (65536u + (unsigned)tc.ntx - 1u) / (unsigned)tc.ntx;
+  int q_tap, q_cg;
+  {
+    const unsigned q = (unsigned)kt0 * 4u + (unsigned)kq;
+    q_tap = (int)(q / (unsigned)Cg);
+    q_cg = (int)(q - (unsigned)q_tap * (unsigned)Cg);
+  }
+  u32x4 ra[AR][NPL], rb[NPL];
+  // loads of the next not-yet-requested K tile (the walker advances by one tile per call); past the block's range: zeros
+  int ld_left = T;
+  auto load_tile = [&]() {
+    const int ty = (int)(((unsigned)q_tap * ntx_magic) >> 16), tx = q_tap - ty * tc.ntx;
+    const bool kvalid = ld_left > 0 && q_tap < ntaps;
+    const int dy = tc.dy0 + ty * p.dstep;
+    const int dx = tc.dx0 + tx * p.dstep + p.gpx * q_cg;
+    const int cofs = q_cg * 16;
+    const int a_tile = kvalid ? (dy * p.Ws + dx) * lds2 + (p.gpx ? 0 : cofs) : OOB_MARK;
+    const int widx = (tc.ky0 + ty * p.kstep) * p.KW + tc.kx0 + tx * p.kstep;
+    const int w_tile = kvalid ? widx * p.N * p.Cs * 2 + cofs : OOB_MARK;
+#pragma unroll
+    for (int i = 0; i < AR; i++) {
+      const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
+      const bool inb = (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+      const int voff = inb ? a_lin[i] + a_tile : OOB_MARK;
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) ra[i][pl] = buf_ld16(src_rs[pl], voff);
+    }
+    {
+      const int voff = b_row + w_tile;
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) rb[pl] = buf_ld16(w_rs[pl], voff);
+    }
+    q_cg += adv_c;
+    q_tap += adv_t;
+    const bool wrap = q_cg >= Cg;
+    q_cg -= wrap ? Cg : 0;
+    q_tap += wrap ? 1 : 0;
+    ld_left--;
+  };
+  auto swz = [](int row, int g) { return row * LDP + 8 * (g ^ ((row >> 2) & 3)); };
+  auto store_tile = [&](int buf) {
+    unsigned short* Ah = Abase + buf * A_TILE;
+    unsigned short* Bh = Bbase + buf * B_TILE;
+#pragma unroll
+    for (int i = 0; i < AR; i++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++)
+        *reinterpret_cast<u32x4*>(Ah + pl * A_PLANE + swz((tid >> 2) + 64 * i, kq)) = ra[i][pl];
+#pragma unroll
+    for (int pl = 0; pl < NPL; pl++) *reinterpret_cast<u32x4*>(Bh + pl * B_PLANE + swz(b_r, kq)) = rb[pl];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int gsw = lh ^ ((l31 >> 2) & 3);
+  const int a_rd = (wm * WM + l31) * LDP, b_rd = (wn * WN + l31) * LDP;
+  s16x8 av[2][TM][NPL], bv[2][TN][NPL];
+  auto read_frags = [&](int buf) {
+    const unsigned short* Ah = Abase + buf * A_TILE + a_rd;
+    const unsigned short* Bh = Bbase + buf * B_TILE + b_rd;
+#pragma unroll
+    for (int slab = 0; slab < 2; slab++)
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          bv[slab][j][pl] = *reinterpret_cast<const s16x8*>(Bh + pl * B_PLANE + j * 32 * LDP + 8 * (gsw ^ (2 * slab)));
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+          av[slab][i][pl] = *reinterpret_cast<const s16x8*>(Ah + pl * A_PLANE + i * 32 * LDP + 8 * (gsw ^ (2 * slab)));
+      }
+  };
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (T > 0) {
+    load_tile();                                 // tile 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_tile(0);
+    load_tile();                                 // tile 1 (in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot_end();                                  // both halves of weight tile 0 are stored
+    if (inst == 1) slot_end();
+#pragma unroll 1
+    for (int t = 0; t < T; t++) {
+      // read slot: fragments of tile t -> registers; tile t + 1 (loads requested one slot pair ago) -> LDS; request tile t + 2
+      read_frags(t & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_tile((t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // stores done (visible after the barrier), fragments in registers
+      slot_end();
+      // multiply slot
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int slab = 0; slab < 2; slab++)
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++)
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[slab][i], bv[slab][j], acc[i][j], tt);
+      __builtin_amdgcn_s_setprio(0);
+      slot_end();
+    }
+    if (inst == 0) slot_end();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero loads past the last tile
+  }
+  __syncthreads();                               // every wave is done with the tiles: the epilogue stages through them
+  if (!tile_ok) return;
+  pl_gather_epilogue<WM, WN>(p, acc, pix, smem16 + inst * 2 * A_TILE, wm, wn, wid, lane, n0, split);
+}
+
 // ------------------------------------------------------------------------------------------------ halo gather kernel
 // Source stride 1 (3x3 / 1x1 stride-1 convs, every conv data gradient incl. the 4 parity classes of stride 2, conv_transpose
 // forward): the taps of a site are its neighbours, so a spatially compact tile re-reads almost the same pixels for every
@@ -1554,25 +1774,33 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
       __builtin_amdgcn_sched_barrier(0);
     };
     if (grp == 1) slot_end();
+    PHASE_DECL;
 #pragma unroll 1
     for (int x = 0; x < n; x++) {
+      PHASE_STAMP(6);
       // (the fragment reads are NOT waited for before the slot's barrier: they return while the other group starts its
       // read slot; the MFMAs wait for them by register dependence.  Their buffer is restaged three stages later.)
       read_frags(x, 0);
       issue_part(x + 2, 0);
       if (HALVES == 1) wait_older();
+      PHASE_STAMP(0);    // read slot 0: fragment reads + loads issued
       slot_end();
+      PHASE_STAMP(1);    // its barrier
       multiply(0);
+      PHASE_STAMP(2);    // 24 MFMAs issued
       slot_end();
+      PHASE_STAMP(3);    // its barrier
       if (HALVES == 2) {
         read_frags(x, 1);
         issue_part(x + 2, 1);
         wait_older();
         slot_end();
+        PHASE_STAMP(4);  // read slot 1 + barrier
         multiply(1);
         slot_end();
       }
     }
+    PHASE_FLUSH;
     if (grp == 0) slot_end();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-fill loads past the last stage
   }
@@ -1704,6 +1932,7 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b)
 struct PlPlan {
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
   int nsplit;
+  bool pp = false;   // ping-pong form (pairs of 128 x 128 tiles)
 };
 
 inline int pl_smem_gather(int bm, int bn, int npl) { return pl_gather_main_bytes(bm, bn, bm == bn ? bm / 2 : 32, npl) + bm * 4 + 16; }   // + the pixel table + the split-K flag
@@ -1713,6 +1942,11 @@ inline int pl_blocks_per_cu(int bm, int bn, int npl) {
   const int byl = (160 * 1024) / pl_smem_gather(bm, bn, npl);
   const int byr = bm == 128 && bn == 128 ? 3 : bm == 128 ? 4 : 6;
   return byl < byr ? byl : byr;
+}
+
+// ping-pong gather form (igemm_pl_gather_pp_kernel): bf16 x 3, 128 x 128 tiles in pairs
+inline bool pl_gather_pp_ok(const GatherGeom& p, int npl, int cfg) {
+  return unflow::options().gather_pp > 0 && npl == 3 && cfg == 0;
 }
 
 inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
@@ -1738,6 +1972,18 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   const int slots = 256 * pl_blocks_per_cu(bm, bn, npl);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
   pl.nsplit = fill_one_round(blocks, slots, max_by_k);
+  if (pl_gather_pp_ok(p, npl, pl.cfg)) {
+    // one 8-wave workgroup per CU: 256 slots.  Taken where the launch fills them (measured per layer, profiles/
+    // r03_gather_pingpong_per_layer.txt: the even-class deconv layers and the deep stride-1 layers gain 5-16 %; conv4's forward at
+    // 75 % fill and the uneven parity classes of the stride-2 data gradients lose) — option gather_pp = 2 forces it (tests)
+    const long pairs = (((M + 127) / 128 + 1) / 2) * ((p.N + 127) / 128) * p.ncls;
+    const int ns = (int)max(1L, min((long)max_by_k, 256 / max(pairs, 1L)));      // ONE round of workgroups
+    const long b = pairs * ns;
+    const double fill = (double)b / (double)(((b + 255) / 256) * 256);
+    bool even = true;
+    for (int c = 1; c < p.ncls; c++) even = even && p.cls[c].nty * p.cls[c].ntx == p.cls[0].nty * p.cls[0].ntx;
+    if (unflow::options().gather_pp >= 2 || (fill >= 0.85 && even)) { pl.pp = true; pl.nsplit = ns; }
+  }
   return pl;
 }
 
@@ -1793,6 +2039,23 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   const int grid = pl_grid(q);
   if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
   igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q);
+  return launch_status();
+}
+
+// ping-pong form: pairs of 128-site tiles per workgroup
+int launch_pl_gather_pp(const PlGatherParams& p, hipStream_t st) {
+  const int M = p.B * p.Hg * p.Wg;
+  constexpr int smem = 6 * 3 * 128 * 32 * 2 + 2 * 128 * 4;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_pp_kernel<3, false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  (void)attr;
+  PlGatherParams q = p;
+  q.mt = cdiv(M, 128); q.nt = cdiv(p.N, 128);
+  pl_gather_tiles2d<128>(q);
+  if (q.tw_log) q.mt = q.B * q.tiles_y * q.tiles_x;
+  q.mt = cdiv(q.mt, 2);                          // M tile PAIRS in the work order
+  const int grid = pl_grid(q);
+  igemm_pl_gather_pp_kernel<3, false><<<grid, 512, smem, st>>>(q);
   return launch_status();
 }
 
@@ -1908,7 +2171,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     // 0.69 ms of the step (no-reduce ablation): what they cost is the second pass over the partials, which
     // one block per tile does no faster than 256 CUs.  Kept as a tested alternative.
     const int fused = opt.fused_splitk;
-    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu;
+    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu && !(pl.pp && !halo);
     p.counters = p.fused_splitk ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pl_gather_slab_bytes(p, p.nsplit)) : nullptr;
   }
   int code;
@@ -1916,7 +2179,7 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
     else code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
   } else {
-    code = npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
+    code = pl.pp ? launch_pl_gather_pp(p, st) : npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   }
   if (code != UNFLOW_OK) return code;
   if (p.nsplit > 1 && !p.fused_splitk) {

@@ -12,6 +12,7 @@
   X(gather_min_kt, 8)     /* split-K of the gather kernels: at least this many K32 tiles per split */                     \
   X(gather_max_split, 16) /* ... and at most this many splits */                                                          \
   X(wgrad_min_kt, 8)      /* split-K of the filter gradients: at least this many 32-site tiles per split */               \
+  X(gather_pp, 1)         /* ping-pong gather kernel (two 128 x 128 tiles per 8-wave workgroup): 1 where it pays, 2 wherever eligible */ \
   X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
   X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \
   X(halo_s2, 1)           /* halo kernel also for source-stride-2 layers (four accumulating parity classes) */            \
