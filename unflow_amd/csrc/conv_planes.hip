@@ -2015,11 +2015,14 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
 #pragma unroll 1
     for (int x = 0; x < n; x++) {
       PHASE_STAMP(6);
-      // (the fragment reads are NOT waited for before the slot's barrier: they return while the other group starts its
-      // read slot; the MFMAs wait for them by register dependence.  Their buffer is restaged three stages later.)
+      // (the fragment reads of the FIRST read slot are not waited for before its barrier: they return while the other group
+      // starts its read slot; the MFMAs wait for them by register dependence)
       read_frags(x, 0);
       issue_part(x + 2, 0);
-      if (HALVES == 1) wait_older();
+      if (HALVES == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (last reads of the stage: see below)
+        wait_older();
+      }
       PHASE_STAMP(0);    // read slot 0: fragment reads + loads issued
       slot_end();
       PHASE_STAMP(1);    // its barrier
@@ -2030,6 +2033,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
       if (HALVES == 2) {
         read_frags(x, 1);
         issue_part(x + 2, 1);
+        // the LAST reads of stage x retire before the barrier: the other group restages this buffer (stage x + 3) in its very
+        // next slot, and an LDS-DMA write is ordered against a ds_read only through lgkmcnt + barrier (cdna_hip_programming.md §5)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_older();
         slot_end();
         PHASE_STAMP(4);  // read slot 1 + barrier
