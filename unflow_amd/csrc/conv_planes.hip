@@ -1343,7 +1343,7 @@ __global__ void pl_splitk_reduce_epilogue_kernel(const PlGatherParams p, int vec
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
       for (int s = 0; s < p.nsplit; s++) {
-        const float4 t = src[(size_t)s * totq];
+        const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(src) + (size_t)s * totq);   // read once
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }
       epi_store4(p, px, n, v);
@@ -2124,9 +2124,10 @@ __device__ __forceinline__ void put_planes8(unsigned short* base, long ps, int n
     const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
     h[i] = hh; m[i] = mm; l[i] = cvt_pk_bf16(sa, sb);
   }
-  *reinterpret_cast<u32x4*>(base + idx) = h;
-  *reinterpret_cast<u32x4*>(base + idx + ps) = m;
-  *reinterpret_cast<u32x4*>(base + idx + 2 * ps) = l;
+  // (streamed once per step, read by the conv kernels much later: non-temporal)
+  __builtin_nontemporal_store(h, reinterpret_cast<u32x4*>(base + idx));
+  __builtin_nontemporal_store(m, reinterpret_cast<u32x4*>(base + idx + ps));
+  __builtin_nontemporal_store(l, reinterpret_cast<u32x4*>(base + idx + 2 * ps));
 }
 
 __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b) {

@@ -373,6 +373,7 @@ static __global__ void sum_partials_kernel(const float* __restrict__ partial, fl
   }
 }
 
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 // float4 variant (n % 4 == 0): same fixed order per element, a quarter of the threads, 8 loads in flight.
 static __global__ void sum_partials4_kernel(const float4* __restrict__ partial, float4* __restrict__ out, size_t nq, int S,
                                             int fan) {
@@ -384,10 +385,12 @@ static __global__ void sum_partials4_kernel(const float4* __restrict__ partial, 
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
     for (int k = (int)g * fan; k < k1; k++) {
-      const float4 a = partial[(size_t)k * nq + e];
+      // partials are read once, the sums go to Adam a whole backward pass later: non-temporal both ways
+      const f32x4_nt a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(partial) + (size_t)k * nq + e);
       v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
-    out[g * nq + e] = v;
+    f32x4_nt o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+    __builtin_nontemporal_store(o, reinterpret_cast<f32x4_nt*>(out) + g * nq + e);
   }
 }
 
