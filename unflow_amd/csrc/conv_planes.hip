@@ -2111,7 +2111,7 @@ __device__ __forceinline__ void put_planes8(unsigned short* base, long ps, int n
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; i++) o[i] = (unsigned)to_f16_bits(v[2 * i]) | ((unsigned)to_f16_bits(v[2 * i + 1]) << 16);
-    *reinterpret_cast<u32x4*>(base + idx) = o;
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(base + idx));
     return;
   }
   u32x4 h, m, l;
