@@ -135,7 +135,7 @@ def main():
                for _ in range(NBATCH)]
     lr = 1e-4
     parity = None
-    if rank == 0 and world == 1 and args.flownet == 'C' and not args.no_parity:
+    if rank == 0 and world == 1 and not args.no_parity:
         parity = measure_parity(eng, batches[0])      # step-1 loss and flows vs the CPU oracle, BEFORE any timing
     step_no = [0]
     # forward + loss + backward as hipGraph replays; with more than one rank the backward pass is cut into parts, and each
@@ -384,7 +384,7 @@ def measure_secondary(args):
     no CPU baseline / fp32 re-measurement / sustained pass), reduced to the fields a reader needs."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-            "--no-cpu-baseline", "--no-alt", "--no-parity", "--no-secondary", "--sustain-seconds", "0"]
+            "--no-cpu-baseline", "--no-alt", "--no-secondary", "--sustain-seconds", "0"]
     cfgs = [("FlowNetCSS 768x1024 B=2 (BASELINE configs[3]; last network trained, the two in front frozen)",
              ["--flownet", "CSS", "--batch", "2", "--height", "768", "--width", "1024"], None),
             ("FlowNetC f16 B=8 384x512 (BASELINE configs[4])", ["--dtype", "f16", "--batch", "8"],
@@ -401,6 +401,8 @@ def measure_secondary(args):
                                                      "ms_per_step_in_kernel_class")}}
             if tol:
                 e["tolerance"] = tol
+            if "parity" in d:
+                e["parity"] = d["parity"]
             out.append(e)
         except Exception as ex:
             out.append({"config": name, "value": None, "error": repr(ex)[:300]})

@@ -152,3 +152,32 @@ def test_resize_area_integer_and_fractional():
     # 5 -> 2 along one axis: windows [0, 2.5) and [2.5, 5) with the middle pixel split in half
     z = resize_area(torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]).view(1, 1, 5, 1), torch.empty(1, 1, 2, 1))
     assert torch.allclose(z.flatten(), torch.tensor([(1 + 2 + 1.5) / 2.5, (1.5 + 4 + 5) / 2.5]))
+
+
+def test_read_png_image_grey_alpha_and_16_bit(tmp_path):
+    """tf.image.decode_png(channels=3) (input.py:208-218) replicates grey to RGB, drops alpha, and returns uint8 also for a
+    16-bit file (the high byte)."""
+    import struct
+    import zlib
+    from unflow_amd.core.input import read_png_image
+
+    def png(arr, ctype, depth):
+        h, w = arr.shape[:2]
+        a = arr.astype('>u2' if depth == 16 else np.uint8).reshape(h, -1)
+        raw = b''.join(b'\x00' + a[y].tobytes() for y in range(h))
+
+        def chunk(t, b):
+            return struct.pack('>I', len(b)) + t + b + struct.pack('>I', zlib.crc32(t + b) & 0xffffffff)
+        return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, depth, ctype, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(raw)) + chunk(b'IEND', b''))
+    rs = np.random.RandomState(3)
+    g8 = rs.randint(0, 256, size=(5, 7, 1))
+    ga8 = rs.randint(0, 256, size=(5, 7, 2))
+    rgb16 = rs.randint(0, 65536, size=(5, 7, 3))
+    g16 = rs.randint(0, 65536, size=(5, 7, 1))
+    for name, arr, ctype, depth, want in (("g8", g8, 0, 8, np.repeat(g8, 3, 2)), ("ga8", ga8, 4, 8, np.repeat(ga8[:, :, :1], 3, 2)),
+                                          ("rgb16", rgb16, 2, 16, rgb16 >> 8), ("g16", g16, 0, 16, np.repeat(g16 >> 8, 3, 2))):
+        p = tmp_path / (name + ".png")
+        p.write_bytes(png(arr, ctype, depth))
+        got = read_png_image(str(p))
+        assert got.dtype == np.float32 and got.shape == (5, 7, 3) and np.array_equal(got, want.astype(np.float32)), name

@@ -208,8 +208,8 @@ def test_trainer_run_resume_and_save_arithmetic(tmp_path):
             self.saved.append(global_step)
             T.write_checkpoint(os.path.join(ckpt_dir, 'model.ckpt-%d' % global_step), {"w": np.zeros(1, np.float32)})
 
-        def restore(self, ckpt_dir):
-            return T.latest_checkpoint(ckpt_dir)
+        def restore(self, ckpt_dir=None):       # (run() calls restore(None) on a fresh start: params['finetune'] only)
+            return T.latest_checkpoint(ckpt_dir) if ckpt_dir else None
 
     def batches(iter_offset):
         k = iter_offset

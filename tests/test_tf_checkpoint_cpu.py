@@ -153,3 +153,60 @@ def test_full_width_names_equal_the_reference_scopes():
     assert tuple(p["flownet_c/deconv5/weights"].shape) == (4, 4, 512, 1024)              # conv2d_transpose: [k, k, out, in]
     assert tuple(p["stack_1_flownet/flownet_s/conv1/weights"].shape) == (7, 7, 14, 64)
     assert tuple(p["stack_1_flownet/flownet_s/flow2/biases"].shape) == (2,)
+
+
+# ---- bytes this repo's writer never touched: tests/golden/ckpt_golden/ is assembled from the LevelDB table + tensor_bundle.proto
+# specifications by tests/golden/make_ckpt_golden_independent.py, which does not import unflow_amd (own varint / protobuf / block
+# builder, a bit-serial CRC-32C) and follows TensorFlow's writer settings (restart interval 16 / 1, last-key index entries)
+GOLD = os.path.join(HERE, "golden", "ckpt_golden")
+
+
+def test_reader_against_independently_assembled_bundle():
+    import make_ckpt_golden_independent as G
+    src = open(os.path.join(HERE, "golden", "make_ckpt_golden_independent.py")).read()
+    assert "import unflow" not in src and "from unflow" not in src and "import tf_checkpoint" not in src
+    table, data = G.build()                                           # the committed bytes are what the script builds
+    assert open(os.path.join(GOLD, G.STEM + ".index"), "rb").read() == table
+    assert open(os.path.join(GOLD, G.STEM + ".data-00000-of-00001"), "rb").read() == data
+    prefix = T.latest_checkpoint(GOLD)
+    assert os.path.basename(prefix) == G.STEM
+    assert T.all_checkpoint_paths(GOLD) == ["model.ckpt-400", "model.ckpt-800", G.STEM]
+    header, entries = T.checkpoint_entries(prefix)
+    assert header["num_shards"] == 1
+    assert list(entries) == sorted(G.TENSORS, key=lambda s: s.encode())
+    got = T.read_checkpoint(prefix, verify_data=True)                 # checks every block CRC and every tensor CRC
+    for name, (dtype, shape) in G.TENSORS.items():
+        want = G.value_of(name, dtype, shape)
+        assert got[name].dtype == want.dtype and got[name].shape == want.shape and np.array_equal(got[name], want), name
+    assert int(got["global_step"]) == 1234 and got["global_step"].shape == ()
+    # several data blocks with prefix-compressed keys behind restart points: the index block lists >= 3 of them
+    raw = open(prefix + ".index", "rb").read()
+    foot, pos = raw[-48:], 0
+    for _ in range(2):
+        _, pos = T._get_varint(foot, pos)
+    ioff, pos = T._get_varint(foot, pos)
+    isize, pos = T._get_varint(foot, pos)
+    assert len(list(T._block_entries(T._read_block(raw, ioff, isize)))) >= 3
+    # and the loader on top of it: network variables only, optimizer slots / counters dropped (input.py load_params)
+    params = I.load_params(GOLD)
+    assert "flownet_c/conv3_1/weights" in params and not any(k.endswith("/Adam") or k in ("global_step", "beta1_power") for k in params)
+    # a flipped payload byte is caught by the entry CRC
+    bad = bytearray(data)
+    bad[17] ^= 0x40
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for fn in os.listdir(GOLD):
+            shutil.copy(os.path.join(GOLD, fn), d)
+        with open(os.path.join(d, G.STEM + ".data-00000-of-00001"), "wb") as f:
+            f.write(bytes(bad))
+        with pytest.raises(Exception):
+            T.read_checkpoint(os.path.join(d, G.STEM), verify_data=True)
+
+
+def test_state_file_keeps_the_checkpoint_history(tmp_path):
+    """Saver(max_to_keep=1000) + recover_last_checkpoints (train.py:38-44): all_model_checkpoint_paths grows."""
+    for step in (10, 20, 30, 20):
+        T.write_checkpoint(str(tmp_path / ("model.ckpt-%d" % step)), {"w": np.full(2, step, np.float32)})
+    assert T.all_checkpoint_paths(str(tmp_path)) == ["model.ckpt-10", "model.ckpt-30", "model.ckpt-20"]
+    assert os.path.basename(T.latest_checkpoint(str(tmp_path))) == "model.ckpt-20"

@@ -468,7 +468,8 @@ class _Stage:
                 dz = L.PT(dz.t.as_strided(dz.t.shape[:3] + (l.cout_p,), dz.t.stride(), dz.t.storage_offset()), dz.pl, dz.scale)
             if e._bias_plan is None:
                 e._bias_jobs.append((dz.t, l))       # bias gradients: one batched column-sum launch at the end
-            wg = (L.conv_bwd_filter, (x, dz, l.dw, l.stride)) if l.kind == 'conv' else (L.deconv_bwd_filter, (x, dz, l.dw))
+            xv = op.src[0] not in self.planes_only      # a planes-only source has no valid fp32 copy: the filter gradient must take the planes
+            wg = (L.conv_bwd_filter, (x, dz, l.dw, l.stride, xv)) if l.kind == 'conv' else (L.deconv_bwd_filter, (x, dz, l.dw, xv))
             if n_flow and l.cout <= 2:
                 flow_jobs.append((l.kind, x, dz, l.dw))
                 wg = (L.flow_wgrad_batched, (flow_jobs,)) if len(flow_jobs) == n_flow else None
@@ -803,8 +804,13 @@ class FlowNetEngine:
         B, N, H, W = self.B, self.N, self.H, self.W
         lib = _lib.lib()
         st = self.stream()
-        assert im1.is_contiguous() and im2.is_contiguous() and im1.dtype == torch.float32 and im2.dtype == torch.float32
-        assert tuple(im1.shape) == (B, H, W, 3) and tuple(im2.shape) == (B, H, W, 3)
+        # the kernels below take raw device pointers: bring whatever the input pipeline delivers (numpy batches of
+        # core/input.py, host tensors, strided views) to contiguous fp32 on this engine's device — a no-op for a conforming tensor
+        im1 = torch.as_tensor(im1).to(device=self.dev, dtype=torch.float32).contiguous()
+        im2 = torch.as_tensor(im2).to(device=self.dev, dtype=torch.float32).contiguous()
+        if tuple(im1.shape) != (B, H, W, 3) or tuple(im2.shape) != (B, H, W, 3):
+            raise ValueError("set_input: expected two [%d,%d,%d,3] batches, got %s and %s"
+                             % (B, H, W, tuple(im1.shape), tuple(im2.shape)))
         if augment is None:
             # one launch: both frames -> mean-free network input (+ its operand planes for conv1 of a FlowNetC) and the [0,1]
             # images of the losses

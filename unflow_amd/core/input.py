@@ -140,7 +140,7 @@ def _paeth(a, b, c):
 
 
 def decode_png(data):
-    """Minimal PNG decoder (8 / 16 bit, grey / RGB / RGBA, non-interlaced) -> uint8 / uint16 array [H,W,C]."""
+    """Minimal PNG decoder (8 / 16 bit, grey / grey+alpha / RGB / RGBA, non-interlaced) -> uint8 / uint16 array [H,W,C]."""
     if data[:8] != b'\x89PNG\r\n\x1a\n':
         raise ValueError("not a PNG")
     pos, idat, hdr = 8, [], None
@@ -157,9 +157,9 @@ def decode_png(data):
     if hdr is None:
         raise ValueError("PNG without an IHDR chunk")
     w, h, depth, ctype, _, _, interlace = hdr
-    if interlace or depth not in (8, 16) or ctype not in (0, 2, 6):
+    if interlace or depth not in (8, 16) or ctype not in (0, 2, 4, 6):
         raise NotImplementedError("PNG variant (depth %d, colour type %d, interlace %d)" % (depth, ctype, interlace))
-    ch = {0: 1, 2: 3, 6: 4}[ctype]
+    ch = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
     bpp = ch * depth // 8
     stride = w * bpp
     raw = zlib.decompress(b''.join(idat))
@@ -271,8 +271,12 @@ def read_png_image(path):
     """read_png_image (input.py:208-218) for one file: decode_png(channels=3) cast to float32, [H,W,3]."""
     with open(path, 'rb') as f:
         a = decode_png(f.read())
+    if a.dtype == np.uint16:          # decode_png(dtype=uint8) of a 16-bit file keeps the high byte
+        a = (a >> 8).astype(np.uint8)
     if a.ndim == 2:
-        a = np.repeat(a[:, :, None], 3, axis=2)
+        a = a[:, :, None]
+    if a.shape[2] in (1, 2):          # grey (+ alpha): replicated to RGB, as channels=3 does
+        a = np.repeat(a[:, :, :1], 3, axis=2)
     return a[:, :, :3].astype(np.float32)
 
 
@@ -362,41 +366,44 @@ class Input:
         image = resize_image_with_crop_or_pad(image, h, w).reshape(h, w, 3)
         return self._normalize_image(image) if self.normalize else image
 
+    @staticmethod
+    def _pair_indices(n_files, sequence, skip):
+        """Index pairs (i, i + 1) into one directory's sorted listing, in the order input_raw emits them (input.py:142-160).
+        sequence: one pass per entry g of `skip` (frames to jump over), first files i = 0, 1 + g, 2 (1 + g), ... while
+        i < n - (1 + g); the partner is ALWAYS the next file in the listing.  Not a sequence: the listing is pairs (0,1), (2,3), ..."""
+        if not sequence:
+            if n_files % 2:
+                raise AssertionError("an uncorrelated-pairs directory must hold an even number of images")
+            return [(i, i + 1) for i in range(0, n_files, 2)]
+        out = []
+        for gap in skip:
+            stride = gap + 1
+            out += [(i, i + 1) for i in range(0, n_files - stride, stride)]
+        return out
+
     def raw_pairs(self, swap_images=True, sequence=True, shift=0, seed=0, skip=0):
         """The ordered example list of input_raw (input.py:121-184): [(first file, second file), ...]."""
         import random
-        if not isinstance(skip, list):
-            skip = [skip]
-        filenames = []
-        for dir_path in self.data.get_raw_dirs():
-            files = sorted(os.listdir(dir_path))
-            if sequence:
-                steps = [1 + s for s in skip]
-                stops = [len(files) - s for s in steps]
-            else:
-                steps = [2]
-                stops = [len(files)]
-                assert len(files) % 2 == 0
-            for step, stop in zip(steps, stops):
-                for i in range(0, stop, step):
-                    if self.skipped_frames and sequence:
-                        assert step == 1
-                        if frame_name_to_num(files[i]) + 1 != frame_name_to_num(files[i + 1]):
-                            continue
-                    filenames.append((os.path.join(dir_path, files[i]), os.path.join(dir_path, files[i + 1])))
-        random.seed(seed)
-        random.shuffle(filenames)
-        extended = []
-        for fn1, fn2 in filenames:
-            extended.append((fn1, fn2))
-            if swap_images:
-                extended.append((fn2, fn1))
-        shift = shift % len(extended)
-        # np.roll of the reference acts on the FLATTENED [n, 2] string array (input.py:173): an odd shift also swaps the roles
-        # of first and second file; reproduced literally
-        flat = [f for pair in extended for f in pair]
-        flat = flat[-shift:] + flat[:-shift] if shift else flat
-        return [(flat[2 * i], flat[2 * i + 1]) for i in range(len(extended))]
+        skip = skip if isinstance(skip, list) else [skip]
+        pairs = []
+        for folder in self.data.get_raw_dirs():
+            listing = sorted(os.listdir(folder))
+            for i, j in self._pair_indices(len(listing), sequence, skip):
+                if sequence and self.skipped_frames:
+                    # datasets with dropped frames: keep a pair only when the frame numbers are consecutive (input.py:153-158)
+                    assert len(skip) == 1 and skip[0] == 0
+                    if frame_name_to_num(listing[j]) - frame_name_to_num(listing[i]) != 1:
+                        continue
+                pairs.append((os.path.join(folder, listing[i]), os.path.join(folder, listing[j])))
+        random.Random(seed).shuffle(pairs)       # == random.seed(seed); random.shuffle(...) of the reference (same generator, same state)
+        if swap_images:
+            pairs = [q for a, b in pairs for q in ((a, b), (b, a))]
+        # the reference rolls the FLATTENED [n, 2] name array by `shift` (np.roll without an axis, input.py:173): an odd shift
+        # therefore also exchanges the roles of first and second file — kept
+        names = [f for pr in pairs for f in pr]
+        k = shift % len(pairs)
+        names = names[len(names) - k:] + names[:len(names) - k]
+        return list(zip(names[0::2], names[1::2]))
 
     def input_raw(self, swap_images=True, sequence=True, needs_crop=True, shift=0, seed=0, center_crop=False, skip=0):
         """input_raw (input.py:121-205): an iterator of (image_1, image_2) batches [B,H,W,3] float32.  `shift`: examples to skip

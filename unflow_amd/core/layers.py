@@ -240,9 +240,14 @@ def conv_bwd_data(dz, w, w_pl, dx, stride, accumulate=False, act_src=None, act_l
           "conv2d_bwd_data_pl")
 
 
-def conv_bwd_filter(x, dz, dw, stride):
+def conv_bwd_filter(x, dz, dw, stride, x_fp32=True):
+    """x_fp32 = False: x lives as operand planes alone (its fp32 tensor is stale) — the library then gets no fp32 pointer and
+    fails loudly if it cannot take the planes path instead of computing a gradient from stale values."""
     x, dz = _pt(x), _pt(dz)
     xp, ldx, B, H, W, Cin = nhwc(x.t)
+    if not x_fp32:
+        assert x.pl is not None
+        xp = ptr(None)
     dzp, lddz, _, Ho, Wo, Cout = nhwc(dz.t)
     k = dw.shape[0]
     assert tuple(dw.shape) == (k, k, Cin, Cout) and dw.is_contiguous()
@@ -281,9 +286,12 @@ def deconv_bwd_data(dz, w, w_pl, dx, accumulate=False, act_src=None, act_lo=0, a
           "conv2d_transpose_bwd_data_pl")
 
 
-def deconv_bwd_filter(x, dz, dw):
+def deconv_bwd_filter(x, dz, dw, x_fp32=True):
     x, dz = _pt(x), _pt(dz)
     xp, ldx, B, H, W, Cin = nhwc(x.t)
+    if not x_fp32:
+        assert x.pl is not None
+        xp = ptr(None)
     dzp, lddz, _, Ho, Wo, Cout = nhwc(dz.t)
     assert tuple(dw.shape) == (4, 4, Cout, Cin)
     wsp, wsn = _ws_pl(x.t.device, B, Ho, Wo, Cin, Cout, 4, 2, _npl(x, dz))

@@ -351,12 +351,27 @@ def latest_checkpoint(directory):
     p = os.path.join(directory, 'checkpoint')
     if not os.path.exists(p):
         return None
-    for line in open(p):
-        line = line.strip()
-        if line.startswith('model_checkpoint_path:'):
-            name = line.split(':', 1)[1].strip().strip('"')
-            return name if os.path.isabs(name) else os.path.join(directory, name)
+    with open(p) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith('model_checkpoint_path:'):
+                name = line.split(':', 1)[1].strip().strip('"')
+                return name if os.path.isabs(name) else os.path.join(directory, name)
     return None
+
+
+def all_checkpoint_paths(directory):
+    """all_model_checkpoint_paths of a directory's `checkpoint` state file, oldest first (what
+    Saver.recover_last_checkpoints is fed, train.py:43-44); [] without a state file."""
+    p = os.path.join(directory, 'checkpoint')
+    out = []
+    if os.path.exists(p):
+        with open(p) as f:
+            for line in f:
+                line = line.strip()
+                if line.startswith('all_model_checkpoint_paths:'):
+                    out.append(line.split(':', 1)[1].strip().strip('"'))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------ bundle (write)
@@ -442,5 +457,10 @@ def write_checkpoint(prefix, tensors, directory_state=True, block_size=4096):
     write_table(prefix + '.index', items, block_size)
     if directory_state:
         d, base = os.path.split(prefix)
+        # the Saver of the reference keeps up to 1000 checkpoints and recovers the list on resume (max_to_keep=1000,
+        # recover_last_checkpoints, train.py:38-44): the history is appended to, never rewritten
+        hist = [h for h in all_checkpoint_paths(d) if h != base] + [base]
         with open(os.path.join(d, 'checkpoint'), 'w') as f:
-            f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+            f.write('model_checkpoint_path: "%s"\n' % base)
+            for h in hist[-1000:]:
+                f.write('all_model_checkpoint_paths: "%s"\n' % h)

@@ -176,25 +176,64 @@ class Trainer:
         ckpt = T.latest_checkpoint(ckpt_dir)
         return None if ckpt is None else int(os.path.basename(ckpt).split('-')[-1])
 
+    def _saved_networks(self):
+        """Indices of the networks in the Saver's scope (train.py:32-37): every network with train_all, else the last one."""
+        n = len(self.engine.spec)
+        return list(range(n)) if self.params.get('train_all') else [n - 1]
+
+    def _in_saved_scope(self, name):
+        from .input import network_scope
+        return any(name.startswith(sc) for i in self._saved_networks() for sc in network_scope(i))
+
     def save(self, ckpt_dir, global_step):
         """saver.save(sess, ckpt_dir/model.ckpt, global_step) (train.py:260-261): a TF checkpoint-V2 bundle under the reference's
-        variable names + the directory's `checkpoint` state file.  Rank 0 writes."""
+        variable names + the directory's `checkpoint` state file, holding what the reference's scoped Saver holds — the trained
+        networks (all with train_all, else the last one, train.py:32-37) and their Adam slots.  Rank 0 writes; every rank
+        waits for the file before it goes on (a resume right after must find it)."""
         from .input import save_checkpoint
         if self.rank == 0:
             os.makedirs(ckpt_dir, exist_ok=True)
             tensors = self.engine.export_tf_params()
             tensors.update(self.engine.export_tf_adam_slots())      # '<var>/Adam', '<var>/Adam_1': in the Saver's scope too
-            save_checkpoint(os.path.join(ckpt_dir, 'model.ckpt-%d' % global_step), tensors, global_step)
+            tensors = {k: v for k, v in tensors.items() if self._in_saved_scope(k)}
+            save_checkpoint(os.path.join(ckpt_dir, 'model.ckpt-%d' % global_step), tensors)
+        if self.world > 1:
+            dist.barrier()
 
-    def restore(self, ckpt_dir):
-        """restore_networks from the latest checkpoint of ckpt_dir, every network of the spec from the same file (the `ckpt is not
-        None` branch of train.py:40-44)."""
+    def restore(self, ckpt_dir=None):
+        """restore_networks (train.py:23-65).  Without a checkpoint in ckpt_dir: the networks named by params['finetune'] (in
+        network order) are loaded, the rest keep their initialisation.  With one (continue training): the networks of the
+        Saver's scope and their Adam slots come from the checkpoint, and — unless train_all — the frozen networks in front
+        again from finetune[:n-1] (the reference's checkpoint of a stacked run does not contain them).  Returns the checkpoint
+        prefix or None."""
         from . import tf_checkpoint as T
         from .input import restore_networks
-        ckpt = T.latest_checkpoint(ckpt_dir)
+        n = len(self.engine.spec)
+        finetune = list(self.params.get('finetune') or [])
+        if len(finetune) > n:
+            raise ValueError("%d finetune entries for the %d networks of spec %r (train.py:31)" % (len(finetune), n, self.engine.spec))
+        ckpt = T.latest_checkpoint(ckpt_dir) if ckpt_dir is not None else None
+        files = [None] * n
         if ckpt is not None:
-            restore_networks(self.engine, self.params, [ckpt] * len(self.engine.spec))
-            names = [k for k in T.checkpoint_entries(ckpt)[1] if k.endswith('/Adam') or k.endswith('/Adam_1')]
+            have = set(T.checkpoint_entries(ckpt)[1])
+            for i in self._saved_networks():
+                files[i] = ckpt
+            external = [] if self.params.get('train_all') else finetune[:n - 1]
+            if not self.params.get('train_all') and not external:
+                # a checkpoint written with every network in it (this trainer before round 4, or a train_all run continued
+                # frozen): take the frozen networks from it rather than leaving them at their initialisation
+                from .input import network_scope
+                for i in range(n - 1):
+                    if any(k.startswith(sc) for k in have for sc in network_scope(i)):
+                        files[i] = ckpt
+        else:
+            external = finetune
+        for i, f in enumerate(external):       # restored after the checkpoint, like the reference's second loop (:46-63)
+            files[i] = f
+        if any(f is not None for f in files):
+            restore_networks(self.engine, self.params, files)
+        if ckpt is not None:
+            names = [k for k in T.checkpoint_entries(ckpt)[1] if (k.endswith('/Adam') or k.endswith('/Adam_1')) and self._in_saved_scope(k)]
             slots = {k: torch.from_numpy(v) for k, v in T.read_checkpoint(ckpt, names).items()}
             self.engine.load_tf_adam_slots(slots)
         return ckpt
@@ -217,6 +256,7 @@ class Trainer:
             self.restore(ckpt_dir)
         else:
             start_iter = min_iter + 1
+            self.restore(None)          # params['finetune'] (train.py:40-46 with ckpt None)
         print('-- training from i = {} to {}'.format(start_iter, max_iter))
         assert (max_iter - start_iter + 1) % save_interval == 0
         log = []

@@ -37,51 +37,49 @@ def downsample(tensor, num):
 
 
 # ------------------------------------------------------------------------------------------------- config.ini (util.py:37-85)
-def config_dict(config_path='../config.ini'):
-    """config_dict (src/e2eflow/util.py:37-62): the ini file as {section: {key: value}} with the reference's coercion order —
-    int, then float, then ConfigParser boolean ('yes' / 'true' / 'on' / '1' ...), else the string."""
+def _ini_value(text):
+    """One ini value under the reference's coercion ladder (util.py:45-59): an int if it parses as one, else a float, else a
+    ConfigParser boolean word ('yes' / 'no' / 'true' / 'false' / 'on' / 'off', any case; '0' / '1' were ints already), else
+    the string itself."""
     import configparser
-    config = configparser.ConfigParser()
-    config.read(config_path)
-    d = {}
-    for section_key in config.sections():
-        section = config[section_key]
-        sd = {}
-        for key in section:
-            val = section[key]
-            try:
-                sd[key] = int(val)
-            except ValueError:
-                try:
-                    sd[key] = float(val)
-                except ValueError:
-                    try:
-                        sd[key] = section.getboolean(key)
-                    except ValueError:
-                        sd[key] = val
-        d[section_key] = sd
-    return d
+    for number in (int, float):
+        try:
+            return number(text)
+        except ValueError:
+            pass
+    return configparser.ConfigParser.BOOLEAN_STATES.get(text.lower(), text)
+
+
+def config_dict(config_path='../config.ini'):
+    """config_dict (src/e2eflow/util.py:37-62): {section: {key: coerced value}} of an ini file (a missing file gives {}, as
+    ConfigParser.read does); keys of [DEFAULT] appear in every section."""
+    import configparser
+    ini = configparser.ConfigParser()
+    ini.read(config_path)
+    return {name: {key: _ini_value(raw) for key, raw in ini[name].items()} for name in ini.sections()}
+
+
+def experiment_checkpoint(name, dirs):
+    """Latest checkpoint prefix of experiment `name`: its working checkpoints (dirs['checkpoints']/<name>) first, then the
+    final one kept with its logs (dirs['log']/ex/<name>) — the two places util.py:75-83 asks tf.train.get_checkpoint_state."""
+    import os
+    from . import tf_checkpoint as T
+    for folder in (os.path.join(dirs['checkpoints'], name), os.path.join(dirs['log'], 'ex', name)):
+        found = T.latest_checkpoint(folder)
+        if found:
+            return found
+    raise AssertionError("Could not load experiment " + name)
 
 
 def convert_input_strings(config_dct, dirs):
-    """convert_input_strings (util.py:65-85), in place: the comma lists 'manual_decay_iters' / 'manual_decay_lrs' become lists
-    (and fix num_iters to their sum); 'finetune' = comma-separated experiment names becomes the list of their latest
-    checkpoint prefixes — looked up under dirs['checkpoints']/<name>, then dirs['log']/ex/<name>, as the reference does with
-    tf.train.get_checkpoint_state (here: the 'checkpoint' state file read by core/tf_checkpoint.py)."""
-    import os
-    from . import tf_checkpoint as T
-    if 'manual_decay_iters' in config_dct and 'manual_decay_lrs' in config_dct:
-        iters_lst = [int(i) for i in str(config_dct['manual_decay_iters']).split(',')]
-        lrs_lst = [float(x) for x in str(config_dct['manual_decay_lrs']).split(',')]
-        config_dct['manual_decay_iters'] = iters_lst
-        config_dct['manual_decay_lrs'] = lrs_lst
-        config_dct['num_iters'] = sum(iters_lst)
+    """convert_input_strings (util.py:65-85), in place.  A manual learning-rate schedule — both comma lists
+    'manual_decay_iters' and 'manual_decay_lrs' present — is parsed into lists and fixes 'num_iters' to the sum of its
+    stage lengths; 'finetune' (comma-separated experiment names) becomes the list of their latest checkpoint prefixes."""
+    def parts(key, cast):
+        return [cast(tok) for tok in str(config_dct[key]).split(',')]
+    if {'manual_decay_iters', 'manual_decay_lrs'} <= config_dct.keys():
+        config_dct['manual_decay_iters'] = parts('manual_decay_iters', int)
+        config_dct['manual_decay_lrs'] = parts('manual_decay_lrs', float)
+        config_dct['num_iters'] = sum(config_dct['manual_decay_iters'])
     if 'finetune' in config_dct:
-        finetune = []
-        for name in str(config_dct['finetune']).split(','):
-            ckpt = T.latest_checkpoint(os.path.join(dirs['checkpoints'], name))
-            if ckpt is None:
-                ckpt = T.latest_checkpoint(os.path.join(dirs['log'], 'ex', name))
-            assert ckpt, "Could not load experiment " + name
-            finetune.append(ckpt)
-        config_dct['finetune'] = finetune
+        config_dct['finetune'] = [experiment_checkpoint(name, dirs) for name in parts('finetune', str)]

@@ -2821,7 +2821,8 @@ UNFLOW_API int unflow_conv2d_bwd_filter_pl(const float* x, int ldx, const unflow
   const bool rgb4 = rgb4_form(x_pl, W, Cin, k, stride) && planes_ok(dz_pl, Cout) && dz_pl->n_planes == x_pl->n_planes &&
                     Cout > 4 && Cout % 4 == 0;
   if (!rgb4 && (!use_planes(x_pl, Cin, dz_pl, Cout, Cout) || Cout % 4 != 0))
-    return unflow_conv2d_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, stream);
+    return (!x || !dz) ? UNFLOW_ERR_UNSUPPORTED :      // planes-only operand: no fp32 copy to fall back on
+           unflow_conv2d_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, stream);
   PlWgradParams p{};
   build_conv_wgrad(p, B, H, W, (Cin + 7) & ~7, Cout, k, stride);
   if (rgb4) { p.Ca = 32; p.KW = 1; p.gpx = 2; }
@@ -2891,7 +2892,8 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_filter_pl(const float* x, int ldx, co
   if (!dw || (!x && !x_pl) || (!dz && !dz_pl)) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return UNFLOW_ERR_SHAPE;
   if (!use_planes(x_pl, Cin, dz_pl, Cout, Cout) || Cin % 4 != 0 || Cin <= 4)
-    return unflow_conv2d_transpose_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, workspace, workspace_bytes, stream);
+    return (!x || !dz) ? UNFLOW_ERR_UNSUPPORTED :
+           unflow_conv2d_transpose_bwd_filter(x, ldx, dz, lddz, dw, nullptr, B, H, W, Cin, Cout, workspace, workspace_bytes, stream);
   // dW[ky,kx,co,ci]: gathered operand = dz (rows (tap, co)), dense operand = x (columns ci)
   PlWgradParams p{};
   build_deconv_wgrad(p, B, H, W, Cin, (Cout + 7) & ~7);
