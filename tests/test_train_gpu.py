@@ -294,7 +294,8 @@ def test_trainer_run_saves_checkpoints_and_resumes_identically(tmp_path):
     assert [i for i, _ in log] == [1, 2, 3, 4] and all(np.isfinite(l) for _, l in log)
     assert tr.checkpoint_step(ck_a) == 4
     ent = T.checkpoint_entries(os.path.join(ck_a, 'model.ckpt-4'))[1]
-    assert 'flownet_s/conv1/weights' in ent and 'flownet_s/conv1/weights/Adam_1' in ent and 'global_step' in ent
+    assert 'flownet_s/conv1/weights' in ent and 'flownet_s/conv1/weights/Adam_1' in ent
+    assert 'global_step' not in ent          # the reference's scoped Saver holds network variables and their slots only
     final = tr.engine.export_tf_params()
     # resume from the checkpoint of the first chunk
     os.makedirs(ck_b)
@@ -309,3 +310,84 @@ def test_trainer_run_saves_checkpoints_and_resumes_identically(tmp_path):
     got = tr2.engine.export_tf_params()
     for k in final:
         assert torch.equal(final[k], got[k]), k
+
+
+@pytest.mark.gpu
+def test_trainer_stacked_restore_follows_restore_networks(tmp_path):
+    """restore_networks (train.py:23-65) for a CS run: without a checkpoint the frozen FlowNetC comes from params['finetune'];
+    the run's checkpoints hold only the trained network (the Saver's scope) and its Adam slots; a resumed trainer takes the
+    frozen network from finetune[:n-1] again and ends bit-identical to the uninterrupted run."""
+    import shutil
+    from unflow_amd.core.train import Trainer
+    from unflow_amd.core import tf_checkpoint as T
+    dev = torch.device("cuda:0")
+    H = W = 64
+    base = dict(learning_rate=1e-4, decay_interval=100000, save_interval=2, display_interval=1)
+    c_dir = str(tmp_path / "C")
+    trc = Trainer(1, H, W, dict(base, flownet='C'), device=dev, seed=11, augment=False, use_graph=False)
+    trc.save(c_dir, 7)
+    c_params = trc.engine.export_tf_params()
+    del trc
+    g = torch.Generator().manual_seed(8)
+    frames = [(torch.rand(1, H, W, 3, generator=g) * 255, torch.rand(1, H, W, 3, generator=g) * 255) for _ in range(4)]
+
+    def batches(iter_offset):
+        k = iter_offset
+        while True:
+            yield frames[k % 4]                       # host tensors: set_input brings them to the device
+            k += 1
+
+    params = dict(base, flownet='CS', finetune=[T.latest_checkpoint(c_dir)])
+    ck_a, ck_b = str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(ck_a)
+    tr = Trainer(1, H, W, params, device=dev, seed=3, augment=False, use_graph=False)
+    assert tr.restore(ck_a) is None                                   # no checkpoint yet: finetune only
+    got = tr.engine.export_tf_params()
+    for k, v in c_params.items():
+        assert torch.equal(got[k], v), k                              # the frozen FlowNetC is the finetune checkpoint's
+    tr.run(0, 4, batches, ck_a)
+    ent = T.checkpoint_entries(os.path.join(ck_a, 'model.ckpt-4'))[1]
+    assert any(k.startswith('stack_1_flownet/') and k.endswith('/Adam_1') for k in ent)
+    assert not any(k.startswith('flownet_c') for k in ent)            # non-train_all: the last network only (train.py:35-37)
+    final = tr.engine.export_tf_params()
+    os.makedirs(ck_b)
+    for f in os.listdir(ck_a):
+        if 'model.ckpt-2' in f:
+            shutil.copy(os.path.join(ck_a, f), ck_b)
+    with open(os.path.join(ck_b, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "model.ckpt-2"\n')
+    tr2 = Trainer(1, H, W, params, device=dev, seed=99, augment=False, use_graph=False)
+    tr2.run(0, 4, batches, ck_b)
+    got = tr2.engine.export_tf_params()
+    for k in final:
+        assert torch.equal(final[k], got[k]), k
+    # a checkpoint without the frozen network and no finetune entry for it: the trained network alone is restored, no KeyError
+    tr3 = Trainer(1, H, W, dict(base, flownet='CS'), device=dev, seed=5, augment=False, use_graph=False)
+    assert tr3.restore(ck_a) is not None
+    got3 = tr3.engine.export_tf_params()
+    assert all(torch.equal(got3[k], final[k]) for k in final if k.startswith('stack_1_flownet/'))
+
+
+@pytest.mark.gpu
+def test_input_raw_feeds_trainer_run(tmp_path):
+    """The input pipeline and the trainer connected end to end (run.py: Input.input_raw -> Trainer.run): PNG frames on disk ->
+    pair list -> random-crop numpy batches -> train steps -> checkpoints; resuming with shift = batch_size * iter_offset."""
+    from unflow_amd.core.input import Input, encode_png8_rgb
+    from unflow_amd.core.train import Trainer
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    d = tmp_path / "frames"
+    d.mkdir()
+    for i in range(6):
+        (d / ("%06d.png" % i)).write_bytes(encode_png8_rgb(rs.randint(0, 256, size=(72, 80, 3)).astype(np.uint8)))
+
+    class Data:
+        def get_raw_dirs(self):
+            return [str(d)]
+    inp = Input(Data(), 2, (64, 64), normalize=False)
+    params = dict(flownet='S', learning_rate=1e-4, decay_interval=100000, save_interval=2, display_interval=1)
+    tr = Trainer(2, 64, 64, params, device=dev, seed=1, augment=True, use_graph=False)
+    ck = str(tmp_path / "ck")
+    log = tr.run(0, 4, lambda off: inp.input_raw(shift=2 * off, seed=0), ck)
+    assert [i for i, _ in log] == [1, 2, 3, 4] and all(np.isfinite(l) for _, l in log)
+    assert tr.checkpoint_step(ck) == 4

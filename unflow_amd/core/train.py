@@ -253,14 +253,16 @@ class Trainer:
             if start_iter > max_iter:
                 print('-- train: max_iter reached')
                 return []
-            self.restore(ckpt_dir)
         else:
             start_iter = min_iter + 1
-            self.restore(None)          # params['finetune'] (train.py:40-46 with ckpt None)
         print('-- training from i = {} to {}'.format(start_iter, max_iter))
         assert (max_iter - start_iter + 1) % save_interval == 0
         log = []
         for i in range(start_iter, max_iter + 1, save_interval):
+            # every chunk of the reference builds a fresh graph and calls restore_networks (train.py:186-218): the networks of the
+            # Saver's scope and their Adam slots continue from the checkpoint just written (or start from params['finetune'] /
+            # their initialisation), frozen networks come from finetune again and every other optimizer slot restarts at zero
+            self.restore(ckpt_dir)
             log += self.train(i, i + save_interval - 1, i - (min_iter + 1), train_batch_fn, ckpt_dir)
             if eval_fn is not None:
                 eval_fn(i + save_interval - 1)
