@@ -425,6 +425,15 @@ int unflow_flow_wgrad_batched(int n, const int* kind, const float* const* x, con
  * the padding workgroups of order 2.  Returns the grid size (out == NULL: query only). */
 int unflow_debug_work_order(int mt, int nt, int ncls, int nsplit, int order, int xcd, int* out, int out_blocks);
 
+/* Persistent stream-K halo kernel (csrc/conv_streamk.hip).  Test hook (host only, no GPU): the first chunk unit
+ * (item * nchunk + chunk; items class-major) of the range of each of G workgroups, G + 1 ints (out[G] = all units), for a launch
+ * of `ncls` tap classes with items_per_class items of nchunk chunks x ntaps[class] K tiles each.  Returns 0, or
+ * UNFLOW_ERR_SHAPE for arguments outside the kernel's limits. */
+int unflow_debug_streamk_units(int G, int items_per_class, int nchunk, int ncls, const int* ntaps, int* out);
+/* ... and the number of bounded spins of those kernels that gave up since the last call (reads and clears a device counter:
+ * must be 0; a result computed past a timeout is wrong). */
+int unflow_debug_streamk_timeouts(void);
+
 /* w_pl: the `transposed` planes of w (ld = round_up_8(Cin)). */
 int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes* x_pl, const float* w, const unflow_planes* w_pl,
                          const float* bias, float* y, int ldy, const unflow_planes* y_pl, int B, int H, int W, int Cin,

@@ -118,8 +118,40 @@ CONV_CASES = [
 @pytest.mark.parametrize("P", [3, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_planes_vs_fp64(case, P, dev, lib_option):
-    from unflow_amd.core import layers as L
     lib_option("halo_s2", 2)       # the accumulating-class halo form wherever it applies (by default only from 384 tiles up)
+    _conv_case_vs_fp64(case, P, dev)
+
+
+# the persistent stream-K halo kernel (csrc/conv_streamk.hip) forced wherever it is eligible (source stride 1, N > 64, bf16 x 3):
+# forward and data gradient of the cases below run through it — single and multiple tap classes (even and uneven tap counts),
+# ragged tiles, an N tail, launches with far fewer chunk units than workgroups (empty ranges, items cut into up to 8 segments)
+# and the step's own shapes (conv3_1; the 4 / 2 / 2 / 1-tap parity classes of conv4's data gradient)
+STREAMK_CASES = [
+    (2, 48, 64, 128, 128, 3, 1),
+    (2, 8, 32, 256, 256, 3, 1),
+    (1, 10, 40, 128, 96, 3, 1),
+    (8, 96, 128, 128, 256, 5, 2),
+    (4, 48, 64, 256, 512, 3, 2),
+    (4, 48, 64, 476, 256, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", STREAMK_CASES)
+def test_conv_planes_streamk_vs_fp64(case, dev, lib_option):
+    from unflow_amd import _lib
+    lib_option("streamk", 2)
+    _lib.lib().unflow_debug_streamk_timeouts()          # clear
+    first = _conv_case_vs_fp64(case, 3, dev)
+    assert _lib.lib().unflow_debug_streamk_timeouts() == 0
+    again = _conv_case_vs_fp64(case, 3, dev)            # fixed-order sums: bit-identical run to run
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    lib_option("streamk", 0)                             # and within fp32 rounding of the one-shot kernels' results
+    plain = _conv_case_vs_fp64(case, 3, dev)
+    assert all(rel_err(a, b) < 2e-6 for a, b in zip(first, plain))
+
+
+def _conv_case_vs_fp64(case, P, dev):
+    from unflow_amd.core import layers as L
     B, H, W, Cin, Cout, k, stride = case
     g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
     x = torch.randn(B, H, W, Cin, generator=g)
@@ -176,6 +208,7 @@ def test_conv_planes_vs_fp64(case, P, dev, lib_option):
     dw = torch.full((k, k, Cin, Cout), 9.0, device=dev)
     L.conv_bwd_filter(X, DZ, dw, stride)
     assert rel_err(dw, wr.grad) < (3e-5 if P == 3 else TOL[P])
+    return Yv.t.clone(), DX.t.clone(), DX2.t.clone()
 
 
 @pytest.mark.parametrize("P", [3, 1])
@@ -241,8 +274,27 @@ DECONV_CASES = [
 @pytest.mark.parametrize("P", [3, 1])
 @pytest.mark.parametrize("case", DECONV_CASES)
 def test_deconv_planes_vs_fp64(case, P, dev, lib_option):
-    from unflow_amd.core import layers as L
     lib_option("halo_s2", 2)
+    _deconv_case_vs_fp64(case, P, dev)
+
+
+@pytest.mark.parametrize("case", [(1, 24, 32, 772, 128), (4, 24, 32, 772, 128), (1, 9, 40, 128, 72)])
+def test_deconv_planes_streamk_vs_fp64(case, dev, lib_option):
+    """conv_transpose forward = four output-parity classes of 2 x 2 taps on the persistent stream-K halo kernel."""
+    from unflow_amd import _lib
+    lib_option("streamk", 2)
+    _lib.lib().unflow_debug_streamk_timeouts()
+    first = _deconv_case_vs_fp64(case, 3, dev)
+    assert _lib.lib().unflow_debug_streamk_timeouts() == 0
+    again = _deconv_case_vs_fp64(case, 3, dev)
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    lib_option("streamk", 0)
+    plain = _deconv_case_vs_fp64(case, 3, dev)
+    assert all(rel_err(a, b) < 2e-6 for a, b in zip(first, plain))
+
+
+def _deconv_case_vs_fp64(case, P, dev):
+    from unflow_amd.core import layers as L
     from oracle import model_ref as M
     B, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
@@ -275,6 +327,7 @@ def test_deconv_planes_vs_fp64(case, P, dev, lib_option):
     dw = torch.full((4, 4, Cout, Cin), 9.0, device=dev)
     L.deconv_bwd_filter(X, DZ, dw)
     assert rel_err(dw, wr.grad) < (3e-5 if P == 3 else TOL[P])
+    return Y.t.clone(), DX.t.clone()
 
 
 def test_planes_kernels_match_inline_split_bitwise_close(dev):

@@ -21,17 +21,10 @@
 //        and the MFMA fragments (8 consecutive k of one channel) come out of LDS through ds_read_b64_tr_b16, the
 //        gfx950 transposing read (semantics probed in tools/microbench/probe_semantics.hip): no per-lane dword gathers.
 #include "igemm_shared.h"
-#include "options.h"
+#include "planes_shared.h"
 
 namespace {
 using namespace igemm;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int LDH = BK;   // 16-bit elements per LDS row of the gather image (64 bytes)
 
 // Phase trace (diagnostic builds only: -DUNFLOW_PHASE_TRACE, tools/phase_trace.py): the waves of workgroup 0 stamp
 // s_memtime at the phase boundaries of their first 64 K tiles; never compiled into the shipped library.
@@ -57,292 +50,6 @@ __device__ unsigned long long g_phase_trace[8 * 8];          // [wave][phase 0..
 #define PHASE_STAMP(slot) do { } while (0)
 #define PHASE_FLUSH do { } while (0)
 #endif
-
-struct PlGatherParams : GatherGeom {
-  const unsigned short* src;   // source planes, channel 0 of the consumed slice; [pixel][lds] per plane
-  long src_ps;                 // plane stride (elements)
-  const unsigned short* w;     // weight planes [tap][N][Cs] (K-contiguous)
-  long w_ps;
-  const float* bias;
-  float* dst;
-  float* partial;
-  const float* act_src;        // leaky-ReLU derivative taken from this fp32 activation (its sign), or
-  const unsigned short* act_pl;   // ... from the activation's FIRST operand plane (bf16 hi / fp16: same sign, 2 bytes per element)
-  int lds, ldd, ld_act, act_lo, act_hi;
-  int nsplit;
-  int leaky, accumulate;
-  float src_inv;               // 1 / (scale of the source planes x scale of the weight planes): applied to the finished sums
-  int* counters;               // fused split-K: one arrival counter per (class, M tile, N tile), zeroed before the launch
-  int fused_splitk;
-  int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
-  int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
-  int xcd;                     // XCD-contiguous work order (xcd_remap + work_decode)
-  int mt, nt;                  // M tiles, N tiles of the launch (the grid is 1-D: mt * nt * ncls * nsplit workgroups)
-  int order;                   // work order (work_decode): 0 N tile fastest .. M tile slowest; 1 M tile fastest; 2 M groups
-  int mgroup;                  // order 2: M tiles per group (one group per XCD)
-  int tw_log;                  // gather kernel: 0 = an M tile is BM consecutive sites of the linear (b, y, x) order; else the
-                               // tile is (BM >> tw_log) rows x (1 << tw_log) sites of one image (tiles_x, tiles_y per image)
-  int gpx;                     // pixels per K granule along x (0: a granule is 8 channels of ONE pixel; 2: conv1 form, below)
-  PlaneOut pl;
-};
-
-// LDS bytes of one gather block: the operand tiles, or (larger for n_planes == 1) the four wave-private staging areas of
-// the epilogue (32 rows x (WN + 4) floats each); the destination-pixel table follows.
-constexpr int pl_gather_main_bytes(int bm, int bn, int wn, int npl) {
-  const int tiles = npl * (bm + bn) * LDH * 2, stage = 4 * 32 * (wn + 4) * 4;
-  return tiles > stage ? tiles : stage;
-}
-
-// (xcd_remap: igemm_shared.h)
-// The launch is a 1-D grid; the linear workgroup id is first made XCD-contiguous (xcd_remap: the workgroups one XCD runs
-// are a contiguous run of the work order) and then decoded so that the workgroups resident together on an XCD share
-// operands in its L2.  Orders (run_pl_gather picks one per layer):
-//   0  N tile fastest, then parity class, K split, M tile: the consumers of one M tile's source pixels are adjacent;
-//   1  M tile fastest, then N tile, class, split: the M tiles of one weight slice are adjacent and an XCD touches 1/8 of the
-//      weights (deep layers: 28-56 MB of weight planes against 5 MB of activations; with the (x, y, z) grid dealt
-//      round-robin the forward / data-gradient kernels of conv5..conv6_1 moved 210-345 MB each);
-//   2  the M tiles are cut into 8 groups (one per XCD: neighbouring tiles share the vertical taps' rows); inside a group the
-//      M tile runs fastest, then N tile, class, split: every weight slice is streamed once per XCD by all its M tiles in
-//      step.  The grid is padded to whole groups; surplus workgroups return at once (m = -1).
-__host__ __device__ __forceinline__ void work_decode(int v, int mt, int nt, int ncls, int nsplit, int order, int mgroup, int& m, int& n,
-                                            int& c, int& s) {
-  if (order == 0) {
-    n = v % nt; v /= nt;
-    c = v % ncls; v /= ncls;
-    s = v % nsplit;
-    m = v / nsplit;
-    return;
-  }
-  if (order == 2) {
-    const int per = mgroup * nt * ncls * nsplit;
-    const int g = v / per;
-    v -= g * per;
-    const int mi = v % mgroup;
-    v /= mgroup;
-    m = g * mgroup + mi;
-    if (m >= mt) m = -1;
-  } else {
-    m = v % mt; v /= mt;
-  }
-  n = v % nt; v /= nt;
-  c = v % ncls;
-  s = v / ncls;
-}
-
-template <int NPL, bool F16>
-__device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (&bv)[NPL], f32x16& acc, int t) {
-  if constexpr (F16) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bv[0]), acc, 0, 0, 0);
-  } else if constexpr (NPL == 1) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[0]), __builtin_bit_cast(bf16x8, bv[0]), acc, 0, 0, 0);
-  } else {
-    constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ta[t]]), __builtin_bit_cast(bf16x8, bv[tb[t]]), acc,
-                                                  0, 0, 0);
-  }
-}
-
-// sign test on a 16-bit plane element (bf16 hi plane or fp16): the value is > 0 (tf.maximum(0.1 x, x) took the x branch)
-__device__ __forceinline__ float leaky_grad_from_bits(unsigned h) { return ((h & 0x8000u) == 0u && (h & 0x7fffu) != 0u) ? 1.f : 0.1f; }
-
-// bias / leaky-ReLU / accumulate / leaky derivative of four consecutive output channels; stores the fp32 result when the
-// layer keeps one (dst may be NULL: tensors that only convolutions read live as operand planes alone) and returns it
-__device__ __forceinline__ float4 epi_value4(const PlGatherParams& p, size_t px, int n, float4 v) {
-  if (p.src_inv != 1.f) { v.x *= p.src_inv; v.y *= p.src_inv; v.z *= p.src_inv; v.w *= p.src_inv; }
-  if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
-  if (p.leaky) { v.x = leaky_relu(v.x); v.y = leaky_relu(v.y); v.z = leaky_relu(v.z); v.w = leaky_relu(v.w); }
-  float4* d = reinterpret_cast<float4*>(p.dst + px * p.ldd + n);
-  if (p.accumulate) {
-    const float4 e = *d;
-    v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
-  }
-  if (n + 3 >= p.act_lo && n < p.act_hi) {
-    float gx = 1.f, gy = 1.f, gz = 1.f, gw = 1.f;
-    bool have = false;
-    if (p.act_src) {
-      const float4 a = *reinterpret_cast<const float4*>(p.act_src + px * p.ld_act + n);
-      gx = leaky_grad_from_out(a.x); gy = leaky_grad_from_out(a.y); gz = leaky_grad_from_out(a.z); gw = leaky_grad_from_out(a.w);
-      have = true;
-    } else if (p.act_pl) {
-      const uint2 a = *reinterpret_cast<const uint2*>(p.act_pl + px * p.ld_act + n);
-      gx = leaky_grad_from_bits(a.x & 0xffffu); gy = leaky_grad_from_bits(a.x >> 16);
-      gz = leaky_grad_from_bits(a.y & 0xffffu); gw = leaky_grad_from_bits(a.y >> 16);
-      have = true;
-    }
-    if (have) {
-      if (n >= p.act_lo && n < p.act_hi) v.x *= gx;
-      if (n + 1 >= p.act_lo && n + 1 < p.act_hi) v.y *= gy;
-      if (n + 2 >= p.act_lo && n + 2 < p.act_hi) v.z *= gz;
-      if (n + 3 >= p.act_lo && n + 3 < p.act_hi) v.w *= gw;
-    }
-  }
-  if (p.dst) *d = v;
-  return v;
-}
-__device__ __forceinline__ void epi_store4(const PlGatherParams& p, size_t px, int n, float4 v) {
-  store_planes4(p.pl, px, n, epi_value4(p, px, n, v));
-}
-// eight consecutive channels n .. n+7 (n % 8 == 0 in the destination row): the fp32 halves as above, the planes as ONE
-// 16-byte store per plane (the epilogues are store-issue bound on layers with few K tiles per output: conv1, the 64-channel
-// decoder levels; a lane that owns 8 channels issues 5 stores where two 4-channel lanes issued 8)
-__device__ __forceinline__ void epi_store8(const PlGatherParams& p, size_t px, int n, float4 v0, float4 v1) {
-  v0 = epi_value4(p, px, n, v0);
-  v1 = epi_value4(p, px, n + 4, v1);
-  store_planes8(p.pl, px, n, v0, v1);
-}
-
-// Split-K without a second kernel (tiles with few slices): after its partial tile is stored, a block takes a ticket on its
-// tile's counter; the block that draws nsplit - 1 (every slice of the tile is then in memory) sums the nsplit partial tiles
-// in slice order — the result does not depend on which block arrives last, and equals the separate reduce kernel's bit for
-// bit — and applies the epilogue.  Hand-off (cdna_hip_programming.md §5 / §6 G16, write-through form): partial tiles are
-// stored with sc1 (write-through) 16-byte buffer stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 relaxed
-// agent-scope ticket; the last arriver reads the slabs with sc1 loads (served by L2 / fabric, never a stale L1 line).
-// No cache-wide fence: a release fence per block (buffer_wbl2) made every split launch ~40 us slower than the separate
-// reduce pass it was meant to replace.  Correct for any placement of a tile's slices over CUs / XCDs.  The counters are
-// zeroed by a memset node ahead of the launch.  Returns true in the block that has to reduce (all threads, after a barrier).
-__device__ __forceinline__ bool splitk_last_arriver(const PlGatherParams& p, int tile_id, int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  return *flag == p.nsplit - 1;
-}
-
-constexpr int AUX_SC1 = 16;    // cache-policy bits of the raw buffer intrinsics: sc1 = write-through store / L1-bypassing load
-
-// the last arriver's pass over its BM x BN tile: fixed-order sum of the partials + epilogue; EU float4 per thread in flight
-// per slice (a single block has to keep >= 8-16 loads per lane outstanding to read the slabs at a useful rate)
-template <int BM, int BN>
-__device__ __forceinline__ void splitk_tile_reduce(const PlGatherParams& p, const int* pix, int n0) {
-  constexpr int QPR = BN / 4;
-  constexpr int PER = BM * QPR / 256;              // float4 per thread: 16 / 8 / 4
-  constexpr int EU = PER < 4 ? PER : 4;
-  const size_t slab_f = (size_t)p.B * p.Hd * p.Wd * p.N;      // floats per split
-  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.partial, slab_f * 4 * (size_t)p.nsplit);
-  const int slab_b = (int)(slab_f * 4);
-#pragma unroll 1
-  for (int e0 = 0; e0 < PER; e0 += EU) {
-    int off[EU], px[EU], nn[EU];
-    float4 v[EU];
-#pragma unroll
-    for (int u = 0; u < EU; u++) {
-      const int e = threadIdx.x + 256 * (e0 + u);
-      const int row = e / QPR;
-      nn[u] = n0 + 4 * (e % QPR);
-      px[u] = pix[row];
-      const bool ok = px[u] >= 0 && nn[u] < p.N;
-      off[u] = ok ? (px[u] * p.N + nn[u]) * 4 : OOB_MARK;       // out of range: zeros, and the store below is skipped
-      if (!ok) px[u] = -1;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll 4
-    for (int s2 = 0; s2 < p.nsplit; s2++) {
-#pragma unroll
-      for (int u = 0; u < EU; u++) {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], s2 * slab_b, AUX_SC1);
-        v[u].x += __uint_as_float(t.x); v[u].y += __uint_as_float(t.y);
-        v[u].z += __uint_as_float(t.z); v[u].w += __uint_as_float(t.w);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < EU; u++)
-      if (px[u] >= 0) epi_store4(p, (size_t)px[u], nn[u], v[u]);
-  }
-}
-
-// Epilogue shared by the gather kernels: bias / leaky-ReLU / accumulate / leaky derivative, fp32 result + output planes, or
-// the split-K partial.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int WM, int WN>
-__device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x16 (&acc)[WM / 32][WN / 32], const int* pix,
-                                                   unsigned short* smem16, int wm, int wn, int wid, int lane, int n0,
-                                                   int split) {
-  constexpr int TM = WM / 32, TN = WN / 32;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const bool to_partial = p.nsplit > 1;
-  if (p.vec_epi) {
-    // Through LDS (free after the K loop; wave-private areas, no barrier): the accumulator layout — lane = column, 16
-    // scattered rows — becomes lane = (row, 4 consecutive columns), so that every global access of the epilogue is a
-    // 16-byte one (fp32) or an 8-byte one (each output plane) covering 256 / 128 contiguous bytes per row.  With one
-    // dword + three 2-byte stores per ELEMENT the epilogue was store-issue bound: conv2's data gradient (25 M outputs)
-    // took 614 us instead of 290.
-    constexpr int EP = WN + 4;                 // staging row pitch (floats)
-    constexpr int QPR = WN / 4, RPI = 64 / QPR;
-    float* stg = reinterpret_cast<float*>(smem16) + wid * (32 * EP);
-    const size_t npix_d = (size_t)p.B * p.Hd * p.Wd;
-    const __amdgpu_buffer_rsrc_t part_rs = make_rsrc(p.partial, to_partial ? npix_d * p.N * 4 * (size_t)p.nsplit : 0);
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-      for (int j = 0; j < TN; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + j * 32 + l31] = acc[i][j][r];
-      if (!to_partial) {
-        // final values: a lane owns 8 consecutive channels of a row (two 16-byte fp32 stores, one 16-byte store per plane)
-        constexpr int OPR = WN / 8, RPI8 = 64 / OPR;
-#pragma unroll
-        for (int it = 0; it < 32 / RPI8; it++) {
-          const int rr = it * RPI8 + lane / OPR, q = lane % OPR;
-          const float4 v0 = *reinterpret_cast<const float4*>(stg + rr * EP + 8 * q);
-          const float4 v1 = *reinterpret_cast<const float4*>(stg + rr * EP + 8 * q + 4);
-          const int px = pix[wm * WM + i * 32 + rr];
-          const int n = n0 + wn * WN + 8 * q;
-          if (px < 0 || n >= p.N) continue;
-          if (n + 8 <= p.N) epi_store8(p, (size_t)px, n, v0, v1);
-          else epi_store4(p, (size_t)px, n, v0);          // (N % 4 == 0: the first half is whole)
-        }
-        continue;
-      }
-#pragma unroll
-      for (int it = 0; it < 32 / RPI; it++) {
-        const int rr = it * RPI + lane / QPR, q = lane % QPR;
-        float4 v = *reinterpret_cast<const float4*>(stg + rr * EP + 4 * q);
-        const int px = pix[wm * WM + i * 32 + rr];
-        const int n = n0 + wn * WN + 4 * q;
-        if (px < 0 || n >= p.N) continue;
-        {
-          float* dp = p.partial + ((size_t)split * npix_d + px) * p.N + n;
-          if (p.fused_splitk) {   // write-through: the last arriver of the tile reads it from L2 / fabric (splitk_last_arriver)
-            u32x4 t;
-            t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-            __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (int)(((size_t)px * p.N + n) * 4), split * (int)(npix_d * p.N * 4), AUX_SC1);
-          } else {
-            *reinterpret_cast<float4*>(dp) = v;
-          }
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int px = pix[row];
-      if (px < 0) continue;
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        if (n >= p.N) continue;
-        float v = acc[i][j][r];
-        if (to_partial) {
-          p.partial[((size_t)split * ((size_t)p.B * p.Hd * p.Wd) + px) * p.N + n] = v;
-        } else {
-          v *= p.src_inv;
-          if (p.bias) v += p.bias[n];
-          if (p.leaky) v = leaky_relu(v);
-          float* d = p.dst + (size_t)px * p.ldd + n;
-          if (p.accumulate) v += *d;
-          if (n >= p.act_lo && n < p.act_hi) {
-            if (p.act_src) v *= leaky_grad_from_out(p.act_src[(size_t)px * p.ld_act + n]);
-            else if (p.act_pl) v *= leaky_grad_from_bits(p.act_pl[(size_t)px * p.ld_act + n]);
-          }
-          if (p.dst) *d = v;
-          store_planes(p.pl, (size_t)px, n, v);
-        }
-      }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ gather kernel
 // 256 threads = 4 waves.  Loads: thread (kq = tid & 3, r = tid >> 2) fetches granule kq (8 consecutive k) of rows r, r + 64
@@ -809,8 +516,6 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_gather_pp_kernel(const PlGath
 // Tile = 4 rows x 32 sites: an MFMA sub-tile (32 lanes) is 32 CONSECUTIVE halo pixels, which with the 80-byte pitch makes
 // every 16-lane group of a ds_read_b128 hit 16 distinct 16-byte bank slots (an 8 x 16 tile puts two image rows into one
 // sub-tile: SQ_LDS_BANK_CONFLICT was 85 % of the LDS-active cycles).
-constexpr int TH = 4, TW = 32, TWL = 5;     // tile = TH x TW = 128 sites
-constexpr int HPITCH = 40;                  // 16-bit elements per halo pixel row: 32 channels + 8 pad (80 bytes)
 
 constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
   const int tiles = npl * (hp * HPITCH + bn * LDH) * 2, stage = 4 * 32 * (wn + 4) * 4;
@@ -2313,14 +2018,6 @@ int run_pl_gather_mode(PlGatherParams& p, int cfg, hipStream_t st) {
 }
 
 // ---- halo kernel: eligibility, plan, launch
-inline int pl_halo_pixels(const GatherGeom& p) {
-  int hp = 0, mty = 0, mtx = 0;
-  for (int c = 0; c < p.ncls; c++) {
-    hp = max(hp, (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1));
-    mty = max(mty, p.cls[c].nty); mtx = max(mtx, p.cls[c].ntx);
-  }
-  return p.acc ? (TH + mty - 1) * (TW + mtx - 1) : hp;      // accumulating classes share one halo image (widest row pitch)
-}
 inline bool pl_halo_ok(const GatherGeom& p) {
   const bool off = !unflow::options().halo;
   if (off || p.sm != 1 || (p.dstep != 1 && p.dstep != -1) || p.Hg < 2 * TH || p.Wg < TW || p.N <= 32) return false;
@@ -2433,6 +2130,8 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
                 (!p.pl.n_planes || p.pl.ld % 4 == 0);
     if (!p.dst && (!p.vec_epi || p.accumulate || !p.pl.n_planes)) return UNFLOW_ERR_UNSUPPORTED;   // planes-only output
   }
+  if (halo && p.vec_epi && pl_halo_sk_ok(p, npl, halo_bn) && ws && ws_bytes >= pl_halo_sk_ws_bytes())
+    return launch_pl_halo_sk(p, ws, ws_bytes, st);      // persistent stream-K form (conv_streamk.hip): no split, no reduce pass
   {
     // option fused_splitk = n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
     // chip-wide reduce kernel: measured on MI355X (FlowNetC 384x512 B=4) the fused form is bit-identical but not faster —
@@ -2709,6 +2408,7 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
   GatherGeom g{};
   build_conv_fwd(g, B, H, W, Ci8, Cout, k, stride);
   need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
+  if (unflow::options().streamk > 0 && n_planes == 3) need = max(need, pl_halo_sk_ws_bytes());      // slabs + flags of the stream-K kernels
   if (stride == 2 && build_conv_fwd_s2acc(g, B, H, W, Ci8, Cout, k) && pl_halo_acc_pays(g))
     need = max(need, pl_gather_partial_bytes(g, pl_gather_nsplit(g, n_planes)));
   GatherGeom d{};

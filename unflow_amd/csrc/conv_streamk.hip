@@ -1,0 +1,426 @@
+// Persistent stream-K form of the halo implicit-GEMM kernel (conv_planes.hip: igemm_pl_halo_pp_kernel) for the source-stride-1
+// layers of FlowNetC/S (src/e2eflow/core/flownet.py:89-237: 3x3 stride-1 convs, every conv data gradient incl. the four
+// output-parity classes of stride 2, conv_transpose forward).
+//
+// One 512-thread workgroup per CU for the whole launch.  The launch's work is the list of ITEMS (tap class, N tile, pair of
+// 4 x 32-site M tiles), each a K loop of nchunk 32-channel chunks x ntaps(class) K32 tiles.  The list is cut by K-tile count
+// into G equal contiguous ranges, at chunk boundaries (sk_unit) — a workgroup walks its range segment by segment:
+//     a segment that covers a whole item           -> the ordinary epilogue;
+//     a segment that does NOT start the item       -> the accumulators go to this workgroup's slab (write-through stores),
+//                                                     then its arrival flag is raised; nothing is waited for;
+//     a segment that starts an item but not ends it -> (always the LAST segment of a workgroup) the accumulators stay in
+//                                                     registers; the slabs of the workgroups that hold the rest of the item
+//                                                     (w + 1, w + 2, ...: each computed that segment FIRST) are added in
+//                                                     workgroup order, then the ordinary epilogue runs.
+// So: no split-K reduce launch, no partial sums for the part of an item its finishing workgroup computed itself, every
+// workgroup runs the same number of K tiles (+- one chunk) whatever the tile count or the tap counts of the parity classes
+// (4 / 2 / 2 / 1 taps for a stride-2 3 x 3 data gradient), and the result is a fixed-order sum: bit-identical run to run.
+// Forward progress: only item-starting segments wait, and only for workgroups with a HIGHER logical id, whose awaited
+// segment is their first and waits for nothing; the grid is <= the CU count (one workgroup per CU by LDS), so every
+// workgroup becomes resident without any other one having to finish.  Every spin is bounded (g_sk_timeouts).
+// Hand-off (cdna_hip_programming.md §5 / Guideline 16, write-through form): 16-byte sc1 stores -> s_waitcnt vmcnt(0) in
+// every wave -> workgroup barrier -> relaxed agent-scope flag store; the reader polls relaxed, passes a barrier, and reads
+// the slab with sc1 loads (served by L2 / fabric, never a stale L1 line).  Flags are zeroed by a memset node ahead of the launch.
+#include "planes_shared.h"
+
+namespace {
+using namespace igemm;
+
+__device__ int g_sk_timeouts;      // spins that gave up (a result is then wrong; the tests assert 0)
+
+struct SkPlan {
+  int G;                   // persistent workgroups
+  int ipc;                 // items per tap class = mtp * nt
+  int mtp;                 // M tile pairs
+  int nchunk;              // 32-channel chunks per item
+  int ntaps[4];            // K tiles per chunk, by class
+  unsigned wpre[5];        // K tiles before class c in the item list (wpre[ncls] = all)
+  int* flags;              // [G] arrival flags of the slabs
+  float* slabs;            // [G][2 instances][4 waves][16 float4 rows][64 lanes] float4
+};
+
+constexpr int SK_SLAB_BYTES = 2 * 4 * 16 * 64 * 16;       // 128 KB per workgroup
+constexpr int SK_SPIN_LIMIT = 1 << 22;
+
+// first chunk unit (item * nchunk + chunk) of workgroup w's range; w >= G: one past the last unit
+__host__ __device__ __forceinline__ int sk_unit(const SkPlan& s, int ncls, int w) {
+  if (w >= s.G) return ncls * s.ipc * s.nchunk;
+  const unsigned pos = (unsigned)(((unsigned long long)s.wpre[ncls] * (unsigned)w) / (unsigned)s.G);
+  int c = 0;
+  while (c + 1 < ncls && pos >= s.wpre[c + 1]) c++;
+  const unsigned rem = pos - s.wpre[c];
+  const unsigned per_item = (unsigned)(s.nchunk * s.ntaps[c]);
+  const unsigned item = rem / per_item;
+  const unsigned chunk = (rem - item * per_item) / (unsigned)s.ntaps[c];
+  return (int)((c * s.ipc + item) * s.nchunk + chunk);
+}
+
+template <int NPL, bool F16>
+__global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGatherParams p, const SkPlan sk, int HPmax) {
+  constexpr int BM = 128, BN = 128, WM = 64, WN = 64;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDP = 32;
+  constexpr int B_PLANE = BN * LDP, B_TILE = NPL * B_PLANE;
+  constexpr int NH = 4;
+  constexpr int NT = NPL == 3 ? 6 : 1;
+  static_assert(NPL == 3 && !F16, "bf16 x 3 only");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_all[];
+  const int inst = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+  const int H_PLANE = HPmax * HPITCH;
+  unsigned short* Hh = smem_all + inst * NPL * H_PLANE;
+  unsigned short* Bbase = smem_all + 2 * NPL * H_PLANE;
+  int* pix = reinterpret_cast<int*>(smem_all + 2 * NPL * H_PLANE + 2 * B_TILE) + inst * BM;
+
+  const int wm = wid >> 1, wn = wid & 1;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x, p.xcd);          // logical id: an XCD runs a contiguous run of the item list
+  const int u_begin = sk_unit(sk, p.ncls, wg), u_end = sk_unit(sk, p.ncls, wg + 1);
+  if (u_begin >= u_end) return;
+
+  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; pl++) {
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
+    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
+  }
+  const __amdgpu_buffer_rsrc_t slab_rs = make_rsrc(sk.slabs, (size_t)sk.G * SK_SLAB_BYTES);
+  const int kq = tid & 3;
+  const int lds2 = p.lds * 2;
+  const int Cg = p.Cs >> 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b_r = 64 * inst + (tid >> 2);       // this instance's half of the weight tile
+  const int b_rd = (wn * WN + l31) * LDP;
+  const int gsw = lh ^ ((l31 >> 2) & 3);
+  const int slab_lane = ((inst * 4 + wid) * 16 * 64 + lane) * 16;       // byte offset of this lane's first float4 in a slab
+  auto swz = [](int row, int g) { return row * LDP + 8 * (g ^ ((row >> 2) & 3)); };
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#pragma unroll 1
+  for (int u = u_begin; u < u_end;) {
+    // ---- the segment: item (class, N tile, M tile pair), chunks [ch0, ch1)
+    const int item = u / sk.nchunk;
+    const int ch0 = u - item * sk.nchunk;
+    const int ch1 = min(sk.nchunk, ch0 + (u_end - u));
+    u += ch1 - ch0;
+    const int cls_id = item / sk.ipc;
+    const int irem = item - cls_id * sk.ipc;
+    const int ntile = irem / sk.mtp;
+    int t = 2 * (irem - ntile * sk.mtp) + inst;
+    const bool tile_ok = t < p.B * p.tiles_y * p.tiles_x;
+    const TapClass tc = p.cls[cls_id];
+    const int n0 = ntile * BN;
+    const int T = (ch1 - ch0) * tc.nty * tc.ntx;
+    const int txi = t % p.tiles_x; t /= p.tiles_x;
+    const int tyi = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    const int HC = TW + tc.ntx - 1;
+
+    __syncthreads();       // the previous segment's epilogue is done with the LDS staging areas and the pixel table
+    int h_off[NH];
+    {
+      const int dmy = p.dstep > 0 ? tc.dy0 : tc.dy0 - (tc.nty - 1);
+      const int dmx = p.dstep > 0 ? tc.dx0 : tc.dx0 - (tc.ntx - 1);
+      const int HRc = TH + tc.nty - 1;
+#pragma unroll
+      for (int j = 0; j < NH; j++) {
+        const int hp = (tid >> 2) + 64 * j;
+        const int hy = hp / HC, hx = hp - hy * HC;
+        const int y = (y0 + hy) * p.sp + dmy, x = (x0 + hx) * p.sp + dmx;
+        const bool ok = tile_ok && hy < HRc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+        h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
+      }
+    }
+    if (tid < BM) {
+      const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
+      pix[tid] = (tile_ok && yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px : -1;
+    }
+    const int b_row = n0 + b_r < p.N ? (n0 + b_r) * p.Cs * 2 + kq * 16 : OOB_MARK;
+
+    // walkers over the segment's K tiles (chunk-major, then tap): L = the tile the next load_b() requests, M = the tile multiplied
+    int l_chunk = ch0, l_ty = 0, l_tx = 0, l_left = T;
+    int m_ty = 0, m_tx = 0;
+    u32x4 rh[NH][NPL], rb[NPL];
+    auto load_b = [&]() {
+      const int widx = (tc.ky0 + l_ty * p.kstep) * p.KW + tc.kx0 + l_tx * p.kstep;
+      const bool ok = l_left > 0 && l_chunk * 4 + kq < Cg;
+      const int voff = ok ? b_row + widx * p.N * p.Cs * 2 + l_chunk * 64 : OOB_MARK;
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) rb[pl] = buf_ld16(w_rs[pl], voff);
+    };
+    auto load_h = [&]() {
+      const bool okc = l_left > 0 && l_chunk * 4 + kq < Cg;
+#pragma unroll
+      for (int j = 0; j < NH; j++) {
+        const int voff = okc ? h_off[j] + l_chunk * 64 : OOB_MARK;
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) rh[j][pl] = buf_ld16(src_rs[pl], voff);
+      }
+    };
+    auto l_advance = [&]() {
+      l_tx++;
+      if (l_tx == tc.ntx) { l_tx = 0; l_ty++; }
+      if (l_ty == tc.nty) { l_ty = 0; l_chunk++; }
+      l_left--;
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) *reinterpret_cast<u32x4*>(Bbase + buf * B_TILE + pl * B_PLANE + swz(b_r, kq)) = rb[pl];
+    };
+    auto store_h = [&]() {
+#pragma unroll
+      for (int j = 0; j < NH; j++) {
+        const int hp = (tid >> 2) + 64 * j;
+        if (hp < HPmax) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; pl++) *reinterpret_cast<u32x4*>(Hh + pl * H_PLANE + hp * HPITCH + kq * 8) = rh[j][pl];
+        }
+      }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    int a_rd[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      const int sidx = wm * WM + i * 32 + l31;
+      a_rd[i] = ((sidx >> TWL) * HC + (sidx & (TW - 1))) * HPITCH + lh * 8;
+    }
+    const int c_hy0 = p.dstep > 0 ? 0 : tc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : tc.ntx - 1;
+
+    s16x8 av[TM][NPL], bv[TN][NPL];
+    auto read_frags = [&](int buf, int slab) {
+      const int tapoff = ((c_hy0 + m_ty * p.dstep) * HC + c_hx0 + m_tx * p.dstep) * HPITCH;
+#pragma unroll
+      for (int pl = 0; pl < NPL; pl++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          bv[j][pl] = *reinterpret_cast<const s16x8*>(Bbase + buf * B_TILE + pl * B_PLANE + b_rd + j * 32 * LDP + 8 * (gsw ^ (2 * slab)));
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+          av[i][pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
+      }
+    };
+    auto multiply = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tt = 0; tt < NT; tt++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], tt);
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- K loop of the segment (the slot schedule of igemm_pl_halo_pp_kernel; T > 0 always)
+    load_h();
+    load_b();
+    l_advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_h();
+    store_b(0);
+    bool h_pending = l_left > 0 && l_ty == 0 && l_tx == 0;
+    if (h_pending) load_h();
+    load_b();
+    l_advance();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot_end();
+    if (inst == 1) slot_end();
+#pragma unroll 1
+    for (int kk = 0; kk < T; kk++) {
+      // read slot 0: slab 0 of tile kk; tile kk + 1's weights -> the other buffer; request tile kk + 2
+      read_frags(kk & 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_b((kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool store_halo_now = h_pending;
+      const bool next_opens = l_left > 0 && l_ty == 0 && l_tx == 0;
+      load_b();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot_end();
+      multiply();                                               // slab 0
+      slot_end();
+      // read slot 1: slab 1 of tile kk
+      read_frags(kk & 1, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every halo read of this tile has returned
+      slot_end();
+      if (store_halo_now) {                                     // the old chunk is done: its successor's halo -> LDS
+        store_h();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      h_pending = false;
+      if (next_opens) {
+        load_h();
+        h_pending = true;
+      }
+      l_advance();
+      __builtin_amdgcn_sched_barrier(0);
+      multiply();                                               // slab 1
+      slot_end();
+      m_tx++;
+      if (m_tx == tc.ntx) { m_tx = 0; m_ty++; }
+      if (m_ty == tc.nty) m_ty = 0;
+    }
+    if (inst == 0) slot_end();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the zero loads past the last tile
+    __syncthreads();                                            // both instances are done with the LDS tiles
+
+    if (ch0 > 0) {
+      // ---- not the start of its item: accumulators -> this workgroup's slab, raise the flag, go on
+      const int soff = wg * SK_SLAB_BYTES;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; r4++) {
+            u32x4 v;
+            v.x = __float_as_uint(acc[i][j][4 * r4]); v.y = __float_as_uint(acc[i][j][4 * r4 + 1]);
+            v.z = __float_as_uint(acc[i][j][4 * r4 + 2]); v.w = __float_as_uint(acc[i][j][4 * r4 + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, slab_rs, slab_lane + (((i * TN + j) * 4 + r4) * 64) * 16, soff, AUX_SC1);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(sk.flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (ch1 < sk.nchunk) {
+      // ---- starts its item but does not end it: add the slabs of the workgroups that hold the rest, in workgroup order
+      const int item_end = (item + 1) * sk.nchunk;
+#pragma unroll 1
+      for (int w2 = wg + 1; w2 < sk.G; w2++) {
+        const int ua = sk_unit(sk, p.ncls, w2);
+        if (ua >= item_end) break;
+        if (sk_unit(sk, p.ncls, w2 + 1) <= ua) continue;         // an empty range: holds nothing
+        if (threadIdx.x == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(sk.flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > SK_SPIN_LIMIT) { atomicAdd(&g_sk_timeouts, 1); break; }
+          }
+        }
+        __syncthreads();
+        const int soff = w2 * SK_SLAB_BYTES;
+        u32x4 v[TM * TN * 4];
+#pragma unroll
+        for (int q = 0; q < TM * TN * 4; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(slab_rs, slab_lane + q * 64 * 16, soff, AUX_SC1);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+              const u32x4 t4 = v[(i * TN + j) * 4 + r4];
+              acc[i][j][4 * r4] += __uint_as_float(t4.x); acc[i][j][4 * r4 + 1] += __uint_as_float(t4.y);
+              acc[i][j][4 * r4 + 2] += __uint_as_float(t4.z); acc[i][j][4 * r4 + 3] += __uint_as_float(t4.w);
+            }
+      }
+    }
+    if (tile_ok) pl_gather_epilogue<WM, WN>(p, acc, pix, smem_all + inst * (4 * 32 * (WN + 4) * 2), wm, wn, wid, lane, n0, 0);
+  }
+}
+
+}  // namespace
+
+namespace igemm {
+
+// LDS of the stream-K halo kernel = the ping-pong halo kernel's: two private halos, the shared double-buffered weight tile, two pixel tables
+int pl_halo_sk_smem(const GatherGeom& p) { return 2 * 3 * pl_halo_pixels(p) * HPITCH * 2 + 2 * 3 * 128 * 32 * 2 + 2 * 128 * 4; }
+
+static int sk_workgroups() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+size_t pl_halo_sk_ws_bytes() { return (size_t)sk_workgroups() * SK_SLAB_BYTES + (size_t)sk_workgroups() * sizeof(int) + 256; }
+
+bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn) {
+  const int o = unflow::options().streamk;
+  if (o <= 0 || npl != 3 || bn != 128 || p.acc || pl_halo_sk_smem(p) > 160 * 1024) return false;
+  long ktiles = 0;
+  const long mtp = ((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) + 1) / 2;
+  const int nchunk = ((p.Cs >> 3) + 3) >> 2;
+  for (int c = 0; c < p.ncls; c++) ktiles += mtp * cdiv(p.N, 128) * nchunk * p.cls[c].nty * p.cls[c].ntx;
+  if (ktiles * sk_workgroups() >= (1L << 31)) return false;
+  // a launch with fewer chunk units than workgroups leaves CUs idle: the one-shot kernels split finer there
+  return o >= 2 || mtp * cdiv(p.N, 128) * p.ncls * nchunk >= 2L * sk_workgroups();
+}
+
+int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!ws || ws_bytes < pl_halo_sk_ws_bytes()) return UNFLOW_ERR_WORKSPACE;
+  const int hp = pl_halo_pixels(p);
+  const int smem = pl_halo_sk_smem(p);
+  static int smem_set = 0;
+  if (smem > smem_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    smem_set = smem;
+  }
+  PlGatherParams q = p;
+  q.nsplit = 1; q.partial = nullptr; q.fused_splitk = 0; q.counters = nullptr;
+  SkPlan sk{};
+  sk.G = sk_workgroups();
+  sk.mtp = cdiv((long)p.B * p.tiles_y * p.tiles_x, 2);
+  sk.ipc = sk.mtp * cdiv(p.N, 128);
+  sk.nchunk = ((p.Cs >> 3) + 3) >> 2;
+  unsigned pre = 0;
+  for (int c = 0; c < 4; c++) {
+    sk.wpre[c] = pre;
+    sk.ntaps[c] = c < p.ncls ? p.cls[c].nty * p.cls[c].ntx : 1;
+    if (c < p.ncls) pre += (unsigned)sk.ipc * sk.nchunk * sk.ntaps[c];
+  }
+  for (int c = p.ncls; c <= 4; c++) sk.wpre[c] = pre;
+  sk.slabs = reinterpret_cast<float*>(ws);
+  sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)sk.G * SK_SLAB_BYTES);
+  if (hipMemsetAsync(sk.flags, 0, (size_t)sk.G * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  igemm_pl_halo_sk_kernel<3, false><<<sk.G, 512, smem, st>>>(q, sk, hp);
+  return launch_status();
+}
+
+}  // namespace igemm
+
+UNFLOW_API int unflow_debug_streamk_units(int G, int items_per_class, int nchunk, int ncls, const int* ntaps, int* out) {
+  if (G <= 0 || items_per_class <= 0 || nchunk <= 0 || ncls < 1 || ncls > 4 || !ntaps || !out) return UNFLOW_ERR_SHAPE;
+  SkPlan sk{};
+  sk.G = G; sk.ipc = items_per_class; sk.nchunk = nchunk;
+  unsigned long long pre = 0;
+  for (int c = 0; c < 4; c++) {
+    sk.wpre[c] = (unsigned)pre;
+    sk.ntaps[c] = c < ncls ? ntaps[c] : 1;
+    if (c < ncls) {
+      if (ntaps[c] <= 0) return UNFLOW_ERR_SHAPE;
+      pre += (unsigned long long)items_per_class * nchunk * ntaps[c];
+    }
+  }
+  if (pre * (unsigned long long)G >= (1ull << 31)) return UNFLOW_ERR_SHAPE;
+  for (int c = ncls; c <= 4; c++) sk.wpre[c] = (unsigned)pre;
+  for (int w = 0; w <= G; w++) out[w] = sk_unit(sk, ncls, w);
+  return UNFLOW_OK;
+}
+
+// spins of the stream-K kernels that hit their bound since the last call (tests: must be 0)
+UNFLOW_API int unflow_debug_streamk_timeouts(void) {
+  int v = 0, zero = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sk_timeouts), sizeof(int)) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_timeouts), &zero, sizeof(int));
+  return v;
+}
