@@ -425,11 +425,13 @@ int unflow_flow_wgrad_batched(int n, const int* kind, const float* const* x, con
  * the padding workgroups of order 2.  Returns the grid size (out == NULL: query only). */
 int unflow_debug_work_order(int mt, int nt, int ncls, int nsplit, int order, int xcd, int* out, int out_blocks);
 
-/* Persistent stream-K halo kernel (csrc/conv_streamk.hip).  Test hook (host only, no GPU): the first chunk unit
- * (item * nchunk + chunk; items class-major) of the range of each of G workgroups, G + 1 ints (out[G] = all units), for a launch
- * of `ncls` tap classes with items_per_class items of nchunk chunks x ntaps[class] K tiles each.  Returns 0, or
- * UNFLOW_ERR_SHAPE for arguments outside the kernel's limits. */
-int unflow_debug_streamk_units(int G, int items_per_class, int nchunk, int ncls, const int* ntaps, int* out);
+/* Persistent stream-K halo kernel (csrc/conv_streamk.hip).  Test hook (host only, no GPU) for a launch of `ncls` tap classes x
+ * nt N tiles x mtp M tile pairs, every item nchunk chunks x ntaps[class] K tiles, the item list ordered M group (ngroups of
+ * them) > class > N tile > pair and laid end to end in K tiles: range_pos[w] (G + 1 ints) = the first K-tile position of
+ * workgroup w's range; decoded[4 i .. 4 i + 3] = (class, N tile, M pair, K tile inside the item) of position pos[i].  Returns 0,
+ * or UNFLOW_ERR_SHAPE for arguments outside the kernel's limits. */
+int unflow_debug_streamk_plan(int G, int mtp, int nt, int nchunk, int ncls, const int* ntaps, int ngroups, int* range_pos, int npos,
+                              const int* pos, int* decoded);
 /* ... and the number of bounded spins of those kernels that gave up since the last call (reads and clears a device counter:
  * must be 0; a result computed past a timeout is wrong). */
 int unflow_debug_streamk_timeouts(void);

@@ -1,73 +1,89 @@
-"""Work partition of the persistent stream-K halo kernel (csrc/conv_streamk.hip: sk_unit) through its host-side test hook —
-no GPU.  The kernel's correctness argument needs: the G ranges tile the unit list exactly (monotone, first = 0, last = all),
-every range is cut at a chunk boundary, ranges carry the same number of K tiles up to one chunk of the heaviest class, and a
-workgroup has at most one segment that does not start its item (its first) and at most one that starts but does not end one
-(its last)."""
+"""Work partition of the persistent stream-K halo kernel (csrc/conv_streamk.hip: sk_pos / sk_decode) through its host-side
+test hook — no GPU.  The kernel's correctness argument needs: decoding the K-tile positions 0 .. all-1 enumerates every
+(class, N tile, M pair, K tile) exactly once, items contiguous and their K tiles in order; the G ranges tile the list exactly
+and differ by at most one K tile; a workgroup has at most one segment that does not start its item (its first) and at most one
+that starts but does not end one (its last); and the workgroups such a segment waits for have HIGHER ids and hold the rest of
+that item as their first segment."""
 import ctypes
 
 import numpy as np
 import pytest
 
 
-def units(G, ipc, nchunk, ntaps):
+def plan(G, mtp, nt, nchunk, ntaps, ngroups):
     from unflow_amd import _lib
     L = _lib.lib()
-    out = (ctypes.c_int * (G + 1))()
-    rc = L.unflow_debug_streamk_units(G, ipc, nchunk, len(ntaps), (ctypes.c_int * len(ntaps))(*ntaps), out)
+    total = mtp * nt * nchunk * sum(ntaps)
+    rng = (ctypes.c_int * (G + 1))()
+    pos = (ctypes.c_int * total)(*range(total))
+    dec = (ctypes.c_int * (4 * total))()
+    rc = L.unflow_debug_streamk_plan(G, mtp, nt, nchunk, len(ntaps), (ctypes.c_int * len(ntaps))(*ntaps), ngroups, rng, total, pos, dec)
     assert rc == 0
-    return np.array(out[:])
+    return np.array(rng[:]), np.array(dec[:]).reshape(total, 4)
 
 
-# (G, items per class, chunks, taps per class): conv3_1 fwd, conv4 dgrad (4/2/2/1), conv3 dgrad (9/6/6/4), deconv3 fwd,
-# a launch with fewer units than workgroups, a single item, primes
-CASES = [(256, 192, 15, [9]), (256, 48, 16, [4, 2, 2, 1]), (256, 96, 8, [9, 6, 6, 4]), (256, 24, 25, [4, 4, 4, 4]),
-         (256, 4, 8, [9]), (256, 1, 3, [1]), (7, 13, 5, [3, 1, 2]), (256, 1000, 1, [1, 7]), (304, 17, 11, [5, 3])]
+# (G, M pairs, N tiles, chunks, taps per class, M groups): conv3_1 fwd, conv4 dgrad (4/2/2/1), conv3 dgrad (9/6/6/4), deconv3 fwd,
+# launches with fewer K tiles than workgroups, a single item, ragged last groups, class-major order (1 group)
+CASES = [(256, 96, 2, 15, [9], 8), (256, 24, 2, 16, [4, 2, 2, 1], 8), (256, 96, 1, 8, [9, 6, 6, 4], 8), (256, 24, 1, 25, [4, 4, 4, 4], 8),
+         (256, 2, 2, 8, [9], 8), (256, 1, 1, 3, [1], 8), (7, 13, 1, 5, [3, 1, 2], 4), (256, 500, 2, 1, [1, 7], 8), (304, 17, 1, 11, [5, 3], 8),
+         (256, 24, 2, 16, [4, 2, 2, 1], 1), (256, 21, 3, 4, [2, 2, 2, 2], 8), (256, 9, 1, 7, [4, 2], 5)]
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_streamk_ranges_tile_the_work(case):
-    G, ipc, nchunk, ntaps = case
-    U = units(G, ipc, nchunk, ntaps)
-    total = len(ntaps) * ipc * nchunk
-    assert U[0] == 0 and U[G] == total and np.all(np.diff(U) >= 0)
-    # K tiles per range: equal up to one chunk of the heaviest class on either side
-    w_of_unit = np.repeat(np.repeat(np.array(ntaps), ipc), nchunk)
-    cum = np.concatenate([[0], np.cumsum(w_of_unit)])
-    work = cum[U[1:]] - cum[U[:-1]]
-    ideal = cum[-1] / G
-    assert work.max() <= ideal + max(ntaps) and work.min() >= ideal - max(ntaps) - 1, (work.min(), work.max(), ideal)
+    G, mtp, nt, nchunk, ntaps, ngroups = case
+    P, D = plan(G, mtp, nt, nchunk, ntaps, ngroups)
+    total = len(D)
+    # every (class, N tile, pair, K tile) exactly once; an item's K tiles are consecutive positions, in order
+    nk = np.array(ntaps)[D[:, 0]] * nchunk
+    assert len({tuple(r) for r in D}) == total
+    assert np.all((D[:, 3] >= 0) & (D[:, 3] < nk)) and D[:, 1].max() == nt - 1 and D[:, 2].max() == mtp - 1 and D[:, 0].max() == len(ntaps) - 1
+    same = np.all(D[1:, :3] == D[:-1, :3], axis=1)
+    assert np.all(D[1:, 3][same] == D[:-1, 3][same] + 1) and np.all(D[1:, 3][~same] == 0) and np.all(D[:-1, 3][~same] == nk[:-1][~same] - 1)
+    assert P[0] == 0 and P[G] == total and np.all(np.diff(P) >= 0)
+    assert np.diff(P).max() - np.diff(P).min() <= 1                    # balanced to one K tile
+    item_start = np.arange(total) - D[:, 3]
     for w in range(G):
-        a, b = U[w], U[w + 1]
+        a, b = P[w], P[w + 1]
         if a == b:
             continue
         segs = []
-        u = a
-        while u < b:
-            item, c0 = divmod(u, nchunk)
-            c1 = min(nchunk, c0 + (b - u))
-            segs.append((item, c0, c1))
-            u += c1 - c0
+        pos = a
+        while pos < b:
+            k0 = D[pos, 3]
+            k1 = min(nk[pos], k0 + (b - pos))
+            segs.append((item_start[pos], k0, k1, nk[pos]))
+            pos += k1 - k0
         not_start = [s for s in segs if s[1] > 0]
-        start_not_end = [s for s in segs if s[1] == 0 and s[2] < nchunk]
+        start_not_end = [s for s in segs if s[1] == 0 and s[2] < s[3]]
         assert len(not_start) <= 1 and (not not_start or not_start[0] == segs[0])
         assert len(start_not_end) <= 1 and (not start_not_end or start_not_end[0] == segs[-1])
-        # the workgroups an item-starting, unfinished segment waits for all have a HIGHER id and hold that item FIRST
-        for item, c0, c1 in start_not_end:
-            end = (item + 1) * nchunk
+        for start, k0, k1, n in start_not_end:
+            end = start + n
+            covered = start + k1
             w2 = w + 1
-            covered = c1 + item * nchunk
-            while w2 < G and U[w2] < end:
-                if U[w2 + 1] > U[w2]:
-                    assert U[w2] == covered and U[w2] // nchunk == item and U[w2] % nchunk > 0
-                    covered = min(end, U[w2 + 1])
+            while w2 < G and P[w2] < end:
+                if P[w2 + 1] > P[w2]:
+                    assert P[w2] == covered and item_start[P[w2]] == start and D[P[w2], 3] > 0
+                    covered = min(end, P[w2 + 1])
                 w2 += 1
             assert covered == end
+
+
+def test_streamk_groups_keep_the_classes_of_a_tile_together():
+    """8 M groups: the eighth of the list an XCD's workgroups walk holds every class and N tile of ITS M pairs only."""
+    G, mtp, nt, nchunk, ntaps = 256, 24, 2, 16, [4, 2, 2, 1]
+    P, D = plan(G, mtp, nt, nchunk, ntaps, 8)
+    for x in range(8):
+        its = D[P[32 * x]:P[32 * (x + 1)]]
+        assert set(its[:, 2]) == {3 * x, 3 * x + 1, 3 * x + 2}
+        assert set(its[:, 0]) == {0, 1, 2, 3} and set(its[:, 1]) == {0, 1}
 
 
 def test_streamk_hook_rejects_bad_arguments():
     from unflow_amd import _lib
     L = _lib.lib()
     out = (ctypes.c_int * 9)()
-    assert L.unflow_debug_streamk_units(8, 4, 4, 5, (ctypes.c_int * 5)(1, 1, 1, 1, 1), out) != 0
-    assert L.unflow_debug_streamk_units(8, 4, 4, 1, (ctypes.c_int * 1)(0), out) != 0
-    assert L.unflow_debug_streamk_units(256, 1 << 20, 64, 1, (ctypes.c_int * 1)(9), out) != 0      # K tiles x G overflows 31 bits
+    assert L.unflow_debug_streamk_plan(8, 4, 1, 4, 5, (ctypes.c_int * 5)(1, 1, 1, 1, 1), 1, out, 0, None, None) != 0
+    assert L.unflow_debug_streamk_plan(8, 4, 1, 4, 1, (ctypes.c_int * 1)(0), 1, out, 0, None, None) != 0
+    assert L.unflow_debug_streamk_plan(256, 1 << 20, 1, 64, 1, (ctypes.c_int * 1)(9), 8, out, 0, None, None) != 0      # overflows 31 bits

@@ -3,8 +3,8 @@
 // output-parity classes of stride 2, conv_transpose forward).
 //
 // One 512-thread workgroup per CU for the whole launch.  The launch's work is the list of ITEMS (tap class, N tile, pair of
-// 4 x 32-site M tiles), each a K loop of nchunk 32-channel chunks x ntaps(class) K32 tiles.  The list is cut by K-tile count
-// into G equal contiguous ranges, at chunk boundaries (sk_unit) — a workgroup walks its range segment by segment:
+// 4 x 32-site M tiles), each a K loop of nchunk 32-channel chunks x ntaps(class) K32 tiles.  The list, laid end to end in K
+// tiles, is cut into G equal contiguous ranges (+- one K tile: sk_pos) — a workgroup walks its range segment by segment:
 //     a segment that covers a whole item           -> the ordinary epilogue;
 //     a segment that does NOT start the item       -> the accumulators go to this workgroup's slab (write-through stores),
 //                                                     then its arrival flag is raised; nothing is waited for;
@@ -13,7 +13,7 @@
 //                                                     (w + 1, w + 2, ...: each computed that segment FIRST) are added in
 //                                                     workgroup order, then the ordinary epilogue runs.
 // So: no split-K reduce launch, no partial sums for the part of an item its finishing workgroup computed itself, every
-// workgroup runs the same number of K tiles (+- one chunk) whatever the tile count or the tap counts of the parity classes
+// workgroup runs the same number of K tiles (+- one) whatever the tile count or the tap counts of the parity classes
 // (4 / 2 / 2 / 1 taps for a stride-2 3 x 3 data gradient), and the result is a fixed-order sum: bit-identical run to run.
 // Forward progress: only item-starting segments wait, and only for workgroups with a HIGHER logical id, whose awaited
 // segment is their first and waits for nothing; the grid is <= the CU count (one workgroup per CU by LDS), so every
@@ -30,11 +30,13 @@ __device__ int g_sk_timeouts;      // spins that gave up (a result is then wrong
 
 struct SkPlan {
   int G;                   // persistent workgroups
-  int ipc;                 // items per tap class = mtp * nt
+  int ncls;                // tap classes
+  int nt;                  // N tiles
   int mtp;                 // M tile pairs
+  int ng, mg, mlast;       // the M tile pairs are cut into ng groups of mg (the last one: mlast) — one group ~ one XCD's share
   int nchunk;              // 32-channel chunks per item
   int ntaps[4];            // K tiles per chunk, by class
-  unsigned wpre[5];        // K tiles before class c in the item list (wpre[ncls] = all)
+  unsigned wfull, wall;    // K tiles of a full group / of the launch
   int* flags;              // [G] arrival flags of the slabs
   float* slabs;            // [G][2 instances][4 waves][16 float4 rows][64 lanes] float4
 };
@@ -42,17 +44,50 @@ struct SkPlan {
 constexpr int SK_SLAB_BYTES = 2 * 4 * 16 * 64 * 16;       // 128 KB per workgroup
 constexpr int SK_SPIN_LIMIT = 1 << 22;
 
-// first chunk unit (item * nchunk + chunk) of workgroup w's range; w >= G: one past the last unit
-__host__ __device__ __forceinline__ int sk_unit(const SkPlan& s, int ncls, int w) {
-  if (w >= s.G) return ncls * s.ipc * s.nchunk;
-  const unsigned pos = (unsigned)(((unsigned long long)s.wpre[ncls] * (unsigned)w) / (unsigned)s.G);
+// The item list, in the order the workgroups walk it: M group (slowest) > tap class > N tile > M tile pair of the group.
+// The workgroups of an XCD hold a contiguous eighth of the list = (about) one M group with ALL its classes and N tiles: the
+// parity classes of a tile read the same source pixels and write interleaved pixels of the same destination rows, so they
+// belong on one L2 at one time (class-major over the whole launch cost the stride-2 data gradients 10 %).
+// First K-tile position of workgroup w's range (w = G: the end of the list).
+__host__ __device__ __forceinline__ unsigned sk_pos(const SkPlan& s, int w) {
+  return w >= s.G ? s.wall : (unsigned)(((unsigned long long)s.wall * (unsigned)w) / (unsigned)s.G);
+}
+
+// K-tile position -> the item it lies in (class, N tile, M tile pair) and its K tile inside that item
+__host__ __device__ __forceinline__ void sk_decode(const SkPlan& s, unsigned pos, int& cls, int& ntile, int& mp, int& k) {
+  unsigned g = pos / s.wfull;
+  if (g > (unsigned)(s.ng - 1)) g = (unsigned)(s.ng - 1);
+  unsigned rem = pos - g * s.wfull;
+  const unsigned sz = (unsigned)(g == (unsigned)(s.ng - 1) ? s.mlast : s.mg);
+  const unsigned per_cls = sz * (unsigned)s.nt;                                   // items of one class in this group
   int c = 0;
-  while (c + 1 < ncls && pos >= s.wpre[c + 1]) c++;
-  const unsigned rem = pos - s.wpre[c];
+  while (c + 1 < s.ncls && rem >= per_cls * (unsigned)(s.nchunk * s.ntaps[c])) {
+    rem -= per_cls * (unsigned)(s.nchunk * s.ntaps[c]);
+    c++;
+  }
   const unsigned per_item = (unsigned)(s.nchunk * s.ntaps[c]);
-  const unsigned item = rem / per_item;
-  const unsigned chunk = (rem - item * per_item) / (unsigned)s.ntaps[c];
-  return (int)((c * s.ipc + item) * s.nchunk + chunk);
+  const unsigned it = rem / per_item;
+  const unsigned nti = it / sz;
+  cls = c;
+  ntile = (int)nti;
+  mp = (int)(g * (unsigned)s.mg + (it - nti * sz));
+  k = (int)(rem - it * per_item);
+}
+
+// host: fill the partition fields (G, ncls, nt, mtp, nchunk, ntaps given); false: outside the 31-bit arithmetic of sk_pos
+static bool sk_fill(SkPlan& s, int ngroups) {
+  if (ngroups < 1) ngroups = 1;
+  s.mg = (s.mtp + ngroups - 1) / ngroups;
+  s.ng = (s.mtp + s.mg - 1) / s.mg;
+  s.mlast = s.mtp - (s.ng - 1) * s.mg;
+  unsigned long long tapsum = 0;
+  for (int c = 0; c < s.ncls; c++) tapsum += (unsigned long long)s.ntaps[c];
+  const unsigned long long per_pair = (unsigned long long)s.nt * s.nchunk * tapsum;
+  const unsigned long long all = per_pair * (unsigned long long)s.mtp;
+  if (all == 0 || all * (unsigned long long)s.G >= (1ull << 31)) return false;
+  s.wfull = (unsigned)(per_pair * (unsigned long long)s.mg);
+  s.wall = (unsigned)all;
+  return true;
 }
 
 template <int NPL, bool F16>
@@ -75,8 +110,8 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
 
   const int wm = wid >> 1, wn = wid & 1;
   const int wg = xcd_remap(blockIdx.x, gridDim.x, p.xcd);          // logical id: an XCD runs a contiguous run of the item list
-  const int u_begin = sk_unit(sk, p.ncls, wg), u_end = sk_unit(sk, p.ncls, wg + 1);
-  if (u_begin >= u_end) return;
+  const unsigned pos_begin = sk_pos(sk, wg), pos_end = sk_pos(sk, wg + 1);
+  if (pos_begin >= pos_end) return;
 
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
@@ -101,20 +136,20 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
   };
 
 #pragma unroll 1
-  for (int u = u_begin; u < u_end;) {
-    // ---- the segment: item (class, N tile, M tile pair), chunks [ch0, ch1)
-    const int item = u / sk.nchunk;
-    const int ch0 = u - item * sk.nchunk;
-    const int ch1 = min(sk.nchunk, ch0 + (u_end - u));
-    u += ch1 - ch0;
-    const int cls_id = item / sk.ipc;
-    const int irem = item - cls_id * sk.ipc;
-    const int ntile = irem / sk.mtp;
-    int t = 2 * (irem - ntile * sk.mtp) + inst;
-    const bool tile_ok = t < p.B * p.tiles_y * p.tiles_x;
+  for (unsigned pos = pos_begin; pos < pos_end;) {
+    // ---- the segment: K tiles [k0, k1) of item (class, N tile, M tile pair)
+    int cls_id, ntile, mpair, k0;
+    sk_decode(sk, pos, cls_id, ntile, mpair, k0);
     const TapClass tc = p.cls[cls_id];
+    const int ntaps = tc.nty * tc.ntx;
+    const int nk = sk.nchunk * ntaps;
+    const int k1 = min(nk, k0 + (int)(pos_end - pos));
+    const unsigned item_end = pos - (unsigned)k0 + (unsigned)nk;      // K-tile position one past this item
+    pos += (unsigned)(k1 - k0);
+    int t = 2 * mpair + inst;
+    const bool tile_ok = t < p.B * p.tiles_y * p.tiles_x;
     const int n0 = ntile * BN;
-    const int T = (ch1 - ch0) * tc.nty * tc.ntx;
+    const int T = k1 - k0;
     const int txi = t % p.tiles_x; t /= p.tiles_x;
     const int tyi = t % p.tiles_y;
     const int b = t / p.tiles_y;
@@ -143,8 +178,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
     const int b_row = n0 + b_r < p.N ? (n0 + b_r) * p.Cs * 2 + kq * 16 : OOB_MARK;
 
     // walkers over the segment's K tiles (chunk-major, then tap): L = the tile the next load_b() requests, M = the tile multiplied
-    int l_chunk = ch0, l_ty = 0, l_tx = 0, l_left = T;
-    int m_ty = 0, m_tx = 0;
+    const int tap0 = k0 % ntaps;                 // a range may start in the middle of a chunk: its halo is loaded all the same
+    int l_chunk = k0 / ntaps, l_ty = tap0 / tc.ntx, l_tx = tap0 % tc.ntx, l_left = T;
+    int m_ty = l_ty, m_tx = l_tx;
     u32x4 rh[NH][NPL], rb[NPL];
     auto load_b = [&]() {
       const int widx = (tc.ky0 + l_ty * p.kstep) * p.KW + tc.kx0 + l_tx * p.kstep;
@@ -279,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the zero loads past the last tile
     __syncthreads();                                            // both instances are done with the LDS tiles
 
-    if (ch0 > 0) {
+    if (k0 > 0) {
       // ---- not the start of its item: accumulators -> this workgroup's slab, raise the flag, go on
       const int soff = wg * SK_SLAB_BYTES;
 #pragma unroll
@@ -298,14 +334,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
       if (threadIdx.x == 0) __hip_atomic_store(sk.flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
-    if (ch1 < sk.nchunk) {
+    if (k1 < nk) {
       // ---- starts its item but does not end it: add the slabs of the workgroups that hold the rest, in workgroup order
-      const int item_end = (item + 1) * sk.nchunk;
 #pragma unroll 1
       for (int w2 = wg + 1; w2 < sk.G; w2++) {
-        const int ua = sk_unit(sk, p.ncls, w2);
-        if (ua >= item_end) break;
-        if (sk_unit(sk, p.ncls, w2 + 1) <= ua) continue;         // an empty range: holds nothing
+        const unsigned pa = sk_pos(sk, w2);
+        if (pa >= item_end) break;
+        if (sk_pos(sk, w2 + 1) <= pa) continue;                  // an empty range: holds nothing
         if (threadIdx.x == 0) {
           int spins = 0;
           while (__hip_atomic_load(sk.flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -354,16 +389,28 @@ static int sk_workgroups() {
 
 size_t pl_halo_sk_ws_bytes() { return (size_t)sk_workgroups() * SK_SLAB_BYTES + (size_t)sk_workgroups() * sizeof(int) + 256; }
 
+static void sk_plan_of(const GatherGeom& p, SkPlan& sk) {
+  sk.G = sk_workgroups();
+  sk.ncls = p.ncls;
+  sk.nt = cdiv(p.N, 128);
+  sk.mtp = cdiv((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW), 2);
+  sk.nchunk = ((p.Cs >> 3) + 3) >> 2;
+  for (int c = 0; c < 4; c++) sk.ntaps[c] = c < p.ncls ? p.cls[c].nty * p.cls[c].ntx : 1;
+}
+
 bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn) {
   const int o = unflow::options().streamk;
   if (o <= 0 || npl != 3 || bn != 128 || p.acc || pl_halo_sk_smem(p) > 160 * 1024) return false;
-  long ktiles = 0;
-  const long mtp = ((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) + 1) / 2;
-  const int nchunk = ((p.Cs >> 3) + 3) >> 2;
-  for (int c = 0; c < p.ncls; c++) ktiles += mtp * cdiv(p.N, 128) * nchunk * p.cls[c].nty * p.cls[c].ntx;
-  if (ktiles * sk_workgroups() >= (1L << 31)) return false;
-  // a launch with fewer chunk units than workgroups leaves CUs idle: the one-shot kernels split finer there
-  return o >= 2 || mtp * cdiv(p.N, 128) * p.ncls * nchunk >= 2L * sk_workgroups();
+  SkPlan sk{};
+  sk_plan_of(p, sk);
+  if (!sk_fill(sk, unflow::options().streamk_groups)) return false;
+  // Where it pays (MI355X, FlowNetC 384x512 B=4, profiles/r04_streamk_per_layer.txt): single-class layers with long ranges —
+  // conv3_1 forward 288 -> 252 us, conv4_1 forward / data gradient 173 -> 153 / 173 -> 158, conv3_1 data gradient 281 -> 272.
+  // The output-parity classes of the stride-2 data gradients and of conv_transpose forward lose (conv4's data gradient
+  // 129 -> 150 us, conv3's 245 -> 277): a one-shot launch keeps two 4-wave workgroups per CU, so one's prologue / epilogue
+  // hides under the other's K loop, and its 768 uneven blocks balance themselves over 512 slots without any partial sums;
+  // one 8-wave workgroup per CU exposes every segment boundary (2.5 per workgroup there).  Option streamk = 2 forces it (tests).
+  return o >= 2 || (sk.ncls == 1 && sk.wall >= 48u * (unsigned)sk.G);
 }
 
 int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -378,17 +425,8 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
   PlGatherParams q = p;
   q.nsplit = 1; q.partial = nullptr; q.fused_splitk = 0; q.counters = nullptr;
   SkPlan sk{};
-  sk.G = sk_workgroups();
-  sk.mtp = cdiv((long)p.B * p.tiles_y * p.tiles_x, 2);
-  sk.ipc = sk.mtp * cdiv(p.N, 128);
-  sk.nchunk = ((p.Cs >> 3) + 3) >> 2;
-  unsigned pre = 0;
-  for (int c = 0; c < 4; c++) {
-    sk.wpre[c] = pre;
-    sk.ntaps[c] = c < p.ncls ? p.cls[c].nty * p.cls[c].ntx : 1;
-    if (c < p.ncls) pre += (unsigned)sk.ipc * sk.nchunk * sk.ntaps[c];
-  }
-  for (int c = p.ncls; c <= 4; c++) sk.wpre[c] = pre;
+  sk_plan_of(p, sk);
+  if (!sk_fill(sk, unflow::options().streamk_groups)) return UNFLOW_ERR_UNSUPPORTED;
   sk.slabs = reinterpret_cast<float*>(ws);
   sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)sk.G * SK_SLAB_BYTES);
   if (hipMemsetAsync(sk.flags, 0, (size_t)sk.G * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
@@ -398,22 +436,21 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
 
 }  // namespace igemm
 
-UNFLOW_API int unflow_debug_streamk_units(int G, int items_per_class, int nchunk, int ncls, const int* ntaps, int* out) {
-  if (G <= 0 || items_per_class <= 0 || nchunk <= 0 || ncls < 1 || ncls > 4 || !ntaps || !out) return UNFLOW_ERR_SHAPE;
+UNFLOW_API int unflow_debug_streamk_plan(int G, int mtp, int nt, int nchunk, int ncls, const int* ntaps, int ngroups, int* range_pos,
+                                         int npos, const int* pos, int* decoded) {
+  if (G <= 0 || mtp <= 0 || nt <= 0 || nchunk <= 0 || ncls < 1 || ncls > 4 || !ntaps || !range_pos) return UNFLOW_ERR_SHAPE;
   SkPlan sk{};
-  sk.G = G; sk.ipc = items_per_class; sk.nchunk = nchunk;
-  unsigned long long pre = 0;
+  sk.G = G; sk.ncls = ncls; sk.nt = nt; sk.mtp = mtp; sk.nchunk = nchunk;
   for (int c = 0; c < 4; c++) {
-    sk.wpre[c] = (unsigned)pre;
     sk.ntaps[c] = c < ncls ? ntaps[c] : 1;
-    if (c < ncls) {
-      if (ntaps[c] <= 0) return UNFLOW_ERR_SHAPE;
-      pre += (unsigned long long)items_per_class * nchunk * ntaps[c];
-    }
+    if (sk.ntaps[c] <= 0) return UNFLOW_ERR_SHAPE;
   }
-  if (pre * (unsigned long long)G >= (1ull << 31)) return UNFLOW_ERR_SHAPE;
-  for (int c = ncls; c <= 4; c++) sk.wpre[c] = (unsigned)pre;
-  for (int w = 0; w <= G; w++) out[w] = sk_unit(sk, ncls, w);
+  if (!sk_fill(sk, ngroups)) return UNFLOW_ERR_SHAPE;
+  for (int w = 0; w <= G; w++) range_pos[w] = (int)sk_pos(sk, w);
+  for (int i = 0; i < npos && pos && decoded; i++) {
+    if (pos[i] < 0 || (unsigned)pos[i] >= sk.wall) return UNFLOW_ERR_SHAPE;
+    sk_decode(sk, (unsigned)pos[i], decoded[4 * i], decoded[4 * i + 1], decoded[4 * i + 2], decoded[4 * i + 3]);
+  }
   return UNFLOW_OK;
 }
 
