@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the two secondary configs (BASELINE configs[3] CSS 768x1024 B=2 and configs[4] fp16 B=8: sub-processes)")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the second timing pass without the all-reduce")
+    ap.add_argument("--comm", default=None, choices=["torch", "rccl"],
+                    help="N > 1: gradient exchange through torch.distributed (backend nccl = RCCL; default) or through the library's "
+                         "own C ABI (ncclAllReduce behind unflow_allreduce_sum_f32); the other one is timed as well and reported "
+                         "in the comm record")
     ap.add_argument("--overlap-adam", action="store_true",
                     help="one rank: keep the backward cuts and run each part's L2/Adam + weight re-split on a second stream "
                          "under the remaining backward pass (what N > 1 does behind its all-reduce); default off (measured slower)")
@@ -113,7 +117,11 @@ def main():
     force_dist = os.environ.get("UNFLOW_FORCE_REDUCER") == "1" and "RANK" in os.environ   # test knob
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("NCCL_DEBUG", "").upper() == "INFO":      # the comm record quotes RCCL's algorithm / protocol lines
+        # the comm record quotes RCCL's algorithm / protocol / channel lines: INFO logging (init-time lines only) into a file
+        # per process, unless the caller chose otherwise
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,GRAPH,TUNING")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "INFO":
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/unflow_rccl_%h_%p.log")
         torch.cuda.set_device(local_rank)
         # UNFLOW_DIST_BACKEND=gloo: test knob — several ranks on ONE GPU (RCCL refuses that); same code path, other transport
@@ -141,7 +149,8 @@ def main():
     # forward + loss + backward as hipGraph replays; with more than one rank the backward pass is cut into parts, and each
     # part's gradients are all-reduced and Adam-updated on the communication stream under the rest of the backward pass
     # (unflow_amd/core/train.py).  One rank: one graph, one Adam launch.
-    runner = StepRunner(eng, world, use_graph=not args.no_graph, force_reducer=force_dist, local_overlap=args.overlap_adam)
+    runner = StepRunner(eng, world, use_graph=not args.no_graph, force_reducer=force_dist, local_overlap=args.overlap_adam,
+                        transport=args.comm)
 
     def step():
         # input preparation is part of the step (unsupervised.py:29-31,67-68): next raw minibatch -> /255, mean
@@ -337,12 +346,54 @@ def measure_comm(runner, eng, step, barrier, args, world, ms_with, dev, dist):
     ranges = [r for part in runner.buckets for r in part]
     nbytes = 4 * sum(hi - lo for lo, hi in ranges)
     sub = sum((hi - lo + red.per - 1) // red.per for lo, hi in ranges)
-    out = {"bytes_per_step": nbytes, "buckets": len(runner.buckets), "collectives_per_step": sub,
+    out = {"transport": "%s (%s)" % (red.transport, "ncclAllReduce behind unflow_allreduce_sum_f32, csrc/comm_rccl.hip" if red.rccl is not None
+                                     else "torch.distributed all_reduce, backend %s" % dist.get_backend()),
+           "bytes_per_step": nbytes, "buckets": len(runner.buckets), "collectives_per_step": sub,
            "bucket_bytes": [4 * sum(hi - lo for lo, hi in part) for part in runner.buckets],
            "sub_bucket_bytes_max": red.per * 4, "backward_parts": runner.nparts,
            "overlap": "all-reduce of a part's gradients + their fused L2/Adam + weight re-split run on a communication stream "
                       "under the remaining backward parts (unflow_amd/core/train.py)",
            "env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_DEBUG", "RCCL_MSCCL_ENABLE") if k in os.environ}}
+    # The replicas must still be bit-identical after the timed steps (same initialisation, same summed gradients, same
+    # update): a bit-level checksum of the flat parameter buffer, min and max over the ranks.  Checked BEFORE the dry pass
+    # below lets them diverge.
+    def replicas_identical():
+        chk = eng.P.view(torch.int32).sum(dtype=torch.int64).reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool((lo == hi).item())
+    out["params_identical_across_ranks"] = replicas_identical()
+    # the other transport on the same runner (same streams, buckets, graphs): K more steps
+    try:
+        if world > 1 and dist.get_backend() != "nccl":
+            raise RuntimeError("ranks share a GPU under the %s test backend: RCCL needs one GPU per rank" % dist.get_backend())
+        from unflow_amd.core.data_parallel import RcclComm
+        prev = red.rccl
+        other = None if prev is not None else RcclComm(world, dist.get_rank() if world > 1 else 0)
+        red.rccl = other
+        try:
+            for _ in range(2):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            dd = time.perf_counter() - t0
+        finally:
+            red.rccl = prev
+        if world > 1:
+            tmax = torch.tensor([dd], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dd = tmax.item()
+        out["other_transport"] = {"transport": "torch.distributed" if other is None else "rccl through the C ABI (RCCL %d)" % other.version,
+                                  "ms_per_step": round(dd / args.steps * 1e3, 4), "params_identical_across_ranks": replicas_identical()}
+        if other is not None:
+            other.close()
+    except Exception as e:
+        out["other_transport"] = "failed: %r" % (e,)
     if not args.no_comm:
         red.dry = True
         try:

@@ -92,6 +92,19 @@ def main():
         o = torch.empty(N, H // s, W // s, 3, device=dev)
         report("downsample scale=%d C=3" % s, int(npx * 12 * (1 + 1.0 / (s * s))),
                timeit(lambda: check(lib.unflow_downsample_fwd(ptr(im), ptr(o), N, H, W, 3, s, st))))
+    # forward_warp (ops/forward_warp_op.cu.cc:16-125): 12 B/px forward (flow in, splat sum out), 20 B/px backward; the work is
+    # the <= 81 taps per source pixel, not the bytes — the HBM fraction is reported all the same (DESIGN.md has the tap-rate bound)
+    fw_out = torch.empty(N, H, W, 1, device=dev)
+    fw_ws = torch.empty(npx * 2, dtype=torch.float32, device=dev)       # 64-bit fixed-point sums of the deterministic mode
+    flow_50 = (torch.rand(N, H, W, 2, generator=g) * 100 - 50).to(dev)
+    for nm, fl in (("smooth field, sigma 4 px", flow), ("i.i.d. N(0,4^2)", flow_iid), ("i.i.d. U(-50,50) px", flow_50)):
+        for det in (1, 0):
+            report("forward_warp_fwd %s, %s" % ("deterministic (64-bit fixed-point sums)" if det else "float atomics (reference contract)", nm),
+                   npx * 12, timeit(lambda: check(lib.unflow_forward_warp_fwd(ptr(fl), ptr(fw_out), N, H, W, det, ptr(fw_ws),
+                                                                              _lib.csz(fw_ws.numel() * 4), st)), reps=5))
+        report("forward_warp_bwd %s" % nm, npx * 20,
+               timeit(lambda: check(lib.unflow_forward_warp_bwd(ptr(gray1), ptr(fl), ptr(dfl), N, H, W, st)), reps=5))
+    del fw_out, fw_ws, flow_50
     n = 39_200_000
     p, gr, m, v = (torch.randn(n, generator=g).to(dev) for _ in range(4))
     v.abs_()

@@ -425,6 +425,20 @@ int unflow_flow_wgrad_batched(int n, const int* kind, const float* const* x, con
  * the padding workgroups of order 2.  Returns the grid size (out == NULL: query only). */
 int unflow_debug_work_order(int mt, int nt, int ncls, int nsplit, int order, int xcd, int* out, int out_blocks);
 
+/* ---- gradient exchange (csrc/comm_rccl.hip): replaces average_gradients, src/e2eflow/core/train.py:388-422 ----------------
+ * One process per GPU; the flat fp32 gradient buffer is summed over the ranks by RCCL (ncclAllReduce over xGMI) on the
+ * caller's stream, the 1 / world factor rides in unflow_adam_step's grad_scale.  RCCL is resolved at run time:
+ * unflow_comm_available() returns its version code (> 0) or 0, and without it the other calls return UNFLOW_ERR_UNSUPPORTED.
+ * Bootstrap: rank 0 calls unflow_comm_unique_id (128 bytes) and passes the id to every rank out of band; every rank then
+ * calls unflow_comm_init(id, nranks, rank, &comm) with its GPU current (collective: returns when all ranks have joined). */
+int unflow_comm_available(void);
+int unflow_comm_unique_id(void* id128);
+int unflow_comm_init(const void* id128, int nranks, int rank, void** comm);
+int unflow_comm_info(void* comm, int* nranks, int* rank);
+/* buf[0 .. n) <- sum over the ranks, in place, enqueued on `stream`; same n and call order on every rank. */
+int unflow_allreduce_sum_f32(float* buf, long n, void* comm, unflow_stream_t stream);
+int unflow_comm_destroy(void* comm);
+
 /* Persistent stream-K halo kernel (csrc/conv_streamk.hip).  Test hook (host only, no GPU) for a launch of `ncls` tap classes x
  * nt N tiles x mtp M tile pairs, every item nchunk chunks x ntaps[class] K tiles, the item list ordered M group (ngroups of
  * them) > class > N tile > pair and laid end to end in K tiles: range_pos[w] (G + 1 ints) = the first K-tile position of

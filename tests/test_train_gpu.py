@@ -33,19 +33,24 @@ batches = [((torch.rand(B, H, W, 3, generator=g) * 255).to(dev), (torch.rand(B, 
 # 'CS': a frozen first network (flownet.py:51-54) whose L2-only update must not race with its forward pass (ADVICE r2)
 for spec in ('C', 'CS'):
     res = []
-    for force in (False, True):
+    # plain path; bucketed path through torch.distributed (backend nccl); bucketed path through the library's own C ABI
+    # (csrc/comm_rccl.hip: a one-rank RCCL communicator from unflow_comm_init, ncclAllReduce on the communication stream)
+    for force, transport in ((False, None), (True, 'torch'), (True, 'rccl')):
         eng = FlowNetEngine(B, H, W, params=dict(DEFAULT_PARAMS, flownet=spec), device=dev, seed=7)
-        run = StepRunner(eng, 1, use_graph=True, force_reducer=force)
+        run = StepRunner(eng, 1, use_graph=True, force_reducer=force, transport=transport)
         assert run.nparts == (3 if force else 1)
+        if transport == 'rccl':
+            assert run.reducer.rccl is not None and (run.reducer.rccl.world, run.reducer.rccl.rank) == (1, 0)
         assert bool(run.frozen) == (spec == 'CS')
         losses = []
         for i in range(4):
             losses.append(run.step(*batches[i %% 3], 1e-4).item())
         torch.cuda.synchronize()
         res.append((eng.P.clone(), eng.M.clone(), eng.V.clone(), losses))
-    (p0, m0, v0, l0), (p1, m1, v1, l1) = res
-    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), "bucketed path differs (%%s)" %% spec
-    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (spec, l0, l1)    # (the L2 loss term is summed per bucket: float-atomic order)
+    (p0, m0, v0, l0) = res[0]
+    for (p1, m1, v1, l1) in res[1:]:
+        assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), "bucketed path differs (%%s)" %% spec
+        assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(l0, l1)), (spec, l0, l1)    # (the L2 loss term is summed per bucket: float-atomic order)
     assert l0[-1] != l0[0]
 dist.barrier(); dist.destroy_process_group()
 print("NCCL_WORLD1_OK", l0)

@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
     if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]      # dlopen: csrc/comm_rccl.hip
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

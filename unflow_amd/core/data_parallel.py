@@ -10,13 +10,73 @@ The gradient buffer is reduced in a few large buckets (xGMI is point-to-point, 7
 GPU: few, large messages), issued on a side stream so the exchange overlaps with whatever the compute
 stream still has queued.  Works with any torch.distributed backend (gloo on CPU for the tests).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
 
+class RcclComm:
+    """An RCCL communicator behind the C ABI (csrc/comm_rccl.hip: unflow_comm_* / unflow_allreduce_sum_f32) — the exchange
+    itself without torch.distributed in the data path: ncclAllReduce is enqueued on the stream the caller names, nothing else.
+    Bootstrap: rank 0's 128-byte unique id travels over the process group that torch.distributed already has (any backend,
+    gloo included); every rank must have its GPU current (torch.cuda.set_device) when this is constructed."""
+
+    def __init__(self, world, rank, group=None):
+        from .. import _lib
+        self.lib = _lib.lib()
+        self.version = self.lib.unflow_comm_available()
+        if not self.version:
+            raise RuntimeError("RCCL is not available to libunflow_hip.so (dlopen of librccl.so failed)")
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self.lib.unflow_comm_unique_id(uid), "comm_unique_id")
+        if world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        self.comm = ctypes.c_void_p()
+        _lib.check(self.lib.unflow_comm_init(uid, int(world), int(rank), ctypes.byref(self.comm)), "comm_init")
+        n, r = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.unflow_comm_info(self.comm, ctypes.byref(n), ctypes.byref(r)), "comm_info")
+        self.world, self.rank = n.value, r.value
+        assert (self.world, self.rank) == (world, rank), "RCCL reports rank %d of %d" % (self.rank, self.world)
+
+    def all_reduce_sum_(self, t, stream):
+        """In-place SUM of a contiguous fp32 CUDA tensor, enqueued on `stream` (a torch.cuda.Stream)."""
+        from .. import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(self.lib.unflow_allreduce_sum_f32(ctypes.c_void_p(t.data_ptr()), ctypes.c_long(t.numel()), self.comm,
+                                                     ctypes.c_void_p(stream.cuda_stream)), "allreduce_sum_f32")
+
+    def close(self):
+        if self.comm:
+            self.lib.unflow_comm_destroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+
+class _Enqueued:
+    """What the direct transport returns in place of a torch.distributed work object: the collective is already ordered on
+    the communication stream."""
+
+    def wait(self):
+        pass
+
+
 class GradAllReducer:
-    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None, force=False, local_overlap=False):
+    def __init__(self, flat_grad, world_size, bucket_bytes=64 << 20, group=None, force=False, local_overlap=False, transport=None):
+        """transport: 'torch' — dist.all_reduce of the process group (RCCL when its backend is nccl; gloo for the CPU tests);
+        'rccl' — ncclAllReduce through the library's own C ABI (RcclComm) on the communication stream.  Default: the
+        UNFLOW_COMM environment variable, else 'torch'."""
         self.g = flat_grad
+        self.transport = transport or os.environ.get("UNFLOW_COMM", "torch")
+        if self.transport not in ("torch", "rccl"):
+            raise ValueError("transport must be 'torch' or 'rccl'")
+        self.rccl = None
+        if self.transport == "rccl" and flat_grad.is_cuda and (world_size > 1 or force):
+            rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+            self.rccl = RcclComm(world_size, rank, group)
         self.world = world_size
         self.force = force      # issue the collectives even for world_size 1 (exercises the stream logic on one GPU)
         # one rank, no process group: reduce_then() still moves fn() to the side stream, so the bucketed optimizer update
@@ -32,17 +92,23 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self.dry = False        # measurement switch (bench.py comm record): reduce_then keeps its stream order but skips the collectives
 
+    def _issue(self, a, b):
+        """One SUM all-reduce of g[a:b], issued with the communication stream current; returns something with .wait()."""
+        if self.rccl is not None:
+            self.rccl.all_reduce_sum_(self.g[a:b], self.stream)
+            return _Enqueued()
+        return dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def all_reduce(self):
         """SUM over ranks, in place (scale by 1/world in the optimizer).  Returns after enqueueing; the
         compute stream is made to wait for the exchange."""
-        if self.world <= 1:
+        if self.world <= 1 and self.rccl is None:
             return
         if self.cuda:
             cur = torch.cuda.current_stream(self.g.device)
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
-                works = [dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                         for a, b in self.bounds]
+                works = [self._issue(a, b) for a, b in self.bounds]
                 for w in works:
                     w.wait()
             cur.wait_stream(self.stream)
@@ -63,8 +129,7 @@ class GradAllReducer:
                     cur = torch.cuda.current_stream(self.g.device)
                     self.stream.wait_stream(cur)
                     with torch.cuda.stream(self.stream):
-                        self._pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                                             async_op=True))
+                        self._pending.append(self._issue(a, b))
                 else:
                     dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
 
@@ -90,9 +155,7 @@ class GradAllReducer:
         cur = torch.cuda.current_stream(self.g.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            works = [] if self.dry else [
-                dist.all_reduce(self.g[a:min(hi, a + self.per)], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                for lo, hi in ranges for a in range(lo, hi, self.per)]
+            works = [] if self.dry else [self._issue(a, min(hi, a + self.per)) for lo, hi in ranges for a in range(lo, hi, self.per)]
             for w in works:
                 w.wait()          # stream-level: the side stream waits for the collective, the host does not
             fn()

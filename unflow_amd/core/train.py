@@ -58,13 +58,13 @@ class StepRunner:
     exchanged), bucketed RCCL all-reduce and bucketed Adam on a communication stream.  Used by bench.py and Trainer."""
 
     def __init__(self, engine, world=1, use_graph=True, force_reducer=False, bucket_cuts=DEFAULT_BUCKET_CUTS,
-                 bucket_bytes=64 << 20, group=None, local_overlap=False):
+                 bucket_bytes=64 << 20, group=None, local_overlap=False, transport=None):
         self.eng = engine
         self.world = world
         local = world == 1 and not force_reducer and engine.dev.type == 'cuda' and local_overlap
         self.dist = world > 1 or force_reducer or local
         self.reducer = GradAllReducer(engine.G, world, bucket_bytes=bucket_bytes, group=group, force=force_reducer,
-                                      local_overlap=local) if self.dist else None
+                                      local_overlap=local, transport=transport) if self.dist else None
         self.nparts = engine.set_backward_parts(bucket_cuts if (self.dist and not engine.train_all) else ())
         self.buckets = engine.part_buckets()
         self.frozen = engine.frozen_ranges()

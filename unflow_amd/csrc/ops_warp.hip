@@ -374,64 +374,163 @@ __device__ __forceinline__ float splat_weight(float dx, float dy) {
   return expf(-(dx * dx + dy * dy) / 2.0f);  // gauss_divisor = 2*std^2 = 2 (ref :53-56)
 }
 
-// Reference-style scatter: one thread per source pixel, float atomics (order nondeterministic).
-__global__ void forward_warp_scatter_kernel(const float* __restrict__ flow, float* __restrict__ out, int B, int H,
-                                            int W) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / ((long)W * H);
-    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
-    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
-    if (!f.ok) continue;
-    for (int nx = f.x_lo; nx <= f.x_hi; nx++)
-      for (int ny = f.y_lo; ny <= f.y_hi; ny++)
-        atomicAdd(out + (b * H + ny) * W + nx, splat_weight((float)nx - f.tx, (float)ny - f.ty));
-  }
-}
+// ---- tiled scatter --------------------------------------------------------------------------------------------------------
+// The reference kernel (forward_warp_op.cu.cc:16-65) is one thread per source pixel and <= 81 float atomicAdds into the output.
+// Its cost is the atomics: 81 device-scope read-modify-writes per pixel.  Here a workgroup owns a 64 x 16 tile of SOURCE pixels
+// and a FW_WX x FW_WY window of TARGET pixels in LDS, centred on the mean target position of the tile's sources (a flow
+// field moves a tile as a whole, so the window follows it; a few outliers do not drag it away); the <= 81 taps of a source are integer LDS atomics, and only the
+// touched window entries go out to memory, once per tile: ~1.6 global atomics per source instead of 81 (measured: the
+// memory-side atomics are what the kernel costs — 46 G atomics/s chip-wide whether 4 or 8 bytes wide — hence the large tile).
+// Taps outside the window (a field that tears a tile apart) take the global path directly — always correct, only slower.
+//   * Weights are separable: exp(-(dx^2 + dy^2) / 2) = exp(-dx^2 / 2) * exp(-dy^2 / 2): 18 expf per source instead of 81
+//     (relative deviation from the reference's single expf <= ~4e-7, the parity tests allow 1e-5 absolute on sums of ~6.3).
+//   * Sums are 2^-31 fixed point in 64-bit integers, in LDS and in memory: integer addition commutes, so the result does not
+//     depend on the arrival order of waves, workgroups or XCDs — bit-reproducible — and cannot overflow (2^33 full-weight taps
+//     per pixel).  The footprints are exactly the reference's (fw_footprint, shared with unflow_forward_warp_ranges).
+// deterministic = 0 keeps the reference's contract (float atomicAdd into `out`, order-dependent last bits) but takes the same
+// LDS path: the window entries are converted and added as floats, one atomic per touched entry.
+constexpr int FW_TX = 64, FW_TY = 64;                 // source tile: 4096 pixels, 16 per thread
+constexpr int FW_WX = 88, FW_WY = 88;                 // target window: 62 KB of 64-bit sums (tile + 4-px splat rim + 8 px of spread each way)
+constexpr int FW_SPT = FW_TX * FW_TY / 256;           // sources per thread
+constexpr float FW_Q = 2147483648.f;                  // 2^31
+constexpr double FW_QINV = 1.0 / 2147483648.0;
 
-// Deterministic variant: the same scatter, but each weight is added as a 2^40-scaled 64-bit integer
-// (integer atomics commute, so the sum is independent of arrival order and bit-reproducible);
-// a second pass converts to float.  Per-term quantisation 2^-41 — far below fp32 resolution of the sum.
-#define FW_FIXED_SCALE 1099511627776.0 /* 2^40 */
-__global__ void forward_warp_scatter_fixed_kernel(const float* __restrict__ flow,
-                                                  unsigned long long* __restrict__ acc, int B, int H, int W) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / ((long)W * H);
-    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
-    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
-    if (!f.ok) continue;
-    for (int nx = f.x_lo; nx <= f.x_hi; nx++)
-      for (int ny = f.y_lo; ny <= f.y_hi; ny++) {
-        const double w = (double)splat_weight((float)nx - f.tx, (float)ny - f.ty);
-        atomicAdd(acc + (b * H + ny) * W + nx, (unsigned long long)(w * FW_FIXED_SCALE + 0.5));
+template <bool DET>
+__global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __restrict__ flow, unsigned long long* __restrict__ acc,
+                                                                float* __restrict__ outf, int B, int H, int W, int tiles_x,
+                                                                int tiles_y) {
+  __shared__ unsigned long long win[FW_WX * FW_WY];
+  __shared__ int s_org[3];
+  const int tid = threadIdx.x;
+  const int ntiles = B * tiles_y * tiles_x;
+  for (int tile = (int)xcd_block(); tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int txi = t % tiles_x; t /= tiles_x;
+    const int tyi = t % tiles_y;
+    const int b = t / tiles_y;
+    if (tid < 3) s_org[tid] = 0;
+    for (int e = tid; e < FW_WX * FW_WY; e += 256) win[e] = 0ull;
+    __syncthreads();
+    // the thread's sources: (x, y + 4 k)
+    const int sx = txi * FW_TX + (tid & (FW_TX - 1));
+    const int sy0 = tyi * FW_TY + (tid >> 6);
+    const long img = (long)b * H * W;
+    auto foot = [&](int k) {
+      const int sy = sy0 + 4 * k;
+      FwFoot f;
+      f.ok = false;
+      if (sx < W && sy < H) {
+        const float2 fl = reinterpret_cast<const float2*>(flow)[img + (long)sy * W + sx];
+        f = fw_footprint(sx, sy, fl.x, fl.y, W, H);
       }
+      return f;
+    };
+    int mx = 0, my = 0, mc = 0;                 // integer sums: the window position is the same in every run
+#pragma unroll 4
+    for (int k = 0; k < FW_SPT; k++) {
+      const FwFoot f = foot(k);
+      if (f.ok) { mx += f.x_lo + f.x_hi; my += f.y_lo + f.y_hi; mc++; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mx += __shfl_xor(mx, off, 64);
+      my += __shfl_xor(my, off, 64);
+      mc += __shfl_xor(mc, off, 64);
+    }
+    if ((tid & 63) == 0) { atomicAdd(&s_org[0], mx); atomicAdd(&s_org[1], my); atomicAdd(&s_org[2], mc); }
+    __syncthreads();
+    const int cnt = s_org[2];
+    if (cnt == 0) { __syncthreads(); continue; }       // no source of this tile reaches the image
+    const int wx0 = s_org[0] / (2 * cnt) - FW_WX / 2, wy0 = s_org[1] / (2 * cnt) - FW_WY / 2;
+#pragma unroll 1
+    for (int k = 0; k < FW_SPT; k++) {
+      const FwFoot f = foot(k);                 // (the flow is read a second time: L2 / L1 hit)
+      if (!f.ok) continue;
+      float wxv[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const float dx = (float)(f.x_lo + j) - f.tx;
+        wxv[j] = expf(-(dx * dx) / 2.0f);
+      }
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int ny = f.y_lo + i;
+        if (ny > f.y_hi) continue;
+        const float dy = (float)ny - f.ty;
+        const float wy = expf(-(dy * dy) / 2.0f);
+        const int ly = ny - wy0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const int nx = f.x_lo + j;
+          if (nx > f.x_hi) continue;
+          const float w = wy * wxv[j];
+          const unsigned long long q = (unsigned long long)(unsigned)(w * FW_Q + 0.5f);
+          const int lx = nx - wx0;
+          if ((unsigned)lx < (unsigned)FW_WX && (unsigned)ly < (unsigned)FW_WY) {
+            atomicAdd(&win[ly * FW_WX + lx], q);
+          } else if (DET) {
+            atomicAdd(acc + img + (long)ny * W + nx, q);
+          } else {
+            atomicAdd(outf + img + (long)ny * W + nx, w);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < FW_WX * FW_WY; e += 256) {
+      const unsigned long long v = win[e];
+      if (v == 0ull) continue;
+      const int ly = e / FW_WX, lx = e - ly * FW_WX;
+      const long g = img + (long)(wy0 + ly) * W + (wx0 + lx);      // inside the image: every tap was clipped to it
+      if (DET) atomicAdd(acc + g, v);
+      else atomicAdd(outf + g, (float)((double)v * FW_QINV));
+    }
+    __syncthreads();
   }
 }
 
 __global__ void forward_warp_fixed_to_float_kernel(const unsigned long long* __restrict__ acc,
                                                    float* __restrict__ out, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    out[i] = (float)((double)acc[i] * (1.0 / FW_FIXED_SCALE));
+    out[i] = (float)((double)acc[i] * FW_QINV);
 }
 
+// Gradient (forward_warp_op.cu.cc:67-125): a gather over the source's own footprint — no atomics in the reference either.
+// Same separable weights; dout is read through L1 (neighbouring sources share most of their 9 x 9 windows).
 __global__ void forward_warp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ flow,
                                         float* __restrict__ dflow, int B, int H, int W) {
-  const long npx = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / ((long)W * H);
-    const float2 fl = reinterpret_cast<const float2*>(flow)[i];
-    const FwFoot f = fw_footprint((int)(i % W), (int)((i / W) % H), fl.x, fl.y, W, H);
+  const unsigned T = tile_count((unsigned)W, (unsigned)H, (unsigned)B);
+  for (unsigned t = tile_first(T); t < tile_last(T); t++) {
+    const TilePix px = tile_pix(t, (unsigned)W, (unsigned)H);
+    if (!px.ok) continue;
+    const float2 fl = reinterpret_cast<const float2*>(flow)[px.i];
+    const FwFoot f = fw_footprint(px.x, px.y, fl.x, fl.y, W, H);
     float du = 0.f, dv = 0.f;
-    if (f.ok)
-      for (int nx = f.x_lo; nx <= f.x_hi; nx++)
-        for (int ny = f.y_lo; ny <= f.y_hi; ny++) {
-          const float dx = (float)nx - f.tx, dy = (float)ny - f.ty;
-          const float factor = 2.f * dout[(b * H + ny) * W + nx] * splat_weight(dx, dy) / 2.0f;
-          du += factor * dx;
+    if (f.ok) {
+      const float* img = dout + (long)px.n * H * W;
+      float wxv[9], dxv[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        dxv[j] = (float)(f.x_lo + j) - f.tx;
+        wxv[j] = expf(-(dxv[j] * dxv[j]) / 2.0f);
+      }
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int ny = f.y_lo + i;
+        if (ny > f.y_hi) continue;
+        const float dy = (float)ny - f.ty;
+        const float wy = expf(-(dy * dy) / 2.0f);
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const int nx = f.x_lo + j;
+          if (nx > f.x_hi) continue;
+          const float factor = img[(long)ny * W + nx] * (wy * wxv[j]);      // 2 * din * weight / gauss_divisor, gauss_divisor = 2
+          du += factor * dxv[j];
           dv += factor * dy;
         }
-    reinterpret_cast<float2*>(dflow)[i] = make_float2(du, dv);
+      }
+    }
+    reinterpret_cast<float2*>(dflow)[px.i] = make_float2(du, dv);
   }
 }
 
@@ -451,17 +550,20 @@ UNFLOW_API int unflow_forward_warp_fwd(const float* flows, float* out, int B, in
   if (B < 0 || H < 0 || W < 0) return UNFLOW_ERR_SHAPE;
   const long npx = (long)B * H * W;
   if (npx == 0) return UNFLOW_OK;
+  const int tiles_x = cdiv(W, FW_TX), tiles_y = cdiv(H, FW_TY);
+  const int ntiles = B * tiles_y * tiles_x;
+  const int grid = ntiles < 2048 ? ntiles : 2048;
   if (deterministic) {
     if (!workspace) return UNFLOW_ERR_NULL;
     if (workspace_bytes < sizeof(unsigned long long) * (size_t)npx) return UNFLOW_ERR_WORKSPACE;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
     if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * npx, as_stream(stream)) != hipSuccess)
       return UNFLOW_ERR_LAUNCH;
-    forward_warp_scatter_fixed_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(flows, acc, B, H, W);
+    forward_warp_tile_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(flows, acc, nullptr, B, H, W, tiles_x, tiles_y);
     forward_warp_fixed_to_float_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(acc, out, npx);
   } else {
     if (hipMemsetAsync(out, 0, sizeof(float) * npx, as_stream(stream)) != hipSuccess) return UNFLOW_ERR_LAUNCH;
-    forward_warp_scatter_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(flows, out, B, H, W);
+    forward_warp_tile_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(flows, nullptr, out, B, H, W, tiles_x, tiles_y);
   }
   return launch_status();
 }
