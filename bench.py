@@ -119,7 +119,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # the comm record quotes RCCL's algorithm / protocol / channel lines: INFO logging (init-time lines only) into a file
         # per process, unless the caller chose otherwise
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN"):     # (the image exports NCCL_DEBUG=VERSION)
+            os.environ["NCCL_DEBUG"] = "INFO"
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,GRAPH,TUNING")
         if os.environ.get("NCCL_DEBUG", "").upper() == "INFO":
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/unflow_rccl_%h_%p.log")

@@ -133,6 +133,8 @@ STREAMK_CASES = [
     (8, 96, 128, 128, 256, 5, 2),
     (4, 48, 64, 256, 512, 3, 2),
     (4, 48, 64, 476, 256, 3, 1),
+    (1, 38, 70, 40, 96, 3, 2),      # forward = four ACCUMULATING classes (2x2 / 2x1 / 1x2 / 1x1 taps) walked inside one item, ragged grid
+    (2, 96, 128, 64, 128, 5, 2),    # conv2-like forward: accumulating 3x3 / 3x2 / 2x3 / 2x2 classes, 2 chunks each
 ]
 
 
@@ -140,6 +142,7 @@ STREAMK_CASES = [
 def test_conv_planes_streamk_vs_fp64(case, dev, lib_option):
     from unflow_amd import _lib
     lib_option("streamk", 2)
+    lib_option("halo_s2", 2)                             # stride-2 forwards as accumulating classes wherever the form applies
     _lib.lib().unflow_debug_streamk_timeouts()          # clear
     first = _conv_case_vs_fp64(case, 3, dev)
     assert _lib.lib().unflow_debug_streamk_timeouts() == 0
@@ -278,11 +281,14 @@ def test_deconv_planes_vs_fp64(case, P, dev, lib_option):
     _deconv_case_vs_fp64(case, P, dev)
 
 
-@pytest.mark.parametrize("case", [(1, 24, 32, 772, 128), (4, 24, 32, 772, 128), (1, 9, 40, 128, 72)])
+@pytest.mark.parametrize("case", [(1, 24, 32, 772, 128), (4, 24, 32, 772, 128), (1, 9, 40, 128, 72), (2, 24, 64, 388, 64),
+                                  (1, 9, 40, 128, 40)])
 def test_deconv_planes_streamk_vs_fp64(case, dev, lib_option):
-    """conv_transpose forward = four output-parity classes of 2 x 2 taps on the persistent stream-K halo kernel."""
+    """conv_transpose on the persistent stream-K halo kernel: forward = four output-parity classes of 2 x 2 taps; data gradient
+    (the last two cases: N = Cin > 64) = four ACCUMULATING 2 x 2-tap classes on the parity sub-lattices of dz."""
     from unflow_amd import _lib
     lib_option("streamk", 2)
+    lib_option("halo_s2", 2)
     _lib.lib().unflow_debug_streamk_timeouts()
     first = _deconv_case_vs_fp64(case, 3, dev)
     assert _lib.lib().unflow_debug_streamk_timeouts() == 0

@@ -90,7 +90,11 @@ static bool sk_fill(SkPlan& s, int ngroups) {
   return true;
 }
 
-template <int NPL, bool F16>
+// ACC: the tap classes of the launch ACCUMULATE into one output tile (GatherGeom.acc: forward of a stride-2 conv, data
+// gradient of a conv_transpose — four stride-1 problems on the parity sub-lattices of the source, pixel pitch p.sp = 2): an
+// item is then (N tile, M tile pair) and its K loop walks class after class (class-major, then chunk, then tap), each class
+// with its own halo geometry and tap grid; the plan sees one class of sum-of-taps K tiles per chunk.
+template <int NPL, bool F16, bool ACC>
 __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGatherParams p, const SkPlan sk, int HPmax) {
   constexpr int BM = 128, BN = 128, WM = 64, WN = 64;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -140,12 +144,21 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
     // ---- the segment: K tiles [k0, k1) of item (class, N tile, M tile pair)
     int cls_id, ntile, mpair, k0;
     sk_decode(sk, pos, cls_id, ntile, mpair, k0);
-    const TapClass tc = p.cls[cls_id];
-    const int ntaps = tc.nty * tc.ntx;
-    const int nk = sk.nchunk * ntaps;
+    const int nk = sk.nchunk * sk.ntaps[ACC ? 0 : cls_id];
     const int k1 = min(nk, k0 + (int)(pos_end - pos));
     const unsigned item_end = pos - (unsigned)k0 + (unsigned)nk;      // K-tile position one past this item
     pos += (unsigned)(k1 - k0);
+    // the class K tile k0 lies in (ACC: classes follow each other inside the item) and its K tile inside that class
+    int cls0 = cls_id, kc0 = k0;
+    if (ACC) {
+      cls0 = 0;
+      for (;;) {
+        const int nkc = sk.nchunk * p.cls[cls0].nty * p.cls[cls0].ntx;
+        if (kc0 < nkc || cls0 + 1 >= p.ncls) break;
+        kc0 -= nkc;
+        cls0++;
+      }
+    }
     int t = 2 * mpair + inst;
     const bool tile_ok = t < p.B * p.tiles_y * p.tiles_x;
     const int n0 = ntile * BN;
@@ -154,36 +167,41 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
     const int tyi = t % p.tiles_y;
     const int b = t / p.tiles_y;
     const int y0 = tyi * TH, x0 = txi * TW;
-    const int HC = TW + tc.ntx - 1;
+    int HC = TW + p.cls[cls0].ntx - 1;           // halo row pitch (pixels); ACC: the widest class's, for every class
+    if (ACC)
+      for (int c = 0; c < p.ncls; c++) HC = max(HC, TW + p.cls[c].ntx - 1);
 
     __syncthreads();       // the previous segment's epilogue is done with the LDS staging areas and the pixel table
+    TapClass ltc = p.cls[cls0], mtc = ltc;       // the class of the tile being LOADED / MULTIPLIED
     int h_off[NH];
-    {
-      const int dmy = p.dstep > 0 ? tc.dy0 : tc.dy0 - (tc.nty - 1);
-      const int dmx = p.dstep > 0 ? tc.dx0 : tc.dx0 - (tc.ntx - 1);
-      const int HRc = TH + tc.nty - 1;
+    auto set_load_class = [&]() {
+      const int dmy = p.dstep > 0 ? ltc.dy0 : ltc.dy0 - (ltc.nty - 1);
+      const int dmx = p.dstep > 0 ? ltc.dx0 : ltc.dx0 - (ltc.ntx - 1);
+      const int HRc = TH + ltc.nty - 1, HCc = TW + ltc.ntx - 1;
 #pragma unroll
       for (int j = 0; j < NH; j++) {
         const int hp = (tid >> 2) + 64 * j;
         const int hy = hp / HC, hx = hp - hy * HC;
         const int y = (y0 + hy) * p.sp + dmy, x = (x0 + hx) * p.sp + dmx;
-        const bool ok = tile_ok && hy < HRc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+        const bool ok = tile_ok && hy < HRc && hx < HCc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
         h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
       }
-    }
+    };
+    set_load_class();
     if (tid < BM) {
       const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
-      pix[tid] = (tile_ok && yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px : -1;
+      pix[tid] = (tile_ok && yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + ltc.py) * p.Wd + xg * p.so + ltc.px : -1;
     }
     const int b_row = n0 + b_r < p.N ? (n0 + b_r) * p.Cs * 2 + kq * 16 : OOB_MARK;
 
     // walkers over the segment's K tiles (chunk-major, then tap): L = the tile the next load_b() requests, M = the tile multiplied
-    const int tap0 = k0 % ntaps;                 // a range may start in the middle of a chunk: its halo is loaded all the same
-    int l_chunk = k0 / ntaps, l_ty = tap0 / tc.ntx, l_tx = tap0 % tc.ntx, l_left = T;
-    int m_ty = l_ty, m_tx = l_tx;
+    const int ntaps0 = ltc.nty * ltc.ntx;
+    const int tap0 = kc0 % ntaps0;               // a range may start in the middle of a chunk: its halo is loaded all the same
+    int l_cls = cls0, l_chunk = kc0 / ntaps0, l_ty = tap0 / ltc.ntx, l_tx = tap0 % ltc.ntx, l_left = T;
+    int m_cls = cls0, m_chunk = l_chunk, m_ty = l_ty, m_tx = l_tx;
     u32x4 rh[NH][NPL], rb[NPL];
     auto load_b = [&]() {
-      const int widx = (tc.ky0 + l_ty * p.kstep) * p.KW + tc.kx0 + l_tx * p.kstep;
+      const int widx = (ltc.ky0 + l_ty * p.kstep) * p.KW + ltc.kx0 + l_tx * p.kstep;
       const bool ok = l_left > 0 && l_chunk * 4 + kq < Cg;
       const int voff = ok ? b_row + widx * p.N * p.Cs * 2 + l_chunk * 64 : OOB_MARK;
 #pragma unroll
@@ -200,8 +218,14 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
     };
     auto l_advance = [&]() {
       l_tx++;
-      if (l_tx == tc.ntx) { l_tx = 0; l_ty++; }
-      if (l_ty == tc.nty) { l_ty = 0; l_chunk++; }
+      if (l_tx == ltc.ntx) { l_tx = 0; l_ty++; }
+      if (l_ty == ltc.nty) { l_ty = 0; l_chunk++; }
+      if (ACC && l_chunk == sk.nchunk && l_cls + 1 < p.ncls) {      // next class: its own halo geometry and tap grid
+        l_chunk = 0;
+        l_cls++;
+        ltc = p.cls[l_cls];
+        set_load_class();
+      }
       l_left--;
     };
     auto store_b = [&](int buf) {
@@ -233,10 +257,10 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
       const int sidx = wm * WM + i * 32 + l31;
       a_rd[i] = ((sidx >> TWL) * HC + (sidx & (TW - 1))) * HPITCH + lh * 8;
     }
-    const int c_hy0 = p.dstep > 0 ? 0 : tc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : tc.ntx - 1;
 
     s16x8 av[TM][NPL], bv[TN][NPL];
     auto read_frags = [&](int buf, int slab) {
+      const int c_hy0 = p.dstep > 0 ? 0 : mtc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : mtc.ntx - 1;
       const int tapoff = ((c_hy0 + m_ty * p.dstep) * HC + c_hx0 + m_tx * p.dstep) * HPITCH;
 #pragma unroll
       for (int pl = 0; pl < NPL; pl++) {
@@ -308,8 +332,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
       multiply();                                               // slab 1
       slot_end();
       m_tx++;
-      if (m_tx == tc.ntx) { m_tx = 0; m_ty++; }
-      if (m_ty == tc.nty) m_ty = 0;
+      if (m_tx == mtc.ntx) { m_tx = 0; m_ty++; }
+      if (m_ty == mtc.nty) { m_ty = 0; m_chunk++; }
+      if (ACC && m_chunk == sk.nchunk && m_cls + 1 < p.ncls) {
+        m_chunk = 0;
+        m_cls++;
+        mtc = p.cls[m_cls];
+      }
     }
     if (inst == 0) slot_end();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the zero loads past the last tile
@@ -365,6 +394,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
             }
       }
     }
+    (void)m_chunk;
     if (tile_ok) pl_gather_epilogue<WM, WN>(p, acc, pix, smem_all + inst * (4 * 32 * (WN + 4) * 2), wm, wn, wid, lane, n0, 0);
   }
 }
@@ -391,26 +421,36 @@ size_t pl_halo_sk_ws_bytes() { return (size_t)sk_workgroups() * SK_SLAB_BYTES + 
 
 static void sk_plan_of(const GatherGeom& p, SkPlan& sk) {
   sk.G = sk_workgroups();
-  sk.ncls = p.ncls;
   sk.nt = cdiv(p.N, 128);
   sk.mtp = cdiv((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW), 2);
   sk.nchunk = ((p.Cs >> 3) + 3) >> 2;
   for (int c = 0; c < 4; c++) sk.ntaps[c] = c < p.ncls ? p.cls[c].nty * p.cls[c].ntx : 1;
+  sk.ncls = p.ncls;
+  if (p.acc) {                                 // accumulating classes: one item walks them all
+    int sum = 0;
+    for (int c = 0; c < p.ncls; c++) sum += sk.ntaps[c];
+    sk.ncls = 1;
+    sk.ntaps[0] = sum;
+  }
 }
 
 bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn) {
   const int o = unflow::options().streamk;
-  if (o <= 0 || npl != 3 || bn != 128 || p.acc || pl_halo_sk_smem(p) > 160 * 1024) return false;
+  if (o <= 0 || npl != 3 || bn != 128 || (p.acc && p.dstep != 1) || pl_halo_sk_smem(p) > 160 * 1024) return false;
   SkPlan sk{};
   sk_plan_of(p, sk);
   if (!sk_fill(sk, unflow::options().streamk_groups)) return false;
-  // Where it pays (MI355X, FlowNetC 384x512 B=4, profiles/r04_streamk_per_layer.txt): single-class layers with long ranges —
-  // conv3_1 forward 288 -> 252 us, conv4_1 forward / data gradient 173 -> 153 / 173 -> 158, conv3_1 data gradient 281 -> 272.
-  // The output-parity classes of the stride-2 data gradients and of conv_transpose forward lose (conv4's data gradient
-  // 129 -> 150 us, conv3's 245 -> 277): a one-shot launch keeps two 4-wave workgroups per CU, so one's prologue / epilogue
-  // hides under the other's K loop, and its 768 uneven blocks balance themselves over 512 slots without any partial sums;
-  // one 8-wave workgroup per CU exposes every segment boundary (2.5 per workgroup there).  Option streamk = 2 forces it (tests).
-  return o >= 2 || (sk.ncls == 1 && sk.wall >= 48u * (unsigned)sk.G);
+  // Where it pays (MI355X, FlowNetC 384x512 B=4, profiles/r04_streamk_per_layer.txt): items with LONG K loops, walked by one
+  // output tile — conv3_1 forward 288 -> 252 us, conv4_1 forward / data gradient 173 -> 153 / 173 -> 158, conv3_1 data
+  // gradient 281 -> 272, conv3 forward (four accumulating classes, 100 K tiles) 237 -> 208.  It loses where an item is short:
+  // conv2 forward (50 K tiles) 223 -> 236, deconv2's data gradient (32) 131 -> 143, and on the output-parity classes of the
+  // stride-2 data gradients / conv_transpose forward (16 .. 72 K tiles per item; conv4's data gradient 129 -> 150 us, conv3's
+  // 245 -> 277).  There a one-shot launch keeps two 4-wave workgroups per CU, so one's prologue / epilogue hides under the
+  // other's K loop, and its uneven blocks balance themselves over 512 slots without any partial sums; one 8-wave workgroup per
+  // CU exposes every segment boundary (2.5 - 3 per workgroup there).  Option streamk = 2 forces it (tests).
+  int min_nk = 1 << 30;
+  for (int c = 0; c < sk.ncls; c++) min_nk = min(min_nk, sk.nchunk * sk.ntaps[c]);
+  return o >= 2 || (sk.ncls == 1 && min_nk >= 64 && sk.wall >= 48u * (unsigned)sk.G);
 }
 
 int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -419,7 +459,8 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
   const int smem = pl_halo_sk_smem(p);
   static int smem_set = 0;
   if (smem > smem_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     smem_set = smem;
   }
   PlGatherParams q = p;
@@ -430,7 +471,8 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
   sk.slabs = reinterpret_cast<float*>(ws);
   sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)sk.G * SK_SLAB_BYTES);
   if (hipMemsetAsync(sk.flags, 0, (size_t)sk.G * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
-  igemm_pl_halo_sk_kernel<3, false><<<sk.G, 512, smem, st>>>(q, sk, hp);
+  if (p.acc) igemm_pl_halo_sk_kernel<3, false, true><<<sk.G, 512, smem, st>>>(q, sk, hp);
+  else igemm_pl_halo_sk_kernel<3, false, false><<<sk.G, 512, smem, st>>>(q, sk, hp);
   return launch_status();
 }
 

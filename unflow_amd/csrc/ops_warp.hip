@@ -379,8 +379,9 @@ __device__ __forceinline__ float splat_weight(float dx, float dy) {
 // Its cost is the atomics: 81 device-scope read-modify-writes per pixel.  Here a workgroup owns a 64 x 16 tile of SOURCE pixels
 // and a FW_WX x FW_WY window of TARGET pixels in LDS, centred on the mean target position of the tile's sources (a flow
 // field moves a tile as a whole, so the window follows it; a few outliers do not drag it away); the <= 81 taps of a source are integer LDS atomics, and only the
-// touched window entries go out to memory, once per tile: ~1.6 global atomics per source instead of 81 (measured: the
-// memory-side atomics are what the kernel costs — 46 G atomics/s chip-wide whether 4 or 8 bytes wide — hence the large tile).
+// touched window entries go out to memory, once per tile: ~2.5 global atomics per source instead of 81 (memory-side atomics
+// run at ~46 G/s chip-wide whether 4 or 8 bytes wide; a 64 x 64 tile needs only 1.6 per source but was slower, 1069 vs 685 us
+// at 16 x 768 x 1024: two workgroups per CU instead of three — the LDS phase is latency-bound).
 // Taps outside the window (a field that tears a tile apart) take the global path directly — always correct, only slower.
 //   * Weights are separable: exp(-(dx^2 + dy^2) / 2) = exp(-dx^2 / 2) * exp(-dy^2 / 2): 18 expf per source instead of 81
 //     (relative deviation from the reference's single expf <= ~4e-7, the parity tests allow 1e-5 absolute on sums of ~6.3).
@@ -389,8 +390,8 @@ __device__ __forceinline__ float splat_weight(float dx, float dy) {
 //     per pixel).  The footprints are exactly the reference's (fw_footprint, shared with unflow_forward_warp_ranges).
 // deterministic = 0 keeps the reference's contract (float atomicAdd into `out`, order-dependent last bits) but takes the same
 // LDS path: the window entries are converted and added as floats, one atomic per touched entry.
-constexpr int FW_TX = 64, FW_TY = 64;                 // source tile: 4096 pixels, 16 per thread
-constexpr int FW_WX = 88, FW_WY = 88;                 // target window: 62 KB of 64-bit sums (tile + 4-px splat rim + 8 px of spread each way)
+constexpr int FW_TX = 64, FW_TY = 16;                 // source tile: 1024 pixels, 4 per thread
+constexpr int FW_WX = 104, FW_WY = 56;                // target window: 46.6 KB of 64-bit sums (tile + 4-px splat rim + 16 px of spread): 3 workgroups per CU
 constexpr int FW_SPT = FW_TX * FW_TY / 256;           // sources per thread
 constexpr float FW_Q = 2147483648.f;                  // 2^31
 constexpr double FW_QINV = 1.0 / 2147483648.0;
@@ -451,6 +452,20 @@ __global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __r
       for (int j = 0; j < 9; j++) {
         const float dx = (float)(f.x_lo + j) - f.tx;
         wxv[j] = expf(-(dx * dx) / 2.0f);
+      }
+      const int lx0 = f.x_lo - wx0, ly0 = f.y_lo - wy0;
+      if (f.x_hi - f.x_lo == 8 && f.y_hi - f.y_lo == 8 && lx0 >= 0 && lx0 + 8 < FW_WX && ly0 >= 0 && ly0 + 8 < FW_WY) {
+        // the common case — a whole 9 x 9 footprint inside the window: no per-tap tests, constant LDS offsets
+        unsigned long long* base = win + ly0 * FW_WX + lx0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const float dy = (float)(f.y_lo + i) - f.ty;
+          const float wy = expf(-(dy * dy) / 2.0f);
+#pragma unroll
+          for (int j = 0; j < 9; j++)
+            atomicAdd(base + i * FW_WX + j, (unsigned long long)(unsigned)(wy * wxv[j] * FW_Q + 0.5f));
+        }
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < 9; i++) {
