@@ -138,19 +138,39 @@ STREAMK_CASES = [
 ]
 
 
+# the 4-wave form also takes the N <= 64 tile: a stride-2 data gradient with N = 64 (parity classes), a partial last chunk,
+# an accumulating 7x7 stride-2 forward with a half-filled chunk
+STREAMK4_EXTRA = [(2, 64, 64, 64, 128, 5, 2), (1, 16, 32, 388, 64, 3, 1), (2, 64, 128, 16, 64, 7, 2)]
+
+
+def _streamk_mode(lib_option, form):
+    """form 8: the 8-wave ping-pong kernel, 4: the 4-wave kernel, 0: the one-shot kernels — each forced wherever eligible."""
+    lib_option("streamk", 2 if form == 8 else 0)
+    lib_option("streamk4", 2 if form == 4 else 0)
+    lib_option("halo_s2", 2)                             # stride-2 forwards as accumulating classes wherever the form applies
+
+
+def _streamk_check(run, lib_option, form):
+    from unflow_amd import _lib
+    _streamk_mode(lib_option, form)
+    _lib.lib().unflow_debug_streamk_timeouts()          # clear
+    first = run()
+    assert _lib.lib().unflow_debug_streamk_timeouts() == 0
+    again = run()                                        # fixed-order sums: bit-identical run to run
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    _streamk_mode(lib_option, 0)                         # and within fp32 rounding of the one-shot kernels' results
+    plain = run()
+    assert all(rel_err(a, b) < 2e-6 for a, b in zip(first, plain))
+
+
 @pytest.mark.parametrize("case", STREAMK_CASES)
 def test_conv_planes_streamk_vs_fp64(case, dev, lib_option):
-    from unflow_amd import _lib
-    lib_option("streamk", 2)
-    lib_option("halo_s2", 2)                             # stride-2 forwards as accumulating classes wherever the form applies
-    _lib.lib().unflow_debug_streamk_timeouts()          # clear
-    first = _conv_case_vs_fp64(case, 3, dev)
-    assert _lib.lib().unflow_debug_streamk_timeouts() == 0
-    again = _conv_case_vs_fp64(case, 3, dev)            # fixed-order sums: bit-identical run to run
-    assert all(torch.equal(a, b) for a, b in zip(first, again))
-    lib_option("streamk", 0)                             # and within fp32 rounding of the one-shot kernels' results
-    plain = _conv_case_vs_fp64(case, 3, dev)
-    assert all(rel_err(a, b) < 2e-6 for a, b in zip(first, plain))
+    _streamk_check(lambda: _conv_case_vs_fp64(case, 3, dev), lib_option, 8)
+
+
+@pytest.mark.parametrize("case", STREAMK_CASES + STREAMK4_EXTRA)
+def test_conv_planes_streamk4_vs_fp64(case, dev, lib_option):
+    _streamk_check(lambda: _conv_case_vs_fp64(case, 3, dev), lib_option, 4)
 
 
 def _conv_case_vs_fp64(case, P, dev):
@@ -286,17 +306,13 @@ def test_deconv_planes_vs_fp64(case, P, dev, lib_option):
 def test_deconv_planes_streamk_vs_fp64(case, dev, lib_option):
     """conv_transpose on the persistent stream-K halo kernel: forward = four output-parity classes of 2 x 2 taps; data gradient
     (the last two cases: N = Cin > 64) = four ACCUMULATING 2 x 2-tap classes on the parity sub-lattices of dz."""
-    from unflow_amd import _lib
-    lib_option("streamk", 2)
-    lib_option("halo_s2", 2)
-    _lib.lib().unflow_debug_streamk_timeouts()
-    first = _deconv_case_vs_fp64(case, 3, dev)
-    assert _lib.lib().unflow_debug_streamk_timeouts() == 0
-    again = _deconv_case_vs_fp64(case, 3, dev)
-    assert all(torch.equal(a, b) for a, b in zip(first, again))
-    lib_option("streamk", 0)
-    plain = _deconv_case_vs_fp64(case, 3, dev)
-    assert all(rel_err(a, b) < 2e-6 for a, b in zip(first, plain))
+    _streamk_check(lambda: _deconv_case_vs_fp64(case, 3, dev), lib_option, 8)
+
+
+@pytest.mark.parametrize("case", [(1, 24, 32, 772, 128), (1, 24, 32, 388, 64), (2, 24, 64, 388, 64), (1, 9, 40, 128, 40)])
+def test_deconv_planes_streamk4_vs_fp64(case, dev, lib_option):
+    """... and on its 4-wave form (incl. the N = 64 decoder level)."""
+    _streamk_check(lambda: _deconv_case_vs_fp64(case, 3, dev), lib_option, 4)
 
 
 def _deconv_case_vs_fp64(case, P, dev):

@@ -517,11 +517,6 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_gather_pp_kernel(const PlGath
 // every 16-lane group of a ds_read_b128 hit 16 distinct 16-byte bank slots (an 8 x 16 tile puts two image rows into one
 // sub-tile: SQ_LDS_BANK_CONFLICT was 85 % of the LDS-active cycles).
 
-constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
-  const int tiles = npl * (hp * HPITCH + bn * LDH) * 2, stage = 4 * 32 * (wn + 4) * 4;
-  return tiles > stage ? tiles : stage;
-}
-
 template <int BN, int WM, int WN, int NPL, bool F16>
 __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherParams p, int HPmax) {
   constexpr int BM = 128;
@@ -2132,6 +2127,8 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   }
   if (halo && p.vec_epi && pl_halo_sk_ok(p, npl, halo_bn) && ws && ws_bytes >= pl_halo_sk_ws_bytes())
     return launch_pl_halo_sk(p, ws, ws_bytes, st);      // persistent stream-K form (conv_streamk.hip): no split, no reduce pass
+  if (halo && p.vec_epi && pl_halo_sk4_ok(p, npl, halo_bn) && ws && ws_bytes >= pl_halo_sk_ws_bytes())
+    return launch_pl_halo_sk4(p, halo_bn, ws, ws_bytes, st);      // ... its 4-wave form
   {
     // option fused_splitk = n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
     // chip-wide reduce kernel: measured on MI355X (FlowNetC 384x512 B=4) the fused form is bit-identical but not faster —

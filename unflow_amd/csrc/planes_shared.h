@@ -303,6 +303,12 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
 constexpr int TH = 4, TW = 32, TWL = 5;     // tile = TH x TW = 128 sites
 constexpr int HPITCH = 40;                  // 16-bit elements per halo pixel row: 32 channels + 8 pad (80 bytes)
 
+// LDS bytes of a 4-wave halo block before its pixel table: the operand tiles, or the epilogue's four wave-private staging areas
+constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
+  const int tiles = npl * (hp * HPITCH + bn * LDH) * 2, stage = 4 * 32 * (wn + 4) * 4;
+  return tiles > stage ? tiles : stage;
+}
+
 // source pixels of a block's halo image (largest class; accumulating classes share one image at the widest row pitch)
 inline int pl_halo_pixels(const GatherGeom& p) {
   int hp = 0, mty = 0, mtx = 0;
@@ -317,5 +323,8 @@ inline int pl_halo_pixels(const GatherGeom& p) {
 bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn);      // eligible and expected to pay (option streamk)
 size_t pl_halo_sk_ws_bytes();                                   // slabs + arrival flags
 int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st);      // p.tiles_y / tiles_x set
+// ... and its 4-wave form (two / three workgroups per CU, one 128-site tile each): the short-item layers
+bool pl_halo_sk4_ok(const GatherGeom& p, int npl, int bn);
+int launch_pl_halo_sk4(const PlGatherParams& p, int bn, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace igemm
