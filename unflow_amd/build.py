@@ -8,16 +8,18 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libunflow_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -fno-slp-vectorize -fno-vectorize: NO compiler-formed packed-fp32 instructions (v_pk_mul/add/fma_f32) anywhere in the
-# code object (checked: `llvm-objdump -d | grep -c "v_pk_.*_f32"` = 0; with only the SLP vectoriser off the loop vectoriser
-# still left 98 of them in the warp / augmentation / resize kernels).  hipcc (ROCm 7.2) allocates some of them with the
-# destination pair overlapping a source pair that another half reads through op_sel, e.g.
-#   v_pk_mul_f32 v[80:81], v[74:75], v[80:81] op_sel:[0,1]      (lo = v74 * v81, hi = v75 * v81 -> v81)
-# and on gfx950 the LOW half of exactly that instruction came out wrong in ~10 % of the replays of the two-branch backward
-# graph — only while a kernel of the other branch shared the SIMD, never alone, never eagerly; the inputs were verified
-# intact after the replay (tools/debug/wgstream_flake.py: 13 wrong sums in 120 replays with packed ops, 0 in 100 without;
-# the stress test stays in the GPU suite: tests/test_engine_gpu.py).  The packed forms buy nothing here (the step is 0.6 %
-# FASTER without them: they are an anti-lever beside MFMAs, MI355X_MICROARCH.md).
+# -fno-slp-vectorize -fno-vectorize: no compiler-formed packed-fp32 instructions (v_pk_mul/add/fma_f32) in the code object
+# (checked: `llvm-objdump -d | grep -c "v_pk_.*_f32"` = 0; the explicit v_pk_fma_f32 of the flow-head kernels are hand-written).
+# WHY, honestly: the step is 0.6 % faster without them (packed fp32 is an anti-lever beside MFMAs, MI355X_MICROARCH.md).  The
+# other reason given in round 2 is UNEXPLAINED: a 2 -> 2 flow-upsampling filter gradient returned one wrong sum in ~10 % of the
+# replays of the two-branch backward graph, always in the low half of one `v_pk_mul_f32 v[80:81], v[74:75], v[80:81]
+# op_sel:[0,1]` (destination pair = the source pair both halves read), never alone, never eagerly; with these flags 0 wrong sums
+# in 100 replays, and the stress test has been clean since (tests/test_engine_gpu.py).  Round 4 isolated that exact instruction
+# form (tools/microbench/pk_mul_hazard.hip, same register overlap via inline asm): 0 wrong results in 1.0e11 executions alone,
+# beside an MFMA-bound kernel and beside a VALU/LDS-bound kernel on a second stream (profiles/r04_pk_mul_hazard.txt) — so the
+# instruction is NOT the demonstrated cause; the flags changed the code (and the timing) of the one kernel that flaked, and that
+# kernel was replaced in round 3 by flow_wgrad_batched_kernel.  A workspace race would have looked the same; none was found
+# (every deferred filter gradient owns its scratch slot, core/engine.py ws_slot 3 +; the 100-replay stress test is the guard).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

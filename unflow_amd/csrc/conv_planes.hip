@@ -2049,7 +2049,7 @@ inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
     sumtaps += p.cls[c].nty * p.cls[c].ntx;
   }
   if (p.acc) maxtaps = sumtaps;                                       // a block walks every class
-  const int max_by_k = max(1, min(16, nchunk * maxtaps / 16));      // >= 16 K tiles per split, whole chunks
+  const int max_by_k = max(1, min(min(16, max(1, unflow::options().halo_max_split)), nchunk * maxtaps / 16));      // >= 16 K tiles per split, whole chunks
   if (bn == 128 && unflow::options().halo_pp > 0 && npl == 3 && !p.acc &&
       2 * 3 * pl_halo_pixels(p) * HPITCH * 2 + 2 * 3 * 128 * 32 * 2 + 2 * 128 * 4 <= 160 * 1024) {      // (= pl_halo_pp_ok, declared below)
     const long pairs = (((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) + 1) / 2) * cdiv(p.N, bn) * pl_grid_classes(p);
