@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the two secondary configs (BASELINE configs[3] CSS 768x1024 B=2 and configs[4] fp16 B=8: sub-processes)")
     ap.add_argument("--no-comm", action="store_true", help="N > 1: skip the second timing pass without the all-reduce")
+    ap.add_argument("--comm-ab", action="store_true",
+                    help="N > 1: also time K steps on the OTHER transport (a second RCCL communicator is created for it); always on "
+                         "in the forced one-rank record (UNFLOW_FORCE_REDUCER=1)")
     ap.add_argument("--comm", default=None, choices=["torch", "rccl"],
                     help="N > 1: gradient exchange through torch.distributed (backend nccl = RCCL; default) or through the library's "
                          "own C ABI (ncclAllReduce behind unflow_allreduce_sum_f32); the other one is timed as well and reported "
@@ -368,6 +371,8 @@ def measure_comm(runner, eng, step, barrier, args, world, ms_with, dev, dist):
     out["params_identical_across_ranks"] = replicas_identical()
     # the other transport on the same runner (same streams, buckets, graphs): K more steps
     try:
+        if world > 1 and not args.comm_ab:
+            raise RuntimeError("not requested (--comm-ab)")
         if world > 1 and dist.get_backend() != "nccl":
             raise RuntimeError("ranks share a GPU under the %s test backend: RCCL needs one GPU per rank" % dist.get_backend())
         from unflow_amd.core.data_parallel import RcclComm
@@ -394,7 +399,7 @@ def measure_comm(runner, eng, step, barrier, args, world, ms_with, dev, dist):
         if other is not None:
             other.close()
     except Exception as e:
-        out["other_transport"] = "failed: %r" % (e,)
+        out["other_transport"] = "not measured: %s" % (e,)
     if not args.no_comm:
         red.dry = True
         try:
