@@ -75,9 +75,11 @@ def _data(i):
 
 
 def _flat_grad(P, im1, im2):
+    """Flat gradient of the oracle's step in fp64: the statement under test is an identity of the MATHS (mean of the shard
+    gradients = gradient of the full-batch loss), so it is checked where rounding cannot blur it."""
     from oracle import model_ref as M
-    Pg = {k: v.clone().requires_grad_() for k, v in P.items()}
-    M.unsupervised_loss(Pg, im1, im2).backward()
+    Pg = {k: v.clone().double().requires_grad_() for k, v in P.items()}
+    M.unsupervised_loss(Pg, im1.double(), im2.double()).backward()
     return torch.cat([Pg[k].grad.reshape(-1) for k in Pg])
 
 
@@ -105,10 +107,9 @@ def test_two_rank_sharded_step_equals_one_rank_full_batch(tmp_path):
     full = _flat_grad(P, torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]]))
     # every loss term is a mean over the replica batch (charbonnier_loss normaliser, losses.py:311-312), the L2
     # term is data independent: mean of the shard gradients == gradient of the full-batch loss
+    assert dp.dtype == torch.float64
     rel = ((dp - full).abs().max() / full.abs().max()).item()
-    assert rel < 5e-3, rel     # fp32 torch-CPU conv gradients differ with the batch size (see test_engine_gpu.py)
-    cos = torch.nn.functional.cosine_similarity(dp, full, dim=0).item()
-    assert cos > 0.99999, cos
+    assert rel < 1e-10, rel    # (in fp32 the same comparison sits at ~1e-3: torch-CPU conv gradients change their summation with the batch size)
 
 
 def test_engine_layer_table_matches_reference_variables():
