@@ -1453,16 +1453,25 @@ __global__ __launch_bounds__(256) void flow_wgrad_batched_kernel(const FlowWgrad
   if (d.kind == 0) head3_wgrad_strip_body<8>(d.p, d.spw, bx, by, red);
   else head3_wgrad_strip_body<4>(d.p, d.spw, bx, by, red);
 }
+// Four lanes per element, each the serial sum of a quarter of the partials (8 loads in flight), combined in a fixed order:
+// (q0 + q1) + (q2 + q3) — the same value in every run.
 __global__ __launch_bounds__(256) void flow_wgrad_sum_kernel(const FlowWgradBatch b) {
   int di = 0;
   while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].rblock0) di++;
   const FlowWgradDesc& d = b.d[di];
-  const int e = (blockIdx.x - d.rblock0) * 256 + threadIdx.x;
-  if (e >= d.wsz) return;
+  const int e = (blockIdx.x - d.rblock0) * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+  const bool ok = e < d.wsz;
+  const int per = (d.chunks + 3) >> 2;
+  const int k0 = q * per, k1 = min(d.chunks, k0 + per);
   float v = 0.f;
+  if (ok) {
 #pragma unroll 8
-  for (int k = 0; k < d.chunks; k++) v += d.p.partial[(size_t)k * d.wsz + e];
-  d.out[e] = v;
+    for (int k = k0; k < k1; k++) v += d.p.partial[(size_t)k * d.wsz + e];
+  }
+  const float v1 = __shfl_down(v, 1, 64);
+  const float s01 = v + v1;                       // lanes q = 0 (q0 + q1) and q = 2 (q2 + q3) hold pair sums
+  const float s23 = __shfl_down(s01, 2, 64);
+  if (ok && q == 0) d.out[e] = s01 + s23;
 }
 
 // Batched column sums (all bias gradients of a step in one launch): block -> (descriptor, 64-col tile, row chunk).
@@ -2039,8 +2048,10 @@ UNFLOW_API int unflow_conv2d_transpose_bwd_filter(const float* x, int ldx, const
   return launch_status();
 }
 
-// Plan of one layer of the batch: <= 64 partials each (one fixed-order pass sums them), enough blocks over the whole batch
-// to fill the chip.  Returns false when the layer needs the per-layer path (no strip form).
+// Plan of one layer of the batch.  Blocks (= partials) per channel-quad group in proportion to the layer's strips, >= 4 strips
+// per wave, <= 256: the kernel lasts as long as its longest block, and with the round-3 cap of 64 that was flow2's (12288 strips
+// of 8 pixels x 196 channels = half the batch's bytes on 64 blocks = a quarter of the CUs: 97 us for 142 MB at B = 4, 210 us at
+// B = 8).  Returns false when the layer needs the per-layer path (no strip form).
 static bool flow_wgrad_plan(FlowWgradDesc& d, int kind_in, int B, int H, int W, int Cin) {
   if (kind_in == 1) {                      // conv_transpose 2 -> 2 over an H x W input
     d.kind = 2; d.colblocks = 1; d.spw = 0; d.wsz = 64;
@@ -2053,7 +2064,7 @@ static bool flow_wgrad_plan(FlowWgradDesc& d, int kind_in, int B, int H, int W, 
   d.colblocks = cdiv(Cin / 4, 64);
   d.wsz = 9 * Cin * 2;
   const long nstrips = (long)B * H * (W / S);
-  const long blocks = min((long)64, max((long)1, nstrips / 4));          // 4 waves per block, >= 1 strip per wave
+  const long blocks = min((long)256, max((long)1, nstrips / (nstrips >= 1024 ? 16 : 4)));      // 4 waves per block; >= 4 strips per wave on the large levels
   const long spw = (nstrips + blocks * 4 - 1) / (blocks * 4);
   d.spw = (int)spw;
   d.chunks = (int)((nstrips + spw * 4 - 1) / (spw * 4));
@@ -2102,7 +2113,7 @@ UNFLOW_API int unflow_flow_wgrad_batched(int n, const int* kind, const float* co
     d.block0 = blocks;
     blocks += d.chunks * d.colblocks;
     d.rblock0 = rblocks;
-    rblocks += cdiv(d.wsz, 256);
+    rblocks += cdiv(d.wsz, 64);
   }
   hipStream_t st = as_stream(stream);
   flow_wgrad_batched_kernel<<<blocks, 256, 0, st>>>(b);
