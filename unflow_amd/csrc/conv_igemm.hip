@@ -2064,7 +2064,7 @@ static bool flow_wgrad_plan(FlowWgradDesc& d, int kind_in, int B, int H, int W, 
   d.colblocks = cdiv(Cin / 4, 64);
   d.wsz = 9 * Cin * 2;
   const long nstrips = (long)B * H * (W / S);
-  const long blocks = min((long)256, max((long)1, nstrips / (nstrips >= 1024 ? 16 : 4)));      // 4 waves per block; >= 4 strips per wave on the large levels
+  const long blocks = min((long)256, max((long)1, nstrips / 16));      // 4 waves per block, >= 4 strips per wave (a block ends in a cross-wave sum + an 18 KB partial)
   const long spw = (nstrips + blocks * 4 - 1) / (blocks * 4);
   d.spw = (int)spw;
   d.chunks = (int)((nstrips + spw * 4 - 1) / (spw * 4));
