@@ -139,6 +139,10 @@ int unflow_forward_warp_ranges(const float* flows, int* ranges, int B, int H, in
 /* ops/downsample_op.cu.cc:15-49 (box mean); H,W must be divisible by scale (downsample_op.cc:37-40). */
 int unflow_downsample_fwd(const float* images, float* out, int B, int H, int W, int C, int scale,
                           unflow_stream_t stream);
+/* The loss pyramid's image chain downsample(., 4), downsample(., 2) x 4 (unsupervised.py:99-100,145-146) on 3-channel images in
+ * one launch; levels[k] = [N, H / (4 << k), W / (4 << k), 3], k = 0..4, each bit-identical to the chained unflow_downsample_fwd
+ * calls.  H, W multiples of 64 (UNFLOW_ERR_NOT_DIVISIBLE otherwise). */
+int unflow_image_pyramid5(const float* images, float* const* levels, int N, int H, int W, unflow_stream_t stream);
 
 /* ===================================================================== */
 /* conv / deconv stacks — slim.conv2d / slim.conv2d_transpose of           */

@@ -198,6 +198,31 @@ def test_downsample_vs_oracle(scale, dev, oracle_lib):
     assert np.array_equal(out.cpu().numpy(), oracle_lib.downsample(im, scale))   # same order of adds -> bit-exact
 
 
+def test_image_pyramid5_is_the_chain_of_downsamples_bit_for_bit(dev, oracle_lib):
+    """unflow_image_pyramid5 (the loss pyramid's images in one launch) == downsample(., 4) then four downsample(., 2)
+    (unsupervised.py:99-100,145-146), every level bit-identical to the chained op and to the C oracle."""
+    import ctypes
+    from unflow_amd import _lib, ops
+    from unflow_amd._lib import check, ptr, stream
+    rs = np.random.RandomState(23)
+    for N, H, W in ((2, 64, 128), (3, 192, 64), (8, 384, 512)):
+        im = rs.rand(N, H, W, 3).astype(np.float32)
+        tim = t(im, dev)
+        outs = [torch.full((N, H >> (2 + k), W >> (2 + k), 3), 7.0, device=dev) for k in range(5)]
+        ptrs = (ctypes.c_void_p * 5)(*[o.data_ptr() for o in outs])
+        check(_lib.lib().unflow_image_pyramid5(ptr(tim), ptrs, N, H, W, stream()), "image_pyramid5")
+        cur, ref = tim, im
+        for k in range(5):
+            cur = ops.downsample(cur, 4 if k == 0 else 2)
+            ref = oracle_lib.downsample(ref, 4 if k == 0 else 2)
+            assert torch.equal(outs[k], cur), (N, H, W, k)
+            assert np.array_equal(outs[k].cpu().numpy(), ref), (N, H, W, k)
+    bad = torch.zeros(1, 96, 128, 3, device=dev)
+    outs = [torch.zeros(1, 96 >> (2 + k), 128 >> (2 + k), 3, device=dev) for k in range(4)] + [torch.zeros(1, 2, 2, 3, device=dev)]
+    ptrs = (ctypes.c_void_p * 5)(*[o.data_ptr() for o in outs])
+    assert _lib.lib().unflow_image_pyramid5(ptr(bad), ptrs, 1, 96, 128, stream()) == -4        # H not a multiple of 64
+
+
 def test_warp_linearity_full_size(dev):
     """Size-independent property at the benchmark size: warps are linear in the image."""
     from unflow_amd.core.image_warp import image_warp

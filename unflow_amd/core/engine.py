@@ -878,11 +878,18 @@ class FlowNetEngine:
         levels = self.lv if P.get('pyramid_loss') else self.lv[:1]
         # image pyramid: downsample(im, 4) then successive downsample(., 2) (unsupervised.py:99-100,145-146); with
         # full_res level 0 is the image itself (unsupervised.py:92-93)
-        prev_im, ph, pw = self.act['im01'], self.H, self.W
-        for lv, sc in list(zip(self.lv, self._image_and_mask_pyramid_scales()))[:len(levels)]:
-            if sc != 1:
-                check(lib.unflow_downsample_fwd(ptr(prev_im), ptr(lv['im']), N, ph, pw, 3, sc, st), "downsample")
-            prev_im, ph, pw = lv['im'], lv['h'], lv['w']
+        scales = self._image_and_mask_pyramid_scales()
+        if len(levels) == 5 and scales[:5] == [4, 2, 2, 2, 2] and len(self.lv) == 5:
+            # the default pyramid in one launch (each level bit-identical to the chained downsample calls)
+            import ctypes
+            ptrs = (ctypes.c_void_p * 5)(*[lv['im'].data_ptr() for lv in self.lv])
+            check(lib.unflow_image_pyramid5(ptr(self.act['im01']), ptrs, N, self.H, self.W, st), "image_pyramid5")
+        else:
+            prev_im, ph, pw = self.act['im01'], self.H, self.W
+            for lv, sc in list(zip(self.lv, scales))[:len(levels)]:
+                if sc != 1:
+                    check(lib.unflow_downsample_fwd(ptr(prev_im), ptr(lv['im']), N, ph, pw, 3, sc, st), "downsample")
+                prev_im, ph, pw = lv['im'], lv['h'], lv['w']
         need_fbwarp = bool(wt('fb')) or occl == 1
         need_fwarp = bool(wt('sym')) or occl == 2
         need_mask_terms = need_fbwarp or need_fwarp or bool(wt('occ')) or not use_border

@@ -619,6 +619,77 @@ __global__ void downsample_kernel(const float* __restrict__ img, float* __restri
   }
 }
 
+// The image pyramid of the loss (unsupervised.py:99-100,145-146: downsample(im, 4), then four times downsample(., 2)) in ONE
+// launch: a workgroup owns a 64 x 64 tile of the full-resolution image = 16 x 16 / 8 x 8 / 4 x 4 / 2 x 2 / 1 pixels of the five
+// levels; every level is the box mean of the previous level's VALUES with downsample_kernel's own summation order (rows outer,
+// columns inner, then one division by scale^2), handed down through LDS — so each level is bit-identical to the chain of five
+// launches it replaces (each 5-6 us of latency on the step's critical path).  H, W multiples of 64, C = 3.
+__global__ __launch_bounds__(256) void image_pyramid5_kernel(const float* __restrict__ img, float* __restrict__ l0, float* __restrict__ l1,
+                                                              float* __restrict__ l2, float* __restrict__ l3, float* __restrict__ l4,
+                                                              int H, int W) {
+  __shared__ float lv[2][16 * 16 * 3];
+  const int tiles_x = W >> 6, tiles_y = H >> 6;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int n = t / tiles_y;
+  const int tid = threadIdx.x;
+  {   // level 0: 16 x 16 pixels per tile, each the mean of 4 x 4 full-resolution pixels
+    const int ox = tid & 15, oy = tid >> 4;
+    const float* src = img + (((long)n * H + (ty * 64 + oy * 4)) * W + tx * 64 + ox * 4) * 3;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int yy = 0; yy < 4; yy++)
+      for (int xx = 0; xx < 4; xx++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) s[c] += src[((long)yy * W + xx) * 3 + c];
+    const int h0 = H >> 2, w0 = W >> 2;
+    float* dst = l0 + (((long)n * h0 + ty * 16 + oy) * w0 + tx * 16 + ox) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float v = s[c] / 16.0f;
+      dst[c] = v;
+      lv[0][(oy * 16 + ox) * 3 + c] = v;
+    }
+  }
+  float* outs[4] = {l1, l2, l3, l4};
+  int side = 16;                                  // pixels per tile side of the level held in lv[cur]
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    __syncthreads();
+    const int cur = k & 1, ns = side >> 1;
+    if (tid < ns * ns) {
+      const int ox = tid % ns, oy = tid / ns;
+      float s[3] = {0.f, 0.f, 0.f};
+      for (int yy = 0; yy < 2; yy++)
+        for (int xx = 0; xx < 2; xx++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) s[c] += lv[cur][((oy * 2 + yy) * side + ox * 2 + xx) * 3 + c];
+      const int hk = H >> (3 + k), wk = W >> (3 + k);
+      float* dst = outs[k] + (((long)n * hk + ty * ns + oy) * wk + tx * ns + ox) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float v = s[c] / 4.0f;
+        dst[c] = v;
+        lv[cur ^ 1][(oy * ns + ox) * 3 + c] = v;
+      }
+    }
+    side = ns;
+  }
+}
+
+// levels[0..4]: [N, H/4, W/4, 3], [N, H/8, W/8, 3], ... [N, H/64, W/64, 3]
+UNFLOW_API int unflow_image_pyramid5(const float* images, float* const* levels, int N, int H, int W, unflow_stream_t stream) {
+  if (!images || !levels) return UNFLOW_ERR_NULL;
+  for (int k = 0; k < 5; k++)
+    if (!levels[k]) return UNFLOW_ERR_NULL;
+  if (N < 0 || H <= 0 || W <= 0) return UNFLOW_ERR_SHAPE;
+  if (H % 64 != 0 || W % 64 != 0) return UNFLOW_ERR_NOT_DIVISIBLE;
+  if (N == 0) return UNFLOW_OK;
+  image_pyramid5_kernel<<<N * (H >> 6) * (W >> 6), 256, 0, as_stream(stream)>>>(images, levels[0], levels[1], levels[2], levels[3],
+                                                                                levels[4], H, W);
+  return launch_status();
+}
+
 UNFLOW_API int unflow_downsample_fwd(const float* images, float* out, int B, int H, int W, int C, int scale,
                                      unflow_stream_t stream) {
   if (!images || !out) return UNFLOW_ERR_NULL;
