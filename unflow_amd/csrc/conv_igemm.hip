@@ -1268,36 +1268,48 @@ __global__ __launch_bounds__(256) void pointwise32_dgrad_kernel(const SkinnyBwdP
 }
 
 // ------------------------------------------------------------------ tiny deconv (flowN_upM: 2 -> 2 channels, k4 s2)
-// y[b,oy,ox,co] = bias + sum over the <=4 valid taps: oy = 2*iy + ky - 1.
+// y[b,oy,ox,co] = bias + sum over the <=4 valid taps: oy = 2*iy + ky - 1.  These kernels sit in the serial chain of the decoder
+// (four forward, four backward launches per step) and are pure latency: every tap is loaded unconditionally from a clamped
+// address and masked afterwards (a `continue` per tap made the loads a chain of dependent L2 round trips), the pixel decode is
+// 32-bit (a 64-bit div / mod pair is ~200 instructions), and invalid taps add +0 in the same order as before.
 template <int CI, int CO>
 __global__ void tiny_deconv_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                        const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int H,
                                        int W, const PlaneOut po) {
-  const int OH = 2 * H, OW = 2 * W;
-  const long n = (long)B * OH * OW;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const int ox = (int)(e % OW), oy = (int)((e / OW) % OH);
-    const long b = e / ((long)OW * OH);
+  const unsigned OH = 2u * (unsigned)H, OW = 2u * (unsigned)W;
+  const unsigned n = (unsigned)B * OH * OW;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(e, OW, OH);
+    const int ox = pp.x, oy = pp.y, b = pp.n;
+    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
+    float xv[2][2][CI];
+    bool ok[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int iy = ((oy + 1 - ky0) >> 1) - a, ix = ((ox + 1 - kx0) >> 1) - c;       // taps (ky0 + 2a, kx0 + 2c)
+        ok[a][c] = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float* xp = x + ((size_t)(b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * ldx;
+#pragma unroll
+        for (int ci = 0; ci < CI; ci++) xv[a][c][ci] = xp[ci];
+      }
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; c++) acc[c] = bias ? bias[c] : 0.f;
-    for (int ky = (oy + 1) & 1; ky < 4; ky += 2) {
-      const int iy = (oy + 1 - ky) >> 1;
-      if ((unsigned)iy >= (unsigned)H) continue;
-      for (int kx = (ox + 1) & 1; kx < 4; kx += 2) {
-        const int ix = (ox + 1 - kx) >> 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const float* xp = x + ((b * H + iy) * W + ix) * ldx;
-        const float* wp = w + (ky * 4 + kx) * CO * CI;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const float* wp = w + ((ky0 + 2 * a) * 4 + kx0 + 2 * c) * CO * CI;
 #pragma unroll
         for (int co = 0; co < CO; co++)
 #pragma unroll
-          for (int ci = 0; ci < CI; ci++) acc[co] += xp[ci] * wp[co * CI + ci];
+          for (int ci = 0; ci < CI; ci++) acc[co] += (ok[a][c] ? xv[a][c][ci] : 0.f) * wp[co * CI + ci];
       }
-    }
 #pragma unroll
     for (int c = 0; c < CO; c++) {
-      y[e * ldy + c] = acc[c];
+      y[(size_t)e * ldy + c] = acc[c];
       store_planes(po, (size_t)e, c, acc[c]);
     }
   }
@@ -1307,30 +1319,36 @@ template <int CI, int CO>
 __global__ void tiny_deconv_dgrad_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ w,
                                          float* __restrict__ dx, int lddx, int accumulate, int B, int H, int W) {
   const int OH = 2 * H, OW = 2 * W;
-  const long n = (long)B * H * W;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const int ix = (int)(e % W), iy = (int)((e / W) % H);
-    const long b = e / ((long)W * H);
+  const unsigned n = (unsigned)B * (unsigned)H * (unsigned)W;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const Pix pp = decode_pix(e, (unsigned)W, (unsigned)H);
+    const int ix = pp.x, iy = pp.y, b = pp.n;
+    float g[16][CO];
+    bool ok[16];
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 4; kx++) {
+        const int oy = 2 * iy + ky - 1, ox = 2 * ix + kx - 1;
+        ok[ky * 4 + kx] = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+        const float* gp = dz + ((size_t)(b * OH + min(max(oy, 0), OH - 1)) * OW + min(max(ox, 0), OW - 1)) * lddz;
+#pragma unroll
+        for (int co = 0; co < CO; co++) g[ky * 4 + kx][co] = gp[co];
+      }
     float acc[CI];
 #pragma unroll
     for (int c = 0; c < CI; c++) acc[c] = 0.f;
-    for (int ky = 0; ky < 4; ky++) {
-      const int oy = 2 * iy + ky - 1;
-      if ((unsigned)oy >= (unsigned)OH) continue;
-      for (int kx = 0; kx < 4; kx++) {
-        const int ox = 2 * ix + kx - 1;
-        if ((unsigned)ox >= (unsigned)OW) continue;
-        const float* gp = dz + ((b * OH + oy) * OW + ox) * lddz;
-        const float* wp = w + (ky * 4 + kx) * CO * CI;
 #pragma unroll
-        for (int co = 0; co < CO; co++)
+    for (int t = 0; t < 16; t++) {
+      const float* wp = w + t * CO * CI;
 #pragma unroll
-          for (int ci = 0; ci < CI; ci++) acc[ci] += gp[co] * wp[co * CI + ci];
-      }
+      for (int co = 0; co < CO; co++)
+#pragma unroll
+        for (int ci = 0; ci < CI; ci++) acc[ci] += (ok[t] ? g[t][co] : 0.f) * wp[co * CI + ci];
     }
 #pragma unroll
     for (int c = 0; c < CI; c++) {
-      float* d = dx + e * lddx + c;
+      float* d = dx + (size_t)e * lddx + c;
       *d = accumulate ? *d + acc[c] : acc[c];
     }
   }
@@ -1453,25 +1471,24 @@ __global__ __launch_bounds__(256) void flow_wgrad_batched_kernel(const FlowWgrad
   if (d.kind == 0) head3_wgrad_strip_body<8>(d.p, d.spw, bx, by, red);
   else head3_wgrad_strip_body<4>(d.p, d.spw, bx, by, red);
 }
-// Four lanes per element, each the serial sum of a quarter of the partials (8 loads in flight), combined in a fixed order:
-// (q0 + q1) + (q2 + q3) — the same value in every run.
+// Sixteen lanes per element: lane q sums the partials q, q + 16, q + 32, ... (<= 16 loads, all in flight at once — under the
+// backward pass's memory traffic a serial chain of 64 loads per thread made this kernel 80-100 us on the filter-gradient
+// stream, 7 us alone), then the sixteen lane sums are combined by a fixed butterfly ((q0 + q1) + (q2 + q3)) + ... — the same
+// value in every run.
 __global__ __launch_bounds__(256) void flow_wgrad_sum_kernel(const FlowWgradBatch b) {
   int di = 0;
   while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].rblock0) di++;
   const FlowWgradDesc& d = b.d[di];
-  const int e = (blockIdx.x - d.rblock0) * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+  const int e = (blockIdx.x - d.rblock0) * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
   const bool ok = e < d.wsz;
-  const int per = (d.chunks + 3) >> 2;
-  const int k0 = q * per, k1 = min(d.chunks, k0 + per);
   float v = 0.f;
   if (ok) {
-#pragma unroll 8
-    for (int k = k0; k < k1; k++) v += d.p.partial[(size_t)k * d.wsz + e];
+#pragma unroll 16
+    for (int k = q; k < d.chunks; k += 16) v += d.p.partial[(size_t)k * d.wsz + e];
   }
-  const float v1 = __shfl_down(v, 1, 64);
-  const float s01 = v + v1;                       // lanes q = 0 (q0 + q1) and q = 2 (q2 + q3) hold pair sums
-  const float s23 = __shfl_down(s01, 2, 64);
-  if (ok && q == 0) d.out[e] = s01 + s23;
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) v += __shfl_down(v, off, 64);      // lane q = 0 of each 16-lane group ends with the tree sum
+  if (ok && q == 0) d.out[e] = v;
 }
 
 // Batched column sums (all bias gradients of a step in one launch): block -> (descriptor, 64-col tile, row chunk).
@@ -2113,7 +2130,7 @@ UNFLOW_API int unflow_flow_wgrad_batched(int n, const int* kind, const float* co
     d.block0 = blocks;
     blocks += d.chunks * d.colblocks;
     d.rblock0 = rblocks;
-    rblocks += cdiv(d.wsz, 64);
+    rblocks += cdiv(d.wsz, 16);
   }
   hipStream_t st = as_stream(stream);
   flow_wgrad_batched_kernel<<<blocks, 256, 0, st>>>(b);
