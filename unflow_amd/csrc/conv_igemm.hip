@@ -1042,6 +1042,107 @@ __global__ __launch_bounds__(256) void head3_fwd_strip_kernel(const SkinnyParams
   }
 }
 
+// 2-D form of the strip kernel for the large levels (flow2, flow3: the activation is 38-77 MB and the op is its HBM time): a wave
+// owns a tile of HT_R rows x 8 pixels.  The 72 filter values of a lane's channel quad stay in registers for the whole tile (the
+// strip kernel reloads a filter row per strip: 96 of 256 bytes per lane and input row), and an input row is loaded ONCE and
+// feeds the up to three output rows it belongs to — (HT_R + 2) / HT_R = 1.5 reads per activation byte instead of 3.
+// acc[r][o][co]: 64 wave sums, reduced by one halving butterfly after which lane l holds value l = (r, o, co).
+constexpr int HT_R = 4;
+__global__ __launch_bounds__(256) void head3_fwd_tile_kernel(const SkinnyParams p) {
+  constexpr int S = 8;
+  const int lane = threadIdx.x & 63;
+  const int strips = p.W / S, rtiles = (p.H + HT_R - 1) / HT_R;
+  const long njobs = (long)p.B * rtiles * strips;
+  const long job = (long)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
+  if (job >= njobs) return;
+  const int xs = (int)(job % strips);
+  const long rowt = job / strips;
+  const int y0 = (int)(rowt % rtiles) * HT_R;
+  const long b = rowt / rtiles;
+  const int x0 = xs * S;
+  const int Cq = p.Cin >> 2;
+  float acc[HT_R][2 * S];
+#pragma unroll
+  for (int r = 0; r < HT_R; r++)
+#pragma unroll
+    for (int o = 0; o < 2 * S; o++) acc[r][o] = 0.f;
+  for (int g0 = 0; g0 < Cq; g0 += 64) {
+    const bool active = g0 + lane < Cq;
+    const int c4 = min(g0 + lane, Cq - 1);          // clamped: every load below is unconditional and in range
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const float* wp = p.w + ((size_t)t * p.Cin + c4 * 4) * 2;
+      const float4 wa = ldg4(wp), wb = ldg4(wp + 4);
+      wr[t][0] = wa.x; wr[t][1] = wa.y; wr[t][2] = wa.z; wr[t][3] = wa.w;
+      wr[t][4] = wb.x; wr[t][5] = wb.y; wr[t][6] = wb.z; wr[t][7] = wb.w;
+    }
+#pragma unroll
+    for (int ri = 0; ri < HT_R + 2; ri++) {          // input row y0 - 1 + ri: output row r = ri - ky takes it through filter row ky
+      const int iy = y0 - 1 + ri;
+      if ((unsigned)iy >= (unsigned)p.H) continue;   // wave-uniform (zero padding: nothing to add)
+      const float* xrow = p.x + ((b * p.H + iy) * p.W) * p.ldx + c4 * 4;
+      float4 xv[S + 2];
+#pragma unroll
+      for (int i = 0; i < S + 2; i++) {
+        const int ix = x0 - 1 + i;
+        const float4 t = ldg4(xrow + (long)min(max(ix, 0), p.W - 1) * p.ldx);
+        const bool ok = active && (unsigned)ix < (unsigned)p.W;
+        xv[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const int r = ri - ky;
+        if (r < 0 || r >= HT_R) continue;            // compile-time after unrolling
+#pragma unroll
+        for (int o = 0; o < S; o++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const float4 v = xv[o + kx];
+            const float* q = wr[ky * 3 + kx];
+            float* a = acc[r];
+            a[2 * o] = fmaf(v.x, q[0], a[2 * o]); a[2 * o + 1] = fmaf(v.x, q[1], a[2 * o + 1]);
+            a[2 * o] = fmaf(v.y, q[2], a[2 * o]); a[2 * o + 1] = fmaf(v.y, q[3], a[2 * o + 1]);
+            a[2 * o] = fmaf(v.z, q[4], a[2 * o]); a[2 * o + 1] = fmaf(v.z, q[5], a[2 * o + 1]);
+            a[2 * o] = fmaf(v.w, q[6], a[2 * o]); a[2 * o + 1] = fmaf(v.w, q[7], a[2 * o + 1]);
+          }
+      }
+    }
+  }
+  // 64 wave sums as one halving butterfly: afterwards lane l holds the wave total of value l = r * 16 + o * 2 + co
+  float v32[32], v16[16], v8[8], v4[4], v2[2];
+  {
+    const float* f = &acc[0][0];
+    const bool hi = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 32; i++) v32[i] = (hi ? f[32 + i] : f[i]) + __shfl_xor(hi ? f[i] : f[32 + i], 32);
+  }
+  {
+    const bool hi = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v16[i] = (hi ? v32[16 + i] : v32[i]) + __shfl_xor(hi ? v32[i] : v32[16 + i], 16);
+  }
+  {
+    const bool hi = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v8[i] = (hi ? v16[8 + i] : v16[i]) + __shfl_xor(hi ? v16[i] : v16[8 + i], 8);
+  }
+  {
+    const bool hi = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v4[i] = (hi ? v8[4 + i] : v8[i]) + __shfl_xor(hi ? v8[i] : v8[4 + i], 4);
+  }
+  {
+    const bool hi = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) v2[i] = (hi ? v4[2 + i] : v4[i]) + __shfl_xor(hi ? v4[i] : v4[2 + i], 2);
+  }
+  const bool hi1 = lane & 1;
+  const float tot = (hi1 ? v2[1] : v2[0]) + __shfl_xor(hi1 ? v2[0] : v2[1], 1);
+  const int r = lane >> 4, o = (lane >> 1) & 7, co = lane & 1;
+  if (y0 + r < p.H) p.y[((b * p.H + y0 + r) * p.W + x0 + o) * p.ldy + co] = tot + (p.bias ? p.bias[co] : 0.f);
+}
+
 // One row of the wave-uniform dz window (columns x0-1 .. x0+S, 2 channels = 2*(S+2) floats, zero outside the image):
 // lane l < 2*(S+2) loads element l in ONE coalesced instruction; consumers broadcast with v_readlane (an SGPR operand).
 template <int S>
@@ -1862,8 +1963,8 @@ int unflow_conv2d_fwd_po(const float* x, int ldx, const float* w, const float* b
     SkinnyParams p{x, ldx, w, bias, y, ldy, B, H, W, Cin, k, pt, pl};
     const int S = head_strip(B, H, W, k, Cout);
     if (S == 8) {
-      const long jobs = (long)B * H * (W / 8);
-      head3_fwd_strip_kernel<8, false><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+      const long jobs = (long)B * cdiv(H, HT_R) * (W / 8);      // 4 x 8-pixel tiles: filter resident, 1.5 reads per input row
+      head3_fwd_tile_kernel<<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
       return launch_status();
     }
     if (S == 4) {
