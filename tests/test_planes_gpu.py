@@ -387,7 +387,20 @@ CORR_PL_CASES = [
     (2, 128, 7, 80, dict(kernel_size=1, max_displacement=10, pad=10, stride_1=1, stride_2=1)),    # r = 10 at stride_2 = 1
     (2, 128, 9, 40, dict(kernel_size=1, max_displacement=8, pad=12, stride_1=1, stride_2=1)),     # pad > displacement
     (2, 192, 5, 33, dict(kernel_size=1, max_displacement=14, pad=14, stride_1=1, stride_2=2)),    # 3 waves, r = 7
+    # a wave pair per output row (C = 128 / 256): groups of four rows, ragged last group, two column tiles, both stride_2
+    (2, 256, 13, 70, dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)),   # 7 + 6 rows per class, 2 tiles
+    (2, 256, 9, 30, dict(kernel_size=1, max_displacement=10, pad=10, stride_1=1, stride_2=1)),    # 9 rows: groups of 4, 4, 1
+    (4, 256, 10, 64, dict(kernel_size=1, max_displacement=16, pad=18, stride_1=1, stride_2=2)),   # r = 8, pad > displacement
 ]
+# the cases corr_fwd_rw_kernel takes by default; with corr_rw = 0 they run on corr_fwd_wb_kernel (its A/B, and the C = 64 / 192 kernel)
+CORR_RW_CASES = [c for c in CORR_PL_CASES if c[1] in (128, 256) and not (c[4]['max_displacement'] // c[4]['stride_2'] <= 6 and c[3] / c[4]['stride_2'] > 32)]
+
+
+@pytest.mark.parametrize("case", CORR_RW_CASES)
+def test_correlation_planes_fwd_wide_band_kernel_vs_oracle(case, dev, oracle_lib, lib_option):
+    """The K-split wide-band kernel on the shapes the wave-pair kernel takes by default."""
+    lib_option("corr_rw", 0)
+    test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib)
 
 
 @pytest.mark.parametrize("case", CORR_PL_CASES)

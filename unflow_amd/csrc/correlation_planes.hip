@@ -7,6 +7,8 @@
 // Forward kernels (corr_pl_fwd picks one):
 //   corr_fwd_wb_kernel  wide band (r > 6, or one site tile per row), C % 64 == 0, C <= 256 — the training step's shape:
 //                       K split over the waves, f1 tiles by LDS-DMA in whole cache lines, two output rows per block.
+//   corr_fwd_rw_kernel  wide band, C = 128 or 256: a wave pair per output row, four rows per workgroup sharing whole f1 tiles
+//                       (the step's kernel since round 4; corr_fwd_wb_kernel stays for C = 64 / 192 and as its A/B).
 //   corr_fwd_nb_kernel  narrow band (r <= 6 over several site tiles: the +-4 / 81-channel cost volume), same limits on C:
 //                       tiles own 32 - 2r sites, one Gram per displacement row.
 //   corr_fwd_pl_kernel  every other C % 16 == 0: the first planes kernel.  A block owns (sample, row, class, 32-site tile): its
@@ -17,6 +19,7 @@
 //                       instruction, which is what bounds it.
 // Backward: corr_bwd_pl_kernel (C % 64 == 0), feature operand from the planes by LDS-DMA + transposing reads.
 #include <cstdlib>
+#include <type_traits>
 #include "igemm_shared.h"
 #include "options.h"
 #include "correlation_geom.h"
@@ -528,6 +531,238 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_wb_kernel(const CorrPlParams 
 }
 
 
+// --------------------------------------------------------------------------------- wide-band forward, a wave pair per output row
+// corr_fwd_wb_kernel splits K over its four waves, so every 32 x 32 Gram exists as four partial Grams that have to meet in LDS
+// in a DIFFERENT element order than the accumulators hold them (store 4 KB per wave and row, barrier, scalar band sums,
+// barrier): 44 of its 108 us (profiles/r03_corr_ablation.txt).  Here the work is cut by OUTPUT ROW instead: a workgroup owns
+// RW_ROWS rows of one row class, oy + s2 k, and streams the f1 rows m = 0 .. gw + RW_ROWS - 2 they share ONCE for all of them
+// (row m is displacement row m - k of output row k: 6 tile loads per output row at the step's shape, 10.5 before) — whole tiles
+// of 32 sites x C channels x 3 planes, double-buffered, LDS-DMA in whole lines, every wave moving its share.  A row belongs to
+// a PAIR of waves, each holding the f0 fragments of half the channels in registers (96 VGPRs at C = 256).  A Gram is then two
+// partials in the SAME register layout: one wave of the pair parks its 16 accumulators in a private 4 KB slot (four 16-byte
+// stores per lane), and after the step's single barrier — the one that also hands the tile buffers over — the other adds them
+// with four 16-byte reads.  The finishing role alternates inside the pair by step, so both waves carry the same load and a slot
+// is rewritten only two barriers after it was read; a + b == b + a, so the alternation does not show in the bits.
+// The band leaves the registers BAND-major: for accumulator e (Gram rows li = lc(e) + 4 h) lane l31 of a half-wave takes
+// displacement o = l31, i.e. column li + l31 - r, from its neighbour by ds_bpermute and the half-wave writes the 2r+1 entries of
+// one output pixel as ONE run — including the zeros of columns that fall into a column tile outside the image (written by the
+// row's first live tile) and the all-zero bands of f1 rows outside the image (a step without tile and products), so there is
+// no separate zero-fill pass.  Which accumulators of a lane belong to which column tile depends on the lane only: three 16-bit
+// masks, computed once.  The previous step's band is finished INSIDE the straight-line block of this step's products (stores
+// through a bounds-checked buffer descriptor instead of branches), so its address arithmetic and stores run under the MFMAs.
+constexpr int RW_ROWS = 4;
+template <int CH>                                      // 64-channel chunks per K half: C = 128 CH
+__global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  constexpr int CHUNK = 3 * 32 * 64;                   // elements of a 64-channel chunk of a tile: 3 planes x 32 sites x 64 channels
+  constexpr int NCH = 2 * CH;                          // chunks of a tile
+  constexpr int TILE = NCH * CHUNK;
+  constexpr int NU = 4 * CH;                           // K16 steps of a wave
+  constexpr int EPU = 16 / NU;                         // band accumulators finished per K16 step
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rw = wid >> 1, kh = wid & 1;               // output row of the group, K half
+  const int l31 = lane & 31, h = lane >> 5;
+  int b = xcd_remap(blockIdx.x, gridDim.x, 1);         // row groups fastest, samples slowest (the step's 8 samples: one per XCD)
+  const int npr = ((p.oh + p.s2 - 1) / p.s2 + RW_ROWS - 1) / RW_ROWS;
+  const int pr = b % npr; b /= npr;
+  const int ry = b % p.s2; b /= p.s2;
+  const int ia = b % p.nA; b /= p.nA;
+  const int q = b % p.s2; b /= p.s2;
+  const int n = b;
+  const int oy = ry + p.s2 * RW_ROWS * pr;
+  if (oy >= p.oh) return;
+  const int nv = min(RW_ROWS, (p.oh - oy + p.s2 - 1) / p.s2);      // rows of the group that exist
+  const int i0 = ia * 32;
+  const int n1 = (n + p.shift) % p.B;
+  const int y0 = oy + p.off;
+  const int ld2 = p.ld * 2;
+  const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
+  u32x4 f1_rs[3];
+  __amdgpu_buffer_rsrc_t f0_rs[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    f0_rs[pl] = make_rsrc(p.f0 + pl * p.ps, recs);
+    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
+  }
+  const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(p.out, (((size_t)p.B * p.oh * p.ow - 1) * (size_t)p.ld_out + (size_t)p.gw * p.gw) * 4);
+  const unsigned tiles_addr = lds_addr(lds);
+  float* slots = reinterpret_cast<float*>(lds + 2 * TILE);         // [wave][4][64 lanes][4]: a wave's accumulators as they lie
+  float* myslot = slots + wid * 1024 + lane * 4;
+  const float* peer = slots + (wid ^ 1) * 1024 + lane * 4;
+
+  // the wave's f0 fragments: row rw, channels 64 CH kh + 16 u + 8 h ..+7 (in flight together with the first f1 tile)
+  s16x8 af[NU][3];
+  {
+    const int xs = q + p.off + p.s2 * (i0 + l31);
+    const int yy = y0 + rw * p.s2;
+    const bool ok = (unsigned)xs < (unsigned)p.W && (unsigned)yy < (unsigned)p.H && rw < nv;
+    const int voff = ok ? ((n * p.H + yy) * p.W + xs) * ld2 + (kh * 64 * CH + h * 8) * 2 : OOB_MARK;
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) af[u][pl] = __builtin_bit_cast(s16x8, buf_ld16(f0_rs[pl], voff + u * 32));
+  }
+  // a tile = NCH chunks x 4 groups of 8 sites x 3 planes of 1 KB DMA instructions; wave w moves NCH / 2 (chunk, group) units
+  const int d_site = lane >> 3, d_slot = lane & 7;     // DMA lane mapping: see corr_fwd_nb_kernel
+  auto issue_tile = [&](int m, int t, int buf) {
+    const int yy = y0 + p.s2 * (m - p.r), k0 = i0 + 32 * t;
+#pragma unroll
+    for (int i = 0; i < NCH / 2; i++) {
+      const int un = wid * (NCH / 2) + i, ch = un >> 2, j = un & 3;
+      const int site = 8 * j + d_site;
+      const int g = d_slot ^ ((site >> 1) & 7);
+      const int xs = q + p.off + p.s2 * (k0 + site);
+      const bool ok = (unsigned)xs < (unsigned)p.W;
+      const int voff = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + (ch * 64 + g * 8) * 2 : OOB_MARK;
+      const unsigned d = tiles_addr + (unsigned)((buf * TILE + ch * CHUNK) * 2 + j * 1024);
+      dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+    }
+  };
+  const int M = p.gw + nv - 1;                         // f1 rows y0 + s2 (m - r): row m is displacement row m - k of output row k
+  auto col_live = [&](int t) -> bool {                 // has column tile t a site inside the image?
+    const int k0 = i0 + 32 * t;
+    return q + p.off + p.s2 * k0 < p.W && q + p.off + p.s2 * (k0 + 31) >= 0;
+  };
+  // column tiles -1, 0, 1 (the host admits r <= 15: a band reaches one tile to either side)
+  const int dead_cols = (p.T >= 1 && col_live(-1) ? 0 : 1) | (col_live(0) ? 0 : 2) | (p.T >= 1 && col_live(1) ? 0 : 4);
+  const int first_t = !(dead_cols & 1) ? -1 : !(dead_cols & 2) ? 0 : 1;              // (unused when all three are dead)
+  auto row_live = [&](int m) -> bool { return dead_cols != 7 && (unsigned)(y0 + p.s2 * (m - p.r)) < (unsigned)p.H; };
+  // steps: one per (live f1 row, live column tile); ONE for an f1 row that is multiplied with nothing (t = 2: matches no tile)
+  auto next_step = [&](int& m, int& t) -> bool {
+    for (;;) {
+      if (t >= 1 || t >= p.T) { t = -p.T; m++; } else t++;
+      if (m >= M) return false;
+      if (!row_live(m)) { t = 2; return true; }
+      if (!((dead_cols >> (t + 1)) & 1)) return true;
+    }
+  };
+  int m = -1, t = 2;
+  bool cur_ok = next_step(m, t);
+  int cur_m = m, cur_t = t, cur_buf = 0, nbuf = 0;
+  if (cur_ok && cur_t != 2) { issue_tile(cur_m, cur_t, 0); nbuf = 1; }
+
+  // Accumulator e of a lane finishes band entry (row li = lc(e) + 4 h, displacement l31): column li + l31 - r, tile (that) >> 5.
+  // msk[tile + 1] bit e: the entry exists (pixel inside the output, l31 < gw) and its column lies in that tile.
+  int msk[3] = {0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int li = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int jabs = li + l31 - p.r;
+    const bool ok = l31 < p.gw && q + p.s2 * (i0 + li) < p.ow;
+#pragma unroll
+    for (int tj = 0; tj < 3; tj++)
+      if (ok && (jabs >> 5) == tj - 1) msk[tj] |= 1 << e;
+  }
+  const int perm0 = 4 * (4 * h + l31 - p.r);            // ds_bpermute: 4 x the column of accumulator 0's entry (+ 4 lc(e); mod 32 = the lane of its half)
+  const int lane_out = ((q + p.s2 * (i0 + 4 * h)) * p.ld_out + l31) * 4;      // byte offset of (row 4 h, displacement l31) in a band
+  const int lc_bytes = p.s2 * p.ld_out * 4;                                   // one Gram row further = one output pixel of the class
+  const float rcf = 1.0f / (float)p.C;                  // C is a power of two here: x * (1/C) == x / C exactly
+
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.f;
+  // one step's straight-line block: FIN — finish the previous step's Gram held in acc (add the partner's half, band-major
+  // stores); MF — this step's products into a fresh acc.  take / any: the lane's accumulators that carry a value / are stored.
+  auto block = [&](auto mf_tag, auto fin_tag, int buf, int take, int any, int out_soff) {
+    constexpr bool MF = decltype(mf_tag)::value, FIN = decltype(fin_tag)::value;
+    f32x16 prev;
+    if (FIN) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 o = *reinterpret_cast<const float4*>(peer + j * 256);
+        prev[4 * j] = acc[4 * j] + o.x; prev[4 * j + 1] = acc[4 * j + 1] + o.y;
+        prev[4 * j + 2] = acc[4 * j + 2] + o.z; prev[4 * j + 3] = acc[4 * j + 3] + o.w;
+      }
+    }
+    if (MF) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    }
+    const unsigned short* tl = lds + buf * TILE + kh * CH * CHUNK + l31 * 64;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      if (MF) {
+        s16x8 bf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+          bf[pl] = *reinterpret_cast<const s16x8*>(tl + (u >> 2) * CHUNK + pl * (32 * 64) + (((2 * (u & 3) + h) ^ ((l31 >> 1) & 7)) << 3));
+#pragma unroll
+        for (int tt = 0; tt < 6; tt++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
+                                                        __builtin_bit_cast(bf16x8, bf[tb[tt]]), acc, 0, 0, 0);
+      }
+      if (FIN) {
+#pragma unroll
+        for (int ee = 0; ee < EPU; ee++) {
+          const int e = u * EPU + ee, lc = (e & 3) + 8 * (e >> 2);
+          const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(((perm0 + 4 * lc) & 124) | (h << 7), __float_as_int(prev[e])));
+          const float val = (take >> e) & 1 ? v * rcf : 0.f;
+          const int voff = (any >> e) & 1 ? lane_out : OOB_MARK;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_rs, voff, out_soff + lc * lc_bytes, 0);
+        }
+      }
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  bool fin_prev = false;                               // this wave holds the finishing half of the previous step's Gram
+  int prv_m = 0, prv_t = 2, step = 0;
+#pragma unroll 1
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the current tile has landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                      // ... everybody's; the other buffer and the slots written last step are free / ready
+    __builtin_amdgcn_sched_barrier(0);
+    bool nxt_ok = false;
+    int nxt_m = 0, nxt_t = 2, nxt_buf = 0;
+    if (cur_ok) {
+      nxt_ok = next_step(m, t);
+      nxt_m = m; nxt_t = t;
+      if (nxt_ok && nxt_t != 2) { nxt_buf = nbuf; issue_tile(nxt_m, nxt_t, nbuf); nbuf ^= 1; }
+    }
+    // the previous step's band: values from the Gram of tile prv_t; zeros for the dead tiles' columns with its row's first tile
+    int take = 0, any = 0, out_soff = 0;
+    if (fin_prev) {
+      take = prv_t == -1 ? msk[0] : prv_t == 0 ? msk[1] : prv_t == 1 ? msk[2] : 0;
+      any = take;
+      if (prv_t == 2 || prv_t == first_t) {
+        const int dc = prv_t == 2 ? 7 : dead_cols;
+        any |= (dc & 1 ? msk[0] : 0) | (dc & 2 ? msk[1] : 0) | (dc & 4 ? msk[2] : 0);
+      }
+      out_soff = ((((n * p.oh + oy + rw * p.s2) * p.ow) * p.ld_out) + (prv_m - rw) * p.gw) * 4;
+    }
+    const int pi = cur_m - rw;
+    const bool mine = cur_ok && pi >= 0 && pi < p.gw && rw < nv;     // (uniform in the pair)
+    const bool mf = mine && cur_t != 2;
+    if (mf) {
+      if (fin_prev) block(T_{}, T_{}, cur_buf, take, any, out_soff);
+      else block(T_{}, F_{}, cur_buf, 0, 0, 0);
+    } else if (fin_prev) {
+      block(F_{}, T_{}, 0, take, any, out_soff);
+    }
+    if (!cur_ok) break;
+    if (mine && !mf) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;       // an f1 row outside the image: the band is zero
+    }
+    fin_prev = mine && ((step + rw) & 1) == kh;
+    if (mine && !fin_prev) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        *reinterpret_cast<float4*>(myslot + j * 256) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile reads and slot stores done before the next barrier
+    __builtin_amdgcn_sched_barrier(0);
+    prv_m = cur_m; prv_t = cur_t;
+    cur_ok = nxt_ok; cur_m = nxt_m; cur_t = nxt_t; cur_buf = nxt_buf;
+    step++;
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------ backward from planes
 // out[site][c] += Band(dOut)[site][k] * F[k][c] (correlation_mfma.hip: corr_bwd_b3_kernel) with the FEATURE operand taken from
 // its bf16 planes instead of being split in registers: per iteration a wave's 32 contracted sites x 64 channels x 3 planes
@@ -899,6 +1134,20 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
       nb_set = nb_smem;
     }
     corr_fwd_nb_kernel<<<B * p.nA * g.s2 * g.oh, 64 * nw, nb_smem, st>>>(p);
+    return launch_status();
+  }
+  const size_t out_bytes = (((size_t)B * g.oh * g.ow - 1) * (size_t)ld_out + (size_t)g.gw * g.gw) * 4;
+  if (p.joff == 0 && (C == 128 || C == 256) && al16 && g.r <= 15 && out_bytes <= 0x3fffffffu && unflow::options().corr_rw) {
+    const int npr = ((g.oh + g.s2 - 1) / g.s2 + RW_ROWS - 1) / RW_ROWS;      // groups of RW_ROWS rows per row class
+    const int smem = 2 * (C / 64) * (3 * 32 * 64 * 2) + 8 * 4096;             // two tiles + the waves' accumulator slots
+    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rw_kernel<1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 12288 + 8 * 4096);
+    static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rw_kernel<2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 12288 + 8 * 4096);
+    (void)a1; (void)a2;
+    const int blocks = B * g.s2 * p.nA * g.s2 * npr;
+    if (C == 128) corr_fwd_rw_kernel<1><<<blocks, 512, smem, st>>>(p);
+    else corr_fwd_rw_kernel<2><<<blocks, 512, smem, st>>>(p);
     return launch_status();
   }
   if (p.joff == 0 && C % 64 == 0 && C <= 256 && al16 && 32 * g.gw <= 6 * 64 * (C / 64) && corr_wb_enabled()) {

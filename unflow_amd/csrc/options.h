@@ -29,6 +29,7 @@
   X(wgrad_pp, 1)          /* ping-pong filter-gradient kernel (8 waves): 1 where it pays, 3 wherever eligible, 0 off */                                           \
   X(corr_nb, 1)           /* narrow-band correlation forward kernel */                                                    \
   X(corr_wb, 1)           /* wide-band correlation forward kernel */                                                      \
+  X(corr_rw, 1)           /* ... its wave-pair-per-row form (C = 128 / 256) */                                            \
   X(corr_bwd_b128, 1)     /* 16-byte band loads in the correlation backward */                                            \
   X(corr_bwd_rot, -1)     /* rotated displacement-row order in the correlation backward (-1: narrow band only) */         \
   X(corr_bwd_planes, 1)   /* correlation backward from the feature planes */                                              \
