@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from unflow_amd import _lib
+from unflow_amd._lib import ptr, stream, check, planes_of
+from unflow_amd.core import layers as L
+dev = torch.device("cuda:0")
+lib = _lib.lib()
+g = torch.Generator().manual_seed(0)
+pt = L.PT.alloc((8, 48, 64, 256), dev, 3)
+pt.t.copy_(torch.randn(8, 48, 64, 256, generator=g).to(dev))
+L.planes_from_f32(pt.t, pt.pl)
+f = pt.t
+st = stream()
+co = torch.zeros((8, 48, 64, 441), device=dev)
+for i in range(6):
+    check(lib.unflow_correlation_nhwc_fwd_pl(ptr(f), ptr(f), 256, planes_of(pt.pl), planes_of(pt.pl), 4, ptr(co), 441, 8, 256, 48, 64, 1, 20, 20, 1, 2, st))
+torch.cuda.synchronize()

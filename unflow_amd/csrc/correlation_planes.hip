@@ -31,6 +31,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Phase trace of corr_fwd_rw_kernel (diagnostic builds only: -DUNFLOW_CORR_TRACE=<workgroup>, tools/debug/corr_phase_trace.py):
+// every wave of that workgroup sums shader cycles per phase of a step in registers; never compiled into the shipped library.
+#ifdef UNFLOW_CORR_TRACE
+__device__ unsigned long long g_corr_trace[8 * 8];
+#define CT_DECL unsigned long long ct_prev = __builtin_readcyclecounter(), ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CT_STAMP(slot) do { const unsigned long long ct_now = __builtin_readcyclecounter(); ct_acc[slot] += ct_now - ct_prev; ct_prev = ct_now; } while (0)
+#define CT_COUNT(slot) do { ct_acc[slot]++; } while (0)
+#define CT_FLUSH do { if (blockIdx.x == UNFLOW_CORR_TRACE && (threadIdx.x & 63) == 0) for (int ct_i = 0; ct_i < 8; ct_i++) g_corr_trace[(threadIdx.x >> 6) * 8 + ct_i] = ct_acc[ct_i]; } while (0)
+#else
+#define CT_DECL do { } while (0)
+#define CT_STAMP(slot) do { } while (0)
+#define CT_COUNT(slot) do { } while (0)
+#define CT_FLUSH do { } while (0)
+#endif
+
 struct CorrPlParams {
   const unsigned short* f0;   // planes of in0, channel 0 of the feature slice; [pixel][ld] per plane
   const unsigned short* f1;
@@ -554,11 +569,12 @@ constexpr int RW_ROWS = 4;
 template <int CH>                                      // 64-channel chunks per K half: C = 128 CH
 __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  CT_DECL;
   constexpr int CHUNK = 3 * 32 * 64;                   // elements of a 64-channel chunk of a tile: 3 planes x 32 sites x 64 channels
   constexpr int NCH = 2 * CH;                          // chunks of a tile
   constexpr int TILE = NCH * CHUNK;
   constexpr int NU = 4 * CH;                           // K16 steps of a wave
-  constexpr int EPU = 16 / NU;                         // band accumulators finished per K16 step
+  constexpr int FPU = CH == 1 ? 16 : 4;                // band accumulators finished per K16 step (from step 3 on)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int rw = wid >> 1, kh = wid & 1;               // output row of the group, K half
@@ -579,94 +595,148 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
   const int ld2 = p.ld * 2;
   const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
   u32x4 f1_rs[3];
-  __amdgpu_buffer_rsrc_t f0_rs[3];
 #pragma unroll
-  for (int pl = 0; pl < 3; pl++) {
-    f0_rs[pl] = make_rsrc(p.f0 + pl * p.ps, recs);
-    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
-  }
+  for (int pl = 0; pl < 3; pl++) f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
   const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(p.out, (((size_t)p.B * p.oh * p.ow - 1) * (size_t)p.ld_out + (size_t)p.gw * p.gw) * 4);
   const unsigned tiles_addr = lds_addr(lds);
   float* slots = reinterpret_cast<float*>(lds + 2 * TILE);         // [wave][4][64 lanes][4]: a wave's accumulators as they lie
   float* myslot = slots + wid * 1024 + lane * 4;
   const float* peer = slots + (wid ^ 1) * 1024 + lane * 4;
 
-  // the wave's f0 fragments: row rw, channels 64 CH kh + 16 u + 8 h ..+7 (in flight together with the first f1 tile)
+  // the wave's f0 fragments: row rw, channels 64 CH kh + 16 u + 8 h ..+7, straight to registers (in flight together with the
+  // first f1 tile).  (Measured: the same rows by whole-line DMA into the two tile buffers, two rows at a time, fragments then
+  // read from LDS — 8 x fewer cache-line look-ups — is no faster: the prologue is the cold first fetch of 37 MB by all
+  // workgroups at once, and the two barrier-separated rounds cost what the look-ups saved: 62.2 against 61.0 us.)
   s16x8 af[NU][3];
   {
     const int xs = q + p.off + p.s2 * (i0 + l31);
     const int yy = y0 + rw * p.s2;
     const bool ok = (unsigned)xs < (unsigned)p.W && (unsigned)yy < (unsigned)p.H && rw < nv;
     const int voff = ok ? ((n * p.H + yy) * p.W + xs) * ld2 + (kh * 64 * CH + h * 8) * 2 : OOB_MARK;
+    const __amdgpu_buffer_rsrc_t f0_ld[3] = {make_rsrc(p.f0, recs), make_rsrc(p.f0 + p.ps, recs), make_rsrc(p.f0 + 2 * p.ps, recs)};
 #pragma unroll
     for (int u = 0; u < NU; u++)
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) af[u][pl] = __builtin_bit_cast(s16x8, buf_ld16(f0_rs[pl], voff + u * 32));
+      for (int pl = 0; pl < 3; pl++) af[u][pl] = __builtin_bit_cast(s16x8, buf_ld16(f0_ld[pl], voff + u * 32));
   }
-  // a tile = NCH chunks x 4 groups of 8 sites x 3 planes of 1 KB DMA instructions; wave w moves NCH / 2 (chunk, group) units
+  // a tile = NCH chunks x 4 groups of 8 sites x 3 planes of 1 KB DMA instructions; wave w moves NCH / 2 (chunk, group) units.
   const int d_site = lane >> 3, d_slot = lane & 7;     // DMA lane mapping: see corr_fwd_nb_kernel
-  auto issue_tile = [&](int m, int t, int buf) {
-    const int yy = y0 + p.s2 * (m - p.r), k0 = i0 + 32 * t;
+  int d_xs[NCH / 2], d_px[NCH / 2];
+#pragma unroll
+  for (int i = 0; i < NCH / 2; i++) {
+    const int un = wid * (NCH / 2) + i, ch = un >> 2, j = un & 3;
+    const int site = 8 * j + d_site;
+    d_px[i] = (ch * 64 + (d_slot ^ ((site >> 1) & 7)) * 8) * 2;
+    d_xs[i] = q + p.off + p.s2 * (i0 + site);
+  }
+  auto tile_voff = [&](int m, int t, bool real, int (&v)[NCH / 2]) __attribute__((always_inline)) {       // a lane's source offsets of f1 row m, column tile t
+    const int row = ((n1 * p.H + y0 + p.s2 * (m - p.r)) * p.W) * ld2;
 #pragma unroll
     for (int i = 0; i < NCH / 2; i++) {
-      const int un = wid * (NCH / 2) + i, ch = un >> 2, j = un & 3;
-      const int site = 8 * j + d_site;
-      const int g = d_slot ^ ((site >> 1) & 7);
-      const int xs = q + p.off + p.s2 * (k0 + site);
-      const bool ok = (unsigned)xs < (unsigned)p.W;
-      const int voff = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + (ch * 64 + g * 8) * 2 : OOB_MARK;
-      const unsigned d = tiles_addr + (unsigned)((buf * TILE + ch * CHUNK) * 2 + j * 1024);
-      dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+      const int xs = d_xs[i] + t * (32 * p.s2);
+      const int in = row + xs * ld2 + d_px[i];
+      const bool ok = (int)real & (int)((unsigned)xs < (unsigned)p.W);
+      v[i] = ok ? in : OOB_MARK;
     }
   };
+  auto unit_lds = [&](int i) __attribute__((always_inline)) -> unsigned {             // LDS byte offset of unit i inside a tile buffer
+    const int un = wid * (NCH / 2) + i;
+    return (unsigned)((un >> 2) * CHUNK * 2 + (un & 3) * 1024);
+  };
   const int M = p.gw + nv - 1;                         // f1 rows y0 + s2 (m - r): row m is displacement row m - k of output row k
-  auto col_live = [&](int t) -> bool {                 // has column tile t a site inside the image?
+  auto col_live = [&](int t) __attribute__((always_inline)) -> bool {                 // has column tile t a site inside the image?
     const int k0 = i0 + 32 * t;
     return q + p.off + p.s2 * k0 < p.W && q + p.off + p.s2 * (k0 + 31) >= 0;
   };
-  // column tiles -1, 0, 1 (the host admits r <= 15: a band reaches one tile to either side)
+  // column tiles -1, 0, 1 (the host admits r <= 15: a band reaches one tile to either side); the live ones in order: lt[0 .. nl)
   const int dead_cols = (p.T >= 1 && col_live(-1) ? 0 : 1) | (col_live(0) ? 0 : 2) | (p.T >= 1 && col_live(1) ? 0 : 4);
-  const int first_t = !(dead_cols & 1) ? -1 : !(dead_cols & 2) ? 0 : 1;              // (unused when all three are dead)
-  auto row_live = [&](int m) -> bool { return dead_cols != 7 && (unsigned)(y0 + p.s2 * (m - p.r)) < (unsigned)p.H; };
-  // steps: one per (live f1 row, live column tile); ONE for an f1 row that is multiplied with nothing (t = 2: matches no tile)
-  auto next_step = [&](int& m, int& t) -> bool {
-    for (;;) {
-      if (t >= 1 || t >= p.T) { t = -p.T; m++; } else t++;
-      if (m >= M) return false;
-      if (!row_live(m)) { t = 2; return true; }
-      if (!((dead_cols >> (t + 1)) & 1)) return true;
-    }
+  const int nl = 3 - __builtin_popcount(dead_cols);
+  const int lt0 = !(dead_cols & 1) ? -1 : !(dead_cols & 2) ? 0 : 1;
+  const int lt1 = !(dead_cols & 1) ? (!(dead_cols & 2) ? 0 : 1) : 1;
+  // (the selects below are written over plain values and bitwise conditions on purpose: a `?:` or `&&` with work in its arms
+  // reaches the back end as a branch, and a branch inside a step's block ends the region the MFMAs can be scheduled across)
+  auto row_live = [&](int m) __attribute__((always_inline)) -> int { return (int)(nl > 0) & (int)((unsigned)(y0 + p.s2 * (m - p.r)) < (unsigned)p.H); };
+  // Steps: one per (live f1 row, live column tile); ONE for an f1 row that is multiplied with nothing (t = 2: matches no tile).
+  // (m, j) -> the step after it, branch-free: it is computed inside the previous step's block, under its MFMAs.
+  auto step_after = [&](int m, int j, int& m2, int& j2, int& t2, bool& ok2) __attribute__((always_inline)) {
+    const int cnt = row_live(m) ? nl : 1;
+    const int wrap = (int)(j + 1 >= cnt);
+    m2 = m + wrap;
+    j2 = (j + 1) & (wrap - 1);
+    ok2 = m2 < M;
+    const int tlive = (-(int)(j2 == 0) & lt0) | (-(int)(j2 == 1) & lt1) | (-(int)(j2 >= 2) & 1);
+    t2 = row_live(m2) ? tlive : 2;
   };
-  int m = -1, t = 2;
-  bool cur_ok = next_step(m, t);
-  int cur_m = m, cur_t = t, cur_buf = 0, nbuf = 0;
-  if (cur_ok && cur_t != 2) { issue_tile(cur_m, cur_t, 0); nbuf = 1; }
 
   // Accumulator e of a lane finishes band entry (row li = lc(e) + 4 h, displacement l31): column li + l31 - r, tile (that) >> 5.
-  // msk[tile + 1] bit e: the entry exists (pixel inside the output, l31 < gw) and its column lies in that tile.
-  int msk[3] = {0, 0, 0};
+  // msk_lo / mid / hi (tile -1 / 0 / 1) bit e: the entry exists (pixel inside the output, l31 < gw) and its column lies in that tile.
+  int msk_lo = 0, msk_mid = 0, msk_hi = 0;             // (three scalars, not an array: a select between array elements becomes a scratch load)
 #pragma unroll
   for (int e = 0; e < 16; e++) {
     const int li = (e & 3) + 8 * (e >> 2) + 4 * h;
-    const int jabs = li + l31 - p.r;
-    const bool ok = l31 < p.gw && q + p.s2 * (i0 + li) < p.ow;
-#pragma unroll
-    for (int tj = 0; tj < 3; tj++)
-      if (ok && (jabs >> 5) == tj - 1) msk[tj] |= 1 << e;
+    const int tj = (li + l31 - p.r) >> 5;
+    const int bit = l31 < p.gw && q + p.s2 * (i0 + li) < p.ow ? 1 << e : 0;
+    msk_lo |= tj == -1 ? bit : 0;
+    msk_mid |= tj == 0 ? bit : 0;
+    msk_hi |= tj == 1 ? bit : 0;
   }
+  const int msk_all = msk_lo | msk_mid | msk_hi;
+  const int msk_dead = (dead_cols & 1 ? msk_lo : 0) | (dead_cols & 2 ? msk_mid : 0) | (dead_cols & 4 ? msk_hi : 0);
   const int perm0 = 4 * (4 * h + l31 - p.r);            // ds_bpermute: 4 x the column of accumulator 0's entry (+ 4 lc(e); mod 32 = the lane of its half)
   const int lane_out = ((q + p.s2 * (i0 + 4 * h)) * p.ld_out + l31) * 4;      // byte offset of (row 4 h, displacement l31) in a band
   const int lc_bytes = p.s2 * p.ld_out * 4;                                   // one Gram row further = one output pixel of the class
+  const int row_out = (((n * p.oh + oy + rw * p.s2) * p.ow) * p.ld_out - rw * p.gw) * 4;   // + 4 gw m: band (row rw, displacement row m - rw)
   const float rcf = 1.0f / (float)p.C;                  // C is a power of two here: x * (1/C) == x / C exactly
+
+  // ---- the step pipeline's registers: cur is multiplied in this step, nxt's tile is requested during it
+  int cur_m = 0, cur_t = row_live(0) ? lt0 : 2, cur_buf = 0, nbuf = 0;
+  bool cur_ok = M > 0;
+  if (cur_ok && cur_t != 2) {
+    int v[NCH / 2];
+    tile_voff(cur_m, cur_t, true, v);
+#pragma unroll
+    for (int i = 0; i < NCH / 2; i++) {
+      const unsigned d = tiles_addr + unit_lds(i);
+      dma3(v[i], f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+    }
+    nbuf = 1;
+  }
+  int nxt_m, nxt_j, nxt_t, nxt_buf;
+  bool nxt_ok;
+  step_after(cur_m, 0, nxt_m, nxt_j, nxt_t, nxt_ok);
+  int dvoff[NCH / 2];
+  tile_voff(nxt_m, nxt_t, nxt_ok && nxt_t != 2, dvoff);
+  unsigned dbase = tiles_addr + (unsigned)(nbuf * TILE * 2);
+  nxt_buf = nbuf;
+  nbuf ^= nxt_ok && nxt_t != 2 ? 1 : 0;
+  int take = 0, any = 0, out_soff = 0;                 // of the Gram being finished: set by the step that computed it
 
   constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; e++) acc[e] = 0.f;
-  // one step's straight-line block: FIN — finish the previous step's Gram held in acc (add the partner's half, band-major
-  // stores); MF — this step's products into a fresh acc.  take / any: the lane's accumulators that carry a value / are stored.
-  auto block = [&](auto mf_tag, auto fin_tag, int buf, int take, int any, int out_soff) {
+  // One step's straight-line block.  FIN: finish the previous step's Gram held in acc (add the partner's half, band-major
+  // stores; take / any: the lane's accumulators that carry a value / are stored) — in the first K16 steps, so that the stores
+  // have drained when the step ends.  MF: this step's products into a fresh acc, fragments one K16 step ahead.  Always: the
+  // wave's share of the NEXT tile, one 1 KB DMA instruction per K16 step (in one burst right after the barrier the 48
+  // instructions of a workgroup queue up in front of the address unit), and the bookkeeping of the step after next — which
+  // step, where its tile comes from, which accumulators the band of THIS step's Gram takes — about 150 scalar and vector
+  // instructions that cost 1200-1700 cycles per step when they sat between the barrier and the first MFMA
+  // (tools/debug/corr_phase_trace.py): inside the block they issue between the MFMAs.  dvoff = the out-of-range mark when
+  // there is no next tile: the DMA then only zero-fills a buffer nobody reads.
+  int nn_m, nn_j, nn_t, nn_buf, dvoff2[NCH / 2], take2, any2, out_soff2;
+  bool nn_ok;
+  unsigned dbase2;
+  auto block = [&](auto mf_tag, auto fin_tag) __attribute__((always_inline)) {
     constexpr bool MF = decltype(mf_tag)::value, FIN = decltype(fin_tag)::value;
+    const unsigned short* tl = lds + cur_buf * TILE + kh * CH * CHUNK + l31 * 64;
+    s16x8 bf[2][3];
+    auto rd = [&](int u, s16x8 (&o)[3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        o[pl] = *reinterpret_cast<const s16x8*>(tl + (u >> 2) * CHUNK + pl * (32 * 64) + (((2 * (u & 3) + h) ^ ((l31 >> 1) & 7)) << 3));
+    };
+    if (MF) rd(0, bf[0]);
     f32x16 prev;
     if (FIN) {
 #pragma unroll
@@ -680,23 +750,35 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[e] = 0.f;
     }
-    const unsigned short* tl = lds + buf * TILE + kh * CH * CHUNK + l31 * 64;
+    // the step after next and its tile; the band masks of this step's Gram
+    step_after(nxt_m, nxt_j, nn_m, nn_j, nn_t, nn_ok);
+    const bool nn_real = (int)nn_ok & (int)(nn_t != 2);
+    tile_voff(nn_m, nn_t, nn_real, dvoff2);
+    dbase2 = tiles_addr + (unsigned)(nbuf * TILE * 2);
+    nn_buf = nbuf;
+    nbuf ^= nn_real ? 1 : 0;
+    // (masks instead of `c ? a : b`: over two captured variables that is an lvalue — a select between ADDRESSES, which keeps
+    // every local of the kernel in scratch)
+    take2 = (-(int)(cur_t == -1) & msk_lo) | (-(int)(cur_t == 0) & msk_mid) | (-(int)(cur_t == 1) & msk_hi);
+    any2 = take2 | (-(int)(cur_t == lt0) & msk_dead) | (-(int)(cur_t == 2) & msk_all);
+    out_soff2 = row_out + cur_m * (p.gw * 4);
 #pragma unroll
     for (int u = 0; u < NU; u++) {
-      if (MF) {
-        s16x8 bf[3];
+      if (MF && u + 1 < NU) rd(u + 1, bf[(u + 1) & 1]);
+      if (u < 3) {                                     // early: the rest of the block covers their round trip
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-          bf[pl] = *reinterpret_cast<const s16x8*>(tl + (u >> 2) * CHUNK + pl * (32 * 64) + (((2 * (u & 3) + h) ^ ((l31 >> 1) & 7)) << 3));
+        for (int i = 0; i < NCH / 2; i++) dma1(dvoff[i], f1_rs[u], dbase + unit_lds(i) + u * (32 * 64 * 2));
+      }
+      if (MF) {
 #pragma unroll
         for (int tt = 0; tt < 6; tt++)
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
-                                                        __builtin_bit_cast(bf16x8, bf[tb[tt]]), acc, 0, 0, 0);
+                                                        __builtin_bit_cast(bf16x8, bf[u & 1][tb[tt]]), acc, 0, 0, 0);
       }
-      if (FIN) {
+      if (FIN && u >= 3 && (u - 3) * FPU < 16) {       // after the DMAs: 16 stores younger than every tile load
 #pragma unroll
-        for (int ee = 0; ee < EPU; ee++) {
-          const int e = u * EPU + ee, lc = (e & 3) + 8 * (e >> 2);
+        for (int ee = 0; ee < FPU; ee++) {
+          const int e = (u - 3) * FPU + ee, lc = (e & 3) + 8 * (e >> 2);
           const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(((perm0 + 4 * lc) & 124) | (h << 7), __float_as_int(prev[e])));
           const float val = (take >> e) & 1 ? v * rcf : 0.f;
           const int voff = (any >> e) & 1 ? lane_out : OOB_MARK;
@@ -709,40 +791,36 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
   using F_ = std::false_type;
 
   bool fin_prev = false;                               // this wave holds the finishing half of the previous step's Gram
-  int prv_m = 0, prv_t = 2, step = 0;
+  bool fin_blk = false;                                // ... and the last block finished one
+  int step = 0;
 #pragma unroll 1
   for (;;) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the current tile has landed
+    CT_STAMP(step == 0 ? 0 : 4);                       // 0: prologue; 4: tail of the previous step
+    // this wave's share of the current tile has landed (vmcnt retires in order on gfx9; the 16 band stores of a finishing
+    // block are all younger than its tile loads and may stay in flight)
+    if (fin_blk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    CT_STAMP(1);                                       // 1: waiting for the tile
     __builtin_amdgcn_s_barrier();                      // ... everybody's; the other buffer and the slots written last step are free / ready
     __builtin_amdgcn_sched_barrier(0);
-    bool nxt_ok = false;
-    int nxt_m = 0, nxt_t = 2, nxt_buf = 0;
-    if (cur_ok) {
-      nxt_ok = next_step(m, t);
-      nxt_m = m; nxt_t = t;
-      if (nxt_ok && nxt_t != 2) { nxt_buf = nbuf; issue_tile(nxt_m, nxt_t, nbuf); nbuf ^= 1; }
-    }
-    // the previous step's band: values from the Gram of tile prv_t; zeros for the dead tiles' columns with its row's first tile
-    int take = 0, any = 0, out_soff = 0;
-    if (fin_prev) {
-      take = prv_t == -1 ? msk[0] : prv_t == 0 ? msk[1] : prv_t == 1 ? msk[2] : 0;
-      any = take;
-      if (prv_t == 2 || prv_t == first_t) {
-        const int dc = prv_t == 2 ? 7 : dead_cols;
-        any |= (dc & 1 ? msk[0] : 0) | (dc & 2 ? msk[1] : 0) | (dc & 4 ? msk[2] : 0);
-      }
-      out_soff = ((((n * p.oh + oy + rw * p.s2) * p.ow) * p.ld_out) + (prv_m - rw) * p.gw) * 4;
-    }
+    CT_STAMP(2);                                       // 2: barrier
     const int pi = cur_m - rw;
     const bool mine = cur_ok && pi >= 0 && pi < p.gw && rw < nv;     // (uniform in the pair)
     const bool mf = mine && cur_t != 2;
+    __builtin_amdgcn_sched_barrier(0);
+    CT_STAMP(3);                                       // 3: dispatch
+    if (mf) CT_COUNT(7);
     if (mf) {
-      if (fin_prev) block(T_{}, T_{}, cur_buf, take, any, out_soff);
-      else block(T_{}, F_{}, cur_buf, 0, 0, 0);
-    } else if (fin_prev) {
-      block(F_{}, T_{}, 0, take, any, out_soff);
+      if (fin_prev) block(T_{}, T_{});
+      else block(T_{}, F_{});
+    } else {
+      if (fin_prev) block(F_{}, T_{});
+      else block(F_{}, F_{});
     }
+    __builtin_amdgcn_sched_barrier(0);
+    CT_STAMP(mf ? (fin_prev ? 5 : 6) : 4);             // 5: products + finish, 6: products only
+    fin_blk = fin_prev;
     if (!cur_ok) break;
     if (mine && !mf) {
 #pragma unroll
@@ -756,10 +834,15 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile reads and slot stores done before the next barrier
     __builtin_amdgcn_sched_barrier(0);
-    prv_m = cur_m; prv_t = cur_t;
+    take = take2; any = any2; out_soff = out_soff2;
     cur_ok = nxt_ok; cur_m = nxt_m; cur_t = nxt_t; cur_buf = nxt_buf;
+    nxt_ok = nn_ok; nxt_m = nn_m; nxt_j = nn_j; nxt_t = nn_t; nxt_buf = nn_buf;
+#pragma unroll
+    for (int i = 0; i < NCH / 2; i++) dvoff[i] = dvoff2[i];
+    dbase = dbase2;
     step++;
   }
+  CT_FLUSH;
 }
 
 
@@ -1107,6 +1190,12 @@ static void corr_pl_tiles(int nq, int r, int* nA, int* T, int* vr, int* joff) {
     *nA = (nq + 31) / 32;
   }
 }
+
+#ifdef UNFLOW_CORR_TRACE
+extern "C" __attribute__((visibility("default"))) int unflow_debug_corr_trace(unsigned long long* host_out) {      // [8 waves][8]
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_corr_trace), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, float* out, int ld_out, int B, int C, int H,
                 int W, const CorrGeom& g, hipStream_t st) {
