@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
 timeout 600 python -m pytest tests/test_planes_gpu.py -q -m gpu -x -k "correlation" 2>&1 | tail -5
 timeout 120 python tools/tmp/corr_time.py 2>&1 | tail -8
-UNFLOW_LIB_PATH=$GRAFT_REPO_ROOT/tools/tmp/trace/libunflow_trace.so timeout 120 python tools/tmp/corr_trace.py 2>&1 | tail -12

@@ -574,7 +574,6 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
   constexpr int NCH = 2 * CH;                          // chunks of a tile
   constexpr int TILE = NCH * CHUNK;
   constexpr int NU = 4 * CH;                           // K16 steps of a wave
-  constexpr int FPU = CH == 1 ? 16 : 4;                // band accumulators finished per K16 step (from step 3 on)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int rw = wid >> 1, kh = wid & 1;               // output row of the group, K half
@@ -682,7 +681,9 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
   }
   const int msk_all = msk_lo | msk_mid | msk_hi;
   const int msk_dead = (dead_cols & 1 ? msk_lo : 0) | (dead_cols & 2 ? msk_mid : 0) | (dead_cols & 4 ? msk_hi : 0);
-  const int perm0 = 4 * (4 * h + l31 - p.r);            // ds_bpermute: 4 x the column of accumulator 0's entry (+ 4 lc(e); mod 32 = the lane of its half)
+  int perm[16];                                        // ds_bpermute byte address = 4 x the source lane: column li + l31 - r (mod 32) of the lane's own half
+#pragma unroll
+  for (int e = 0; e < 16; e++) perm[e] = ((4 * ((e & 3) + 8 * (e >> 2) + 4 * h + l31 - p.r)) & 124) | (h << 7);
   const int lane_out = ((q + p.s2 * (i0 + 4 * h)) * p.ld_out + l31) * 4;      // byte offset of (row 4 h, displacement l31) in a band
   const int lc_bytes = p.s2 * p.ld_out * 4;                                   // one Gram row further = one output pixel of the class
   const int row_out = (((n * p.oh + oy + rw * p.s2) * p.ow) * p.ld_out - rw * p.gw) * 4;   // + 4 gw m: band (row rw, displacement row m - rw)
@@ -765,9 +766,9 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
 #pragma unroll
     for (int u = 0; u < NU; u++) {
       if (MF && u + 1 < NU) rd(u + 1, bf[(u + 1) & 1]);
-      if (u < 3) {                                     // early: the rest of the block covers their round trip
-#pragma unroll
-        for (int i = 0; i < NCH / 2; i++) dma1(dvoff[i], f1_rs[u], dbase + unit_lds(i) + u * (32 * 64 * 2));
+      if (u >= 1 && u <= 3 * (NCH / 2)) {
+        const int i = (u - 1) / 3, pl = (u - 1) % 3;
+        dma1(dvoff[i], f1_rs[pl], dbase + unit_lds(i) + pl * (32 * 64 * 2));
       }
       if (MF) {
 #pragma unroll
@@ -775,14 +776,15 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
                                                         __builtin_bit_cast(bf16x8, bf[u & 1][tb[tt]]), acc, 0, 0, 0);
       }
-      if (FIN && u >= 3 && (u - 3) * FPU < 16) {       // after the DMAs: 16 stores younger than every tile load
+      if (FIN && u < 4) {
 #pragma unroll
-        for (int ee = 0; ee < FPU; ee++) {
-          const int e = (u - 3) * FPU + ee, lc = (e & 3) + 8 * (e >> 2);
-          const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(((perm0 + 4 * lc) & 124) | (h << 7), __float_as_int(prev[e])));
-          const float val = (take >> e) & 1 ? v * rcf : 0.f;
-          const int voff = (any >> e) & 1 ? lane_out : OOB_MARK;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_rs, voff, out_soff + lc * lc_bytes, 0);
+        for (int ee = 0; ee < 4; ee++) {
+          const int e = u * 4 + ee, lc = (e & 3) + 8 * (e >> 2);
+          const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(perm[e], __float_as_int(prev[e])));
+          const int tm = (take << (31 - e)) >> 31, am = (any << (31 - e)) >> 31;          // bit e as 0 / -1: bfe, and, bfe, bfi
+          const unsigned val = __float_as_uint(v * rcf) & (unsigned)tm;
+          const int voff = (lane_out & am) | (OOB_MARK & ~am);
+          __builtin_amdgcn_raw_buffer_store_b32(val, out_rs, voff, out_soff + lc * lc_bytes, 0);
         }
       }
     }
@@ -791,15 +793,11 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
   using F_ = std::false_type;
 
   bool fin_prev = false;                               // this wave holds the finishing half of the previous step's Gram
-  bool fin_blk = false;                                // ... and the last block finished one
   int step = 0;
 #pragma unroll 1
   for (;;) {
     CT_STAMP(step == 0 ? 0 : 4);                       // 0: prologue; 4: tail of the previous step
-    // this wave's share of the current tile has landed (vmcnt retires in order on gfx9; the 16 band stores of a finishing
-    // block are all younger than its tile loads and may stay in flight)
-    if (fin_blk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the current tile has landed
     __builtin_amdgcn_sched_barrier(0);
     CT_STAMP(1);                                       // 1: waiting for the tile
     __builtin_amdgcn_s_barrier();                      // ... everybody's; the other buffer and the slots written last step are free / ready
@@ -820,7 +818,6 @@ __global__ __launch_bounds__(512) void corr_fwd_rw_kernel(const CorrPlParams p) 
     }
     __builtin_amdgcn_sched_barrier(0);
     CT_STAMP(mf ? (fin_prev ? 5 : 6) : 4);             // 5: products + finish, 6: products only
-    fin_blk = fin_prev;
     if (!cur_ok) break;
     if (mine && !mf) {
 #pragma unroll
