@@ -949,37 +949,68 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   // row R has R / s2 = k (mod 2r+1), so the blocks of neighbouring rows y ask for a feature row in the same step.
   const int yq = (y - (p.s2 - 1) * (y < 0)) / p.s2;
   const int rot0 = p.rot ? ((p.r - yq) % p.gw + p.gw) % p.gw : 0, rot1 = p.rot ? (yq + p.r) % p.gw : 0;
-  int it_role = role_lo, it_k = -1, it_pi = 0, it_t = p.T;      // advanced before use
+  // Items: (role, displacement row, column tile).  Only live ones are visited: the column tiles with a site inside the image
+  // are a range [t_lo, t_hi], and so are the displacement rows of a role whose feature row and dout row exist — at the step's
+  // shape (T = 1, one tile wide) the old walk tried three tiles per item, two of them dead, in a 250-instruction scalar loop.
+  int t_lo = p.T + 1, t_hi = -p.T - 1;
+  for (int t = -p.T; t <= p.T; t++) {
+    const int kk = i0 + 32 * t + p.joff;
+    if (q + p.off + p.s2 * (kk + 31) >= 0 && q + p.off + p.s2 * kk < p.W) { t_lo = min(t_lo, t); t_hi = max(t_hi, t); }
+  }
+  const int nd_r1 = ((s - p.shift) % p.B + p.B) % p.B, ns_r0 = (s + p.shift) % p.B;
+  auto row_ok = [&](int role, int pi) -> bool {
+    const int dyp = p.s2 * (pi - p.r);
+    const int ys = role == 0 ? y + dyp : y - dyp;
+    const int o = (role == 0 ? y : ys) - p.off;
+    return (unsigned)ys < (unsigned)p.H && (unsigned)o < (unsigned)p.oh;
+  };
+  int it_role = role_lo, it_k = -1, it_pi = 0, it_t = t_hi;      // advanced before use
   int nd = 0, ns = 0, ysrc = 0, oy = 0, k0 = 0;
   auto next_item = [&]() -> bool {
-    for (;;) {
-      if (++it_t > p.T) { it_t = -p.T; if (++it_k >= p.gw) { it_k = 0; if (++it_role > role_hi) return false; } }
-      it_pi = !p.rot ? it_k : it_role == 0 ? (it_k + rot0) % p.gw : ((rot1 - it_k) % p.gw + p.gw) % p.gw;
-      const int role = it_role;
-      nd = role == 0 ? s : ((s - p.shift) % p.B + p.B) % p.B;
-      ns = role == 0 ? (s + p.shift) % p.B : nd;
+    if (t_lo > t_hi) return false;
+    if (++it_t > t_hi) {
+      it_t = t_lo;
+      for (;;) {                                                  // the next live displacement row
+        if (++it_k >= p.gw) { it_k = 0; if (++it_role > role_hi) return false; }
+        it_pi = !p.rot ? it_k : it_role == 0 ? (it_k + rot0) % p.gw : ((rot1 - it_k) % p.gw + p.gw) % p.gw;
+        if (row_ok(it_role, it_pi)) break;
+      }
       const int dyp = p.s2 * (it_pi - p.r);
-      ysrc = role == 0 ? y + dyp : y - dyp;
-      oy = (role == 0 ? y : y - dyp) - p.off;
-      if ((unsigned)ysrc >= (unsigned)p.H || (unsigned)oy >= (unsigned)p.oh) continue;
-      k0 = i0 + 32 * it_t + p.joff;
-      const int xk_lo = q + p.off + p.s2 * k0, xk_hi = q + p.off + p.s2 * (k0 + 31);
-      if (xk_hi < 0 || xk_lo >= p.W) continue;
-      return true;
+      nd = it_role == 0 ? s : nd_r1;
+      ns = it_role == 0 ? ns_r0 : nd_r1;
+      ysrc = it_role == 0 ? y + dyp : y - dyp;
+      oy = (it_role == 0 ? y : ysrc) - p.off;
     }
+    k0 = i0 + 32 * it_t + p.joff;
+    return true;
   };
-  // the feature tile of the current item -> LDS (role 0 multiplies in1, role 1 in0)
-  auto issue_tile = [&]() {
+  // the feature tile of the current item -> LDS (role 0 multiplies in1, role 1 in0); a lane's column and channel offsets once
+  int t_xs[4], t_off[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int site = 8 * j + d_site;
-      const int g = ((((d_slot >> 1) ^ (((site >> 1) & 1) << 1)) << 1) | (d_slot & 1));
-      const int xs = q + p.off + p.s2 * (k0 + site);
-      const bool ok = (unsigned)xs < (unsigned)p.W;
-      const int voff = ok ? ((ns * p.H + ysrc) * p.W + xs) * ld2 + (c0 + g * 8) * 2 : OOB_MARK;
-      const unsigned d = tile_addr + (unsigned)(j * 1024);
-      if (it_role == 0) dma3(voff, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
-      else dma3(voff, f0_rs[0], f0_rs[1], f0_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+  for (int j = 0; j < 4; j++) {
+    const int site = 8 * j + d_site;
+    const int g = ((((d_slot >> 1) ^ (((site >> 1) & 1) << 1)) << 1) | (d_slot & 1));
+    t_xs[j] = q + p.off + p.s2 * site;
+    t_off[j] = t_xs[j] * ld2 + (c0 + g * 8) * 2;
+  }
+  auto issue_tile = [&]() {
+    const int xk = p.s2 * k0;
+    const int rowb = ((ns * p.H + ysrc) * p.W + xk) * ld2;
+    int voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) voff[j] = (unsigned)(t_xs[j] + xk) < (unsigned)p.W ? rowb + t_off[j] : OOB_MARK;
+    if (it_role == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned d = tile_addr + (unsigned)(j * 1024);
+        dma3(voff[j], f1_rs[0], f1_rs[1], f1_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned d = tile_addr + (unsigned)(j * 1024);
+        dma3(voff[j], f0_rs[0], f0_rs[1], f0_rs[2], d, d + 32 * 64 * 2, d + 2 * 32 * 64 * 2);
+      }
     }
   };
   // the band operand of the current item: av[slab][e] for contracted site k0 + 16 slab + 8 h + e.
@@ -1043,30 +1074,33 @@ __global__ __launch_bounds__(256, 2) void corr_bwd_pl_kernel(const CorrBwdPlPara
   const int sh_a = (int)(threadIdx.x >> 3), sh_b = (int)(threadIdx.x & 7) << 2;
   float breg[4];
   int bmask = 0;
+  // (32-bit arithmetic: SHARE requires dout_total < 2^30)
+  const int sh_c = sh_b - sh_a;
   auto load_band_shared = [&]() {
     const int role = it_role;
-    const size_t srow = ((size_t)nd * p.oh + oy) * p.ow;
+    const int srow = (nd * p.oh + oy) * p.ow;
     const int site = (role == 0 ? i0 : k0) + sh_a;            // the site whose dout row is read
     const int ox = q + p.s2 * site;
     const bool site_ok = (unsigned)ox < (unsigned)p.ow;
     // offsets of the four values: role 0: o = (k0 + b + e) - (i0 + a); role 1: o = (i0 + b + e) - (k0 + a)
-    const int o0 = role == 0 ? (k0 + sh_b) - (i0 + sh_a) : (i0 + sh_b) - (k0 + sh_a);
-    const long base = (long)(srow + (site_ok ? ox : 0)) * p.ld_dout + it_pi * p.gw + p.r + o0;   // float index of value 0
-    bmask = 0;
-#pragma unroll
-    for (int e = 0; e < 4; e++) bmask |= (site_ok && o0 + e >= -p.r && o0 + e <= p.r) ? (1 << e) : 0;
+    const int dk = k0 - i0;
+    const int o0 = (role == 0 ? dk : -dk) + sh_c;
+    const int base = (srow + (site_ok ? ox : 0)) * p.ld_dout + it_pi * p.gw + p.r + o0;   // float index of value 0
+    // the band entries among the four: -r <= o0 + e <= r
+    const int e_lo = max(0, -p.r - o0), e_hi = min(3, p.r - o0);
+    bmask = site_ok && e_hi >= e_lo ? ((2 << e_hi) - 1) & ~((1 << e_lo) - 1) : 0;
     // the four values are consecutive floats: one dword-aligned 16-byte load unless the run would start before / end after
     // the tensor (first / last site only), masked afterwards
-    const bool inb = base >= 0 && (base + 4) * 4 <= (long)p.dout_total;
+    const bool inb = base >= 0 && (size_t)(base + 4) * 4 <= p.dout_total;
     if (__all(bmask == 0 || inb)) {
-      const u32x4 v = buf_ld16(dout_rs_all, bmask ? (int)(base * 4) : OOB_MARK);
+      const u32x4 v = buf_ld16(dout_rs_all, bmask ? base * 4 : OOB_MARK);
 #pragma unroll
       for (int e = 0; e < 4; e++) breg[e] = __uint_as_float(v[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const bool ok = (bmask >> e) & 1;
-        breg[e] = buf_ld1(dout_rs_all, ok ? (int)((base + e) * 4) : OOB_MARK, 0);
+        breg[e] = buf_ld1(dout_rs_all, ok ? (base + e) * 4 : OOB_MARK, 0);
       }
     }
   };
