@@ -87,28 +87,39 @@ steps = [((torch.rand(2, H, W, 3, generator=g) * 255), (torch.rand(2, H, W, 3, g
 eng = FlowNetEngine(1, H, W, params=dict(DEFAULT_PARAMS, flownet='C'), device=dev, seed=7)
 run = StepRunner(eng, world, use_graph=True)
 assert run.nparts == 3 and run.reducer.world == 2
-losses = []
-for a, b in steps:
-    losses.append(run.step(a[rank:rank + 1].to(dev), b[rank:rank + 1].to(dev), 1e-4).item())
-torch.cuda.synchronize()
-# (1) every rank holds the same parameters and moments, bit for bit
-for t in (eng.P, eng.M, eng.V):
-    ref = t.clone()
-    dist.broadcast(ref, 0)
-    assert torch.equal(ref, t), "rank %%d diverged" %% rank
-# (2) they are what ONE process computes on the concatenated minibatch (mean over replicas of the per-replica gradient =
-#     gradient of the mean loss: average_gradients, train.py:388-422), up to fp32 summation order
+# rank 0 also holds the reference: ONE process on the concatenated minibatch (mean over replicas of the per-replica gradient
+# = gradient of the mean loss: average_gradients, train.py:388-422)
 if rank == 0:
     one = FlowNetEngine(2, H, W, params=dict(DEFAULT_PARAMS, flownet='C'), device=dev, seed=7)
+    start = one.P.clone()
     r1 = StepRunner(one, 1, use_graph=True)
-    l1 = [r1.step(a.to(dev), b.to(dev), 1e-4).item() for a, b in steps]
+losses, l1, closeness = [], [], []
+for a, b in steps:
+    losses.append(run.step(a[rank:rank + 1].to(dev), b[rank:rank + 1].to(dev), 1e-4).item())
     torch.cuda.synchronize()
-    d = (one.P - eng.P).abs()
-    moved = (one.P - FlowNetEngine(2, H, W, params=dict(DEFAULT_PARAMS, flownet='C'), device=dev, seed=7).P).abs().max().item()
+    # (1) every rank holds the same parameters and moments, bit for bit — after every step
+    for t in (eng.P, eng.M, eng.V):
+        ref = t.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, t), "rank %%d diverged" %% rank
+    # (2) the step equals the single-process step FROM THE SAME STATE up to fp32 summation order.  Per step, not per
+    #     trajectory: the loss has hard occlusion / border masks (losses.py:19-45), so two runs that differ in the last bit part
+    #     ways at the first mask pixel that flips (measured: one conv3 weight moved by 3.6e-6 changes 2 M gradient entries by
+    #     > 1e-6 of the largest), and Adam turns every sign change of a near-zero gradient into 2 lr.  After the comparison the
+    #     reference takes over the ranks' state, so every step is compared from identical parameters and moments.
+    if rank == 0:
+        l1.append(r1.step(a.to(dev), b.to(dev), 1e-4).item())
+        torch.cuda.synchronize()
+        d = (one.P - eng.P).abs()
+        frac_close = (d <= 2e-6).float().mean().item()
+        assert frac_close > 0.999 and d.max().item() <= 3.1e-4, (len(l1), frac_close, d.max().item())
+        closeness.append((frac_close, d.max().item()))
+        for dst, src in ((one.P, eng.P), (one.M, eng.M), (one.V, eng.V)):
+            dst.copy_(src)
+if rank == 0:
+    moved = (start - eng.P).abs().max().item()
     assert moved > 1e-4                                            # three Adam steps of 1e-4 did move the weights
-    frac_close = (d <= 2e-6).float().mean().item()
-    assert frac_close > 0.999 and d.max().item() <= 3.1e-4, (frac_close, d.max().item())
-    print("GLOO2_OK", frac_close, d.max().item(), losses, l1)
+    print("GLOO2_OK", closeness, losses, l1)
 dist.barrier(); dist.destroy_process_group()
 '''
 
