@@ -1,3 +1,5 @@
+"""Same-box A/B of the step's forward correlation (8 x 48 x 64 x 256 -> 441 channels, NaN-prefilled output): option corr_rw 0 (corr_fwd_wb_kernel)
+against 1 (corr_fwd_rw_kernel), three interleaved rounds, median of 40 launches each; prints the largest difference of the two results."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,3 +1,5 @@
+"""The forward correlation kernels run to run and across batch compositions: a sample's output must not depend on the batch it sits in
+(bit-identical), with either kernel (option corr_rw)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

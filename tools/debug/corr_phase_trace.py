@@ -1,3 +1,13 @@
+"""Where the waves of one workgroup of corr_fwd_rw_kernel spend a step (diagnostic build).  Build a traced copy of the library and run:
+
+    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-vectorize -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden \\
+          -DUNFLOW_CORR_TRACE=16 -c unflow_amd/csrc/correlation_planes.hip -o scratch/corr_trace.o        # 16: an interior row group
+    hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libunflow_trace.so scratch/corr_trace.o <the other .o files> -ldl
+    UNFLOW_LIB_PATH=scratch/libunflow_trace.so python tools/debug/corr_phase_trace.py
+
+Every wave of that workgroup sums shader cycles (s_memtime) per phase in registers: prologue, waiting for the tile, barrier, dispatch,
+tail + blocks without products, blocks with products (+ finish), and counts its product steps.  The stamps are scheduling barriers, so
+the traced build interleaves a little less than the shipped one; small phases are only indicative (profiles/r04_corr_fwd_rw.txt)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

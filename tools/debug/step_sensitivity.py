@@ -1,3 +1,5 @@
+"""How much of the gradient moves when ONE conv3 weight moves by 3.6e-6 (FlowNetC, 128 x 192, eager, both forward correlation kernels):
+the evidence that the loss is discontinuous (hard masks) behind profiles/r04_two_rank_test_sensitivity.txt."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
