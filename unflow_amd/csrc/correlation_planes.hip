@@ -5,7 +5,7 @@
 // 32x32 Gram matrix G[i][j] = sum_c f0[y, x_i, c] * f1[y + s2 p, x_j, c] (correlation_mfma.hip).
 //
 // Forward kernels (corr_pl_fwd picks one):
-//   corr_fwd_wb_kernel  wide band (r > 6, or one site tile per row), C % 64 == 0, C <= 256 — the training step's shape:
+//   corr_fwd_wb_kernel  wide band (r > 6, or one site tile per row), C % 64 == 0, C <= 256 (the step's kernel of rounds 2-3):
 //                       K split over the waves, f1 tiles by LDS-DMA in whole cache lines, two output rows per block.
 //   corr_fwd_rw_kernel  wide band, C = 128 or 256: a wave pair per output row, four rows per workgroup sharing whole f1 tiles
 //                       (the step's kernel since round 4; corr_fwd_wb_kernel stays for C = 64 / 192 and as its A/B).
