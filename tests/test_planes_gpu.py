@@ -282,6 +282,55 @@ def test_conv1_two_pixel_granules(case, P, dev):
     assert rel_err(Y.t, Y8.t) < 1e-5
 
 
+def _planes_value(pl):
+    """fp32 value of bf16 x 3 operand planes [3, ...]: hi + mid + lo (exact in fp64)."""
+    v = (pl.to(torch.int32) & 0xffff) << 16
+    return v.view(torch.float32).double().sum(0)
+
+
+@pytest.mark.parametrize("leaky", [True, False])
+@pytest.mark.parametrize("case", [(2, 64, 128), (1, 50, 76), (3, 16, 64), (8, 384, 512)])
+def test_conv_first_layer_kernel_planes_only_vs_fp64(case, leaky, dev, lib_option):
+    """FlowNetC's first layer as the step runs it — planes-only output, rgb4 input — on its own kernel (csrc/conv_first.hip):
+    against fp64 and against the gather kernel (option conv1_direct = 0), full and ragged tiles, with and without leaky ReLU; the
+    planes must be the exact 3-way split of an fp32 value (hi + mid + lo representable)."""
+    import ctypes
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, stream
+    from unflow_amd.core import layers as L
+    from oracle import model_ref as M
+    B, H, W = case
+    Cout = 64
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = torch.randn(B, H, W, 4, generator=g)
+    x[..., 3] = 0
+    w = torch.randn(7, 7, 4, Cout, generator=g) * (1.0 / np.sqrt(147))
+    b = torch.randn(Cout, generator=g) * 0.1
+    y_ref = M.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), 2, act=leaky).permute(0, 2, 3, 1)
+    X = L.PT(x.to(dev), torch.zeros(3, B, H, W, 4, dtype=torch.int16, device=dev))
+    L.planes_from_f32(X.t, X.pl, C=4)
+    wd = w.to(dev).contiguous()
+    w_dir = torch.zeros(3, 7, 28, Cout, dtype=torch.int16, device=dev)
+    w_tr = torch.zeros(3, 7, Cout, 32, dtype=torch.int16, device=dev)
+    check(_lib.lib().unflow_weight_planes_batched(1, (ctypes.c_void_p * 1)(wd.data_ptr()), (ctypes.c_int * 1)(7),
+                                                  (ctypes.c_int * 1)(28), (ctypes.c_int * 1)(Cout),
+                                                  (ctypes.c_void_p * 1)(w_dir.data_ptr()),
+                                                  (ctypes.c_void_p * 1)(w_tr.data_ptr()), 3, stream()), "weight_planes")
+    Ho, Wo = L.out_hw(H, W, 2)
+    outs = []
+    for direct in (1, 0):
+        lib_option("conv1_direct", direct)
+        Y = L.PT.alloc((B, Ho, Wo, Cout), dev, 3)
+        Y.pl.fill_(0x7fc0)                      # bf16 NaN pattern: every plane element must be written
+        L.conv_fwd(X, wd, w_tr, b.to(dev), Y, 2, leaky, planes_only=True)
+        outs.append(_planes_value(Y.pl).cpu())
+    scale = y_ref.abs().max().item()
+    for o in outs:
+        assert not torch.isnan(o).any()
+        assert (o - y_ref).abs().max().item() <= 5e-6 * scale
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-6 * scale
+
+
 # (B, H, W, Cin, Cout)   H,W = INPUT size; output is 2H x 2W
 DECONV_CASES = [
     (8, 6, 8, 1024, 512),     # deconv5

@@ -1,0 +1,249 @@
+// FlowNetC's first layer (7 x 7 stride 2 over RGB0 -> 64 channels, flownet.py:204) as its own kernel.
+//
+// Through the gather kernel (conv_planes.hip, rgb4_form: two-pixel K granules, a tap row = 8 pixels x 4 channels = one K32 tile)
+// a 128 x 64 output tile moves 7 tap rows x 128 sites x 64 B x 3 planes = 172 KB of gathered rows plus the 86 KB filter through
+// L2 -> LDS: 3072 tiles x 258 KB = 0.79 GB in 93 us = 8.5 TB/s — the operand-stream bound of the deep layers, with
+// the matrix cores at 29 %.  But the seven tap rows of an output row read overlapping input rows, and the filter is the same for
+// every tile.  Here a workgroup (8 waves) owns an 8-row x 32-column output tile:
+//   * its 21 input rows x 70 pixels x 4 channels x 3 planes (36 KB) are staged ONCE per tile — registers -> LDS, the next tile's
+//     loads in flight under this tile's products — and serve all seven tap rows: a K16 step of a tap row is four pixels, a lane's
+//     half two pixels = one 16-byte granule, and the 32 sites of an output row read 32 CONSECUTIVE granules (conflict-free);
+//   * the whole filter (7 tap rows x 64 channels x 32 K x 3 planes = 86 KB, XOR-swizzled 64-byte rows) is loaded once per
+//     workgroup, and workgroups are persistent (one per CU, tiles strided by the grid): 0.08 GB of operands instead of 0.79;
+//   * no barrier inside a tile's 14 K16 steps (168 MFMAs per wave); the MFMA takes the FILTER as its row operand, so a lane ends
+//     up with four consecutive output channels of ONE site per accumulator group: bias, leaky ReLU and the 3-way bf16 split
+//     happen in registers, the planes pass through a wave-private staging slab (8-byte stores, 16-byte reads) and leave as
+//     whole 128-byte lines (one pixel's 64 channels of one plane).
+// Output: the bf16 x 3 operand planes only (conv1's activation has no fp32 copy in the step: engine.py planes_only); any other
+// request takes the gather kernel.
+#include "igemm_shared.h"
+#include "options.h"
+
+namespace {
+using namespace igemm;
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct First7Params {
+  const unsigned short* x;     // input planes [B,H,W,4]
+  long x_ps;
+  const unsigned short* w;     // filter planes [7 tap rows][64][32 K] (K = 4 kx + channel; kx = 7 and rows 28..31 zero)
+  long w_ps;
+  const float* bias;           // [64] or NULL
+  unsigned short* y;           // output planes [B,Ho,Wo,ldy], channels 0..63
+  long y_ps;
+  int ldy;
+  int B, H, W, Ho, Wo, pad;    // pad: rows / pixels of zero padding above / left (2 for even sizes)
+  int tiles_y, tiles_x, ntiles;
+  int leaky;
+};
+
+constexpr int F_TH = 8, F_TW = 32;               // output tile: one row per wave
+constexpr int F_ROWS = 2 * F_TH + 5;             // input rows of a tile
+constexpr int F_GR = F_TW + 3;                   // 16-byte granules (two pixels) per input row: 70 pixels
+constexpr int F_PITCH = 576;                     // bytes per staged input row (36 granules)
+constexpr int F_HPLANE = F_ROWS * F_PITCH;       // 12096
+constexpr int F_WPLANE = 7 * 64 * 64;            // 28672 bytes: [tap row][channel][32 K]
+constexpr int F_SPITCH = 144;                    // staging: bytes per site (64 channels + 16 pad)
+constexpr int F_STAGE = F_TW * F_SPITCH;         // per wave
+constexpr int F_SMEM = 3 * F_WPLANE + 3 * F_HPLANE + 8 * F_STAGE;      // 86016 + 36288 + 36864 = 159168
+constexpr int F_NLOAD = (3 * F_ROWS * F_GR + 511) / 512;               // halo granules per thread
+
+__global__ __launch_bounds__(512) void conv_first7_kernel(const First7Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  unsigned char* Wl = fsm;
+  unsigned char* Hl = fsm + 3 * F_WPLANE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  unsigned char* Sl = fsm + 3 * F_WPLANE + 3 * F_HPLANE + wid * F_STAGE;
+
+  // one descriptor per tensor: the three planes lie plane_stride apart (the host checks that everything stays below 1 GB, the
+  // out-of-range mark)
+  const int x_pb = (int)(p.x_ps * 2), w_pb = (int)(p.w_ps * 2), y_pb = (int)(p.y_ps * 2);      // plane pitch in bytes
+  const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(p.x, (size_t)2 * x_pb + (size_t)p.B * p.H * p.W * 8);
+  const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(p.w, (size_t)2 * w_pb + (size_t)7 * 64 * 64);
+  const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(p.y, (size_t)2 * y_pb + (((size_t)p.B * p.Ho * p.Wo - 1) * (size_t)p.ldy + 64) * 2);
+  // ---- the filter, once: granule g of row (tap row, channel n) sits at slot g ^ ((n >> 2) & 3) of its 64-byte row
+  for (int idx = tid; idx < 3 * 7 * 64 * 4; idx += 512) {
+    const int pl = idx / (7 * 64 * 4), rem = idx - pl * (7 * 64 * 4);
+    const int row = rem >> 2, g = rem & 3, n = row & 63;
+    const u32x4 v = buf_ld16(w_rs, pl * w_pb + rem * 16);
+    *reinterpret_cast<u32x4*>(Wl + pl * F_WPLANE + row * 64 + ((g ^ ((n >> 2) & 3)) << 4)) = v;
+  }
+
+  // ---- a thread's share of a tile's input rows: granule idx = (plane, row, granule)
+  int h_lds[F_NLOAD], h_row[F_NLOAD], h_px[F_NLOAD], h_src[F_NLOAD];      // h_src: plane offset in the source, or the mark (no granule)
+#pragma unroll
+  for (int i = 0; i < F_NLOAD; i++) {
+    const int idx = tid + i * 512;
+    const bool any = idx < 3 * F_ROWS * F_GR;
+    const int pl = idx / (F_ROWS * F_GR), rem = idx - pl * (F_ROWS * F_GR);
+    const int r = rem / F_GR, g = rem - r * F_GR;
+    h_src[i] = any ? pl * x_pb : OOB_MARK;
+    h_row[i] = r;
+    h_px[i] = 2 * g;
+    h_lds[i] = any ? pl * F_HPLANE + r * F_PITCH + g * 16 : -1;
+  }
+  u32x4 hl[F_NLOAD];
+  auto tile_of = [&](int t, int& b, int& oy0, int& ox0) {
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    b = t / p.tiles_y;
+    oy0 = ty * F_TH;
+    ox0 = tx * F_TW;
+  };
+  auto load_rows = [&](int t) {                 // -> registers (zeros outside the image and past the last tile)
+    int b, oy0, ox0;
+    tile_of(t, b, oy0, ox0);
+    const bool live = t < p.ntiles;
+#pragma unroll
+    for (int i = 0; i < F_NLOAD; i++) {
+      const int yi = 2 * oy0 - p.pad + h_row[i], px = 2 * ox0 - p.pad + h_px[i];
+      const bool ok = live && (unsigned)yi < (unsigned)p.H && (unsigned)px < (unsigned)p.W;
+      hl[i] = buf_ld16(x_rs, ok ? h_src[i] + ((b * p.H + yi) * p.W + px) * 8 : OOB_MARK);
+    }
+  };
+
+  float bias4[2][4][4];                         // bias of the lane's channels: [subtile][group][4]
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) bias4[c][g4][e] = p.bias ? p.bias[32 * c + 8 * g4 + 4 * h + e] : 0.f;
+
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  int t = blockIdx.x;
+  load_rows(t);
+#pragma unroll 1
+  for (; t < p.ntiles; t += gridDim.x) {
+    __syncthreads();                             // every wave is done with the previous tile's rows (first pass: the filter stores)
+    // (the compiler's own wait for this tile's rows counts the 12 younger plane stores of the previous tile and lets them fly)
+#pragma unroll
+    for (int i = 0; i < F_NLOAD; i++)
+      if (h_lds[i] >= 0) *reinterpret_cast<u32x4*>(Hl + h_lds[i]) = hl[i];
+    __syncthreads();
+    load_rows(t + gridDim.x);                    // the next tile's rows land under this tile's products
+
+    // ---- products: wave = output row wid; operand A = filter (32 channels per subtile), operand B = the row's 32 sites
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
+    const unsigned char* xrow = Hl + (2 * wid) * F_PITCH + (l31 + h) * 16;
+    const unsigned char* wrow = Wl + l31 * 64;
+    const int sw = (l31 >> 2) & 3;               // (channel 32 c + l31: the same swizzle for both subtiles)
+#pragma unroll
+    for (int ky = 0; ky < 7; ky++)
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        s16x8 xf[3], wf[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+          xf[pl] = *reinterpret_cast<const s16x8*>(xrow + pl * F_HPLANE + ky * F_PITCH + s * 32);
+#pragma unroll
+          for (int c = 0; c < 2; c++)
+            wf[c][pl] = *reinterpret_cast<const s16x8*>(wrow + pl * F_WPLANE + (ky * 64 + 32 * c) * 64 + (((2 * s + h) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+          for (int c = 0; c < 2; c++)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[c][ta[tt]]),
+                                                             __builtin_bit_cast(bf16x8_t, xf[tb[tt]]), acc[c], 0, 0, 0);
+      }
+
+    // ---- epilogue: acc[c][e] = channel 32 c + (e & 3) + 8 (e >> 2) + 4 h of site l31 in output row oy0 + wid
+    int b, oy0, ox0;
+    tile_of(t, b, oy0, ox0);
+    const int oy = oy0 + wid;
+    unsigned pk[3][2][4][2];                     // [plane][subtile][group][pair]: two packed bf16 each
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+          float a = acc[c][4 * g4 + 2 * pr] + bias4[c][g4][2 * pr], bb = acc[c][4 * g4 + 2 * pr + 1] + bias4[c][g4][2 * pr + 1];
+          if (p.leaky) { a = leaky_relu(a); bb = leaky_relu(bb); }
+          const unsigned hh = cvt_pk_bf16(a, bb);
+          const float ra = a - __uint_as_float(hh << 16), rb = bb - __uint_as_float(hh & 0xffff0000u);
+          const unsigned mm = cvt_pk_bf16(ra, rb);
+          const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
+          pk[0][c][g4][pr] = hh; pk[1][c][g4][pr] = mm; pk[2][c][g4][pr] = cvt_pk_bf16(sa, sb);
+        }
+    const int st_site = lane >> 3, st_gr = lane & 7;       // read-back: lane -> (site 8 j + lane / 8, granule lane % 8)
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++)
+          *reinterpret_cast<uint2*>(Sl + l31 * F_SPITCH + (32 * c + 8 * g4 + 4 * h) * 2) = make_uint2(pk[pl][c][g4][0], pk[pl][c][g4][1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int site = 8 * j + st_site, ox = ox0 + site;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Sl + site * F_SPITCH + st_gr * 16);
+        const bool ok = oy < p.Ho && ox < p.Wo;
+        const int voff = ok ? (((b * p.Ho + oy) * p.Wo + ox) * p.ldy) * 2 + st_gr * 16 : OOB_MARK;
+        __builtin_amdgcn_raw_buffer_store_b128(v, y_rs, voff, pl * y_pb, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is read before the next plane overwrites it
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+int first7_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+}  // namespace
+
+// conv_planes.hip (unflow_conv2d_fwd_pl) asks here first for the rgb4 form.  Returns UNFLOW_ERR_UNSUPPORTED when the request is
+// not this kernel's (then the gather kernel takes it).
+int conv_first7_fwd(const unflow_planes* x_pl, const unflow_planes* w_pl, const float* bias, const unflow_planes* y_pl, int B, int H,
+                    int W, int Cout, int leaky, hipStream_t st) {
+  if (!unflow::options().conv1_direct) return UNFLOW_ERR_UNSUPPORTED;
+  if (Cout != 64 || !x_pl || !w_pl || !y_pl || !y_pl->base || x_pl->n_planes != 3 || w_pl->n_planes != 3 || y_pl->n_planes != 3)
+    return UNFLOW_ERR_UNSUPPORTED;
+  if (x_pl->ld != 4 || w_pl->ld != 32 || y_pl->ld < 64 || y_pl->ld % 8 != 0 || H % 2 != 0 || W % 2 != 0) return UNFLOW_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(y_pl->base) & 15) || (y_pl->plane_stride & 7) || (reinterpret_cast<uintptr_t>(x_pl->base) & 15) ||
+      (x_pl->plane_stride & 7) || (reinterpret_cast<uintptr_t>(w_pl->base) & 15) || (w_pl->plane_stride & 7))
+    return UNFLOW_ERR_UNSUPPORTED;
+  const float sx = x_pl->scale, sw = w_pl->scale, sy = y_pl->scale;
+  if ((sx != 0.f && sx != 1.f) || (sw != 0.f && sw != 1.f) || (sy != 0.f && sy != 1.f)) return UNFLOW_ERR_UNSUPPORTED;
+  const int Ho = H / 2, Wo = W / 2;
+  if (x_pl->plane_stride < 0 || y_pl->plane_stride < 0 || w_pl->plane_stride < 0 ||
+      (size_t)4 * x_pl->plane_stride + (size_t)B * H * W * 8 > 0x3fffffffu ||
+      (size_t)4 * y_pl->plane_stride + ((size_t)B * Ho * Wo * y_pl->ld) * 2 > 0x3fffffffu || (size_t)4 * w_pl->plane_stride > 0x3ffffffu)
+    return UNFLOW_ERR_UNSUPPORTED;
+  First7Params p{};
+  p.x = reinterpret_cast<const unsigned short*>(x_pl->base); p.x_ps = x_pl->plane_stride;
+  p.w = reinterpret_cast<const unsigned short*>(w_pl->base); p.w_ps = w_pl->plane_stride;
+  p.bias = bias;
+  p.y = reinterpret_cast<unsigned short*>(y_pl->base); p.y_ps = y_pl->plane_stride; p.ldy = y_pl->ld;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.pad = 2;      // SAME, k 7, stride 2, even sizes: 2 above / left, 3 below / right
+  p.tiles_y = (Ho + F_TH - 1) / F_TH; p.tiles_x = (Wo + F_TW - 1) / F_TW;
+  p.ntiles = B * p.tiles_y * p.tiles_x;
+  p.leaky = leaky;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first7_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
+  (void)attr;
+  const int grid = p.ntiles < first7_cus() ? p.ntiles : first7_cus();
+  conv_first7_kernel<<<grid, 512, F_SMEM, st>>>(p);
+  return launch_status();
+}

@@ -2436,6 +2436,9 @@ UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, i
   return need + 1024;
 }
 
+int conv_first7_fwd(const unflow_planes* x_pl, const unflow_planes* w_pl, const float* bias, const unflow_planes* y_pl, int B, int H,
+                    int W, int Cout, int leaky, hipStream_t st);      // conv_first.hip
+
 // The first layer of a FlowNetC (7x7 stride 2 over RGB0, flownet.py:204): with 8-channel K granules half of every granule
 // is padding (49 taps x 8 = 392 K slots for 147 weights).  Stored with row length 4, a 16-byte granule of the input planes is
 // TWO neighbouring pixels, and because the SAME padding on the left is even (2) and W is even, the pairs a tap row needs —
@@ -2464,6 +2467,10 @@ UNFLOW_API int unflow_conv2d_fwd_pl(const float* x, int ldx, const unflow_planes
     return !y ? UNFLOW_ERR_UNSUPPORTED : unflow_conv2d_fwd_po(x, ldx, w, bias, y, ldy, B, H, W, Cin, Cout, k, stride, leaky, plane_out(y_pl, 0, Cout), workspace,
                                 workspace_bytes, stream);
   if (y && ldy < Cout) return UNFLOW_ERR_UNSUPPORTED;
+  if (rgb4 && !y) {                 // planes-only first layer: its own kernel where it applies (conv_first.hip)
+    const int code = conv_first7_fwd(x_pl, w_pl, bias, y_pl, B, H, W, Cout, leaky, as_stream(stream));
+    if (code != UNFLOW_ERR_UNSUPPORTED) return code;
+  }
   PlGatherParams p{};
   build_conv_fwd(p, B, H, W, Ci8, Cout, k, stride);
   if (stride == 2 && !rgb4) {       // source stride 2: the halo kernel over four accumulating parity classes, where it applies
