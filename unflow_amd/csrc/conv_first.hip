@@ -16,6 +16,7 @@
 //     whole 128-byte lines (one pixel's 64 channels of one plane).
 // Output: the bf16 x 3 operand planes only (conv1's activation has no fp32 copy in the step: engine.py planes_only); any other
 // request takes the gather kernel.
+#include <type_traits>
 #include "igemm_shared.h"
 #include "options.h"
 
@@ -24,6 +25,10 @@ using namespace igemm;
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+// the staging slab is written as 8-byte and read as 16-byte vectors: both through may_alias types — type-based alias analysis
+// (also the machine scheduler's) would otherwise be free to move the read-back above the stores it reads
+typedef unsigned u32x2_ma __attribute__((ext_vector_type(2), may_alias));
+typedef unsigned u32x4_ma __attribute__((ext_vector_type(4), may_alias));
 
 struct First7Params {
   const unsigned short* x;     // input planes [B,H,W,4]
@@ -116,88 +121,127 @@ __global__ __launch_bounds__(512) void conv_first7_kernel(const First7Params p) 
       for (int e = 0; e < 4; e++) bias4[c][g4][e] = p.bias ? p.bias[32 * c + 8 * g4 + 4 * h + e] : 0.f;
 
   constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  const int st_site = lane >> 3, st_gr = lane & 7;         // read-back of the staging slab: lane -> (site 8 j + lane / 8, granule lane % 8)
+  const int sw = (l31 >> 2) & 3;                 // (channel 32 c + l31: the same swizzle for both subtiles)
+  f32x16 acc[2], accp[2];
+  int pb = 0, poy = 0, pox0 = 0;                 // the tile whose accumulators wait in accp
+  // One tile's straight-line block.  MF: its 14 K16 steps (wave = output row wid; operand A = filter, 32 channels per subtile,
+  // operand B = the row's 32 sites).  EPI: the PREVIOUS tile's epilogue from accp — bias, leaky ReLU, 3-way split, staging slab,
+  // line stores — in the same block, so that its ~300 vector instructions and its LDS / store traffic issue between this tile's
+  // MFMAs instead of after them with the matrix pipes idle (all eight waves run their phases in step: there is nobody else to
+  // fill the pipe).  accp[c][e] = channel 32 c + (e & 3) + 8 (e >> 2) + 4 h of site l31 in output row poy.
+  auto block = [&](auto mf_tag, auto epi_tag) __attribute__((always_inline)) {
+    constexpr bool MF = decltype(mf_tag)::value, EPI = decltype(epi_tag)::value;
+    unsigned pk[3][2][4][2];                     // [plane][subtile][group][pair]: two packed bf16 each
+    if (EPI) {
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++)
+#pragma unroll
+          for (int pr = 0; pr < 2; pr++) {
+            float a = accp[c][4 * g4 + 2 * pr] + bias4[c][g4][2 * pr], bb = accp[c][4 * g4 + 2 * pr + 1] + bias4[c][g4][2 * pr + 1];
+            if (p.leaky) { a = leaky_relu(a); bb = leaky_relu(bb); }
+            const unsigned hh = cvt_pk_bf16(a, bb);
+            const float ra = a - __uint_as_float(hh << 16), rb = bb - __uint_as_float(hh & 0xffff0000u);
+            const unsigned mm = cvt_pk_bf16(ra, rb);
+            const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
+            pk[0][c][g4][pr] = hh; pk[1][c][g4][pr] = mm; pk[2][c][g4][pr] = cvt_pk_bf16(sa, sb);
+          }
+    }
+    if (MF) {
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
+    }
+    const unsigned char* xrow = Hl + (2 * wid) * F_PITCH + (l31 + h) * 16;
+    const unsigned char* wrow = Wl + l31 * 64;
+    // fragments one K16 step ahead of the MFMAs (two register sets): the LDS reads of step k + 1 run under the products of step k
+    s16x8 xf[2][3], wf[2][2][3];
+    auto rd = [&](int k, s16x8 (&x)[3], s16x8 (&w)[2][3]) __attribute__((always_inline)) {
+      const int ky = k >> 1, sk = k & 1;
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+        x[pl] = *reinterpret_cast<const s16x8*>(xrow + pl * F_HPLANE + ky * F_PITCH + sk * 32);
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+          w[c][pl] = *reinterpret_cast<const s16x8*>(wrow + pl * F_WPLANE + (ky * 64 + 32 * c) * 64 + (((2 * sk + h) ^ sw) << 4));
+      }
+    };
+    if (MF) rd(0, xf[0], wf[0]);
+#pragma unroll
+    for (int ky = 0; ky < 7; ky++) {
+      if (MF) {
+#pragma unroll
+        for (int sk = 0; sk < 2; sk++) {
+          const int k = 2 * ky + sk;
+          if (k + 1 < 14) rd(k + 1, xf[(k + 1) & 1], wf[(k + 1) & 1]);
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+              acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[k & 1][c][ta[tt]]),
+                                                               __builtin_bit_cast(bf16x8_t, xf[k & 1][tb[tt]]), acc[c], 0, 0, 0);
+        }
+      }
+      if (EPI && ky >= 1 && ky <= 6) {           // plane (ky - 1) / 2: its slab stores with the odd tap row, read-back + line stores with the even one
+        const int pl = (ky - 1) >> 1;
+        if ((ky & 1) == 1) {
+#pragma unroll
+          for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++)
+              *reinterpret_cast<u32x2_ma*>(Sl + l31 * F_SPITCH + (32 * c + 8 * g4 + 4 * h) * 2) = u32x2_ma{pk[pl][c][g4][0], pk[pl][c][g4][1]};
+          asm volatile("" ::: "memory");           // (the read-back below uses another access type: no reordering across this line)
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int site = 8 * j + st_site, ox = pox0 + site;
+            const u32x4 v = *reinterpret_cast<const u32x4_ma*>(Sl + site * F_SPITCH + st_gr * 16);
+            const bool ok = poy < p.Ho && ox < p.Wo;
+            const int voff = ok ? (((pb * p.Ho + poy) * p.Wo + ox) * p.ldy) * 2 + st_gr * 16 : OOB_MARK;
+            __builtin_amdgcn_raw_buffer_store_b128(v, y_rs, voff, pl * y_pb, 0);
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+      // One scheduling region per tap row.  With the whole block as one region a few hundred to a few thousand elements per launch
+      // come out WRONG, different ones every run but always the same kind — the first channel pair of every group of the second
+      // subtile, odd sites 9-15 of the lower half-wave, the four younger waves (profiles/r04_conv_first.txt) — i.e. single
+      // registers of single lanes of the packed planes on their way through the staging slab.  Not the compiler's waits (an
+      // explicit vmcnt(0) changes nothing), not type-based aliasing of the slab (may_alias accesses, compiler barriers), not the
+      // opaque inline-asm conversion (the builtin form fails the same way): UNEXPLAINED.  With the regions the layer is
+      // bit-identical over 80 full-size launches and to the gather kernel within rounding; they cost 4 us (72 -> 76), and the test
+      // replays the full-size layer for bit-identity.
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
   int t = blockIdx.x;
+  bool have_prev = false;
   load_rows(t);
 #pragma unroll 1
   for (; t < p.ntiles; t += gridDim.x) {
     __syncthreads();                             // every wave is done with the previous tile's rows (first pass: the filter stores)
-    // (the compiler's own wait for this tile's rows counts the 12 younger plane stores of the previous tile and lets them fly)
+    // (the compiler's own wait for this tile's rows counts the younger plane stores of the previous tile and lets them fly)
 #pragma unroll
     for (int i = 0; i < F_NLOAD; i++)
       if (h_lds[i] >= 0) *reinterpret_cast<u32x4*>(Hl + h_lds[i]) = hl[i];
     __syncthreads();
     load_rows(t + gridDim.x);                    // the next tile's rows land under this tile's products
-
-    // ---- products: wave = output row wid; operand A = filter (32 channels per subtile), operand B = the row's 32 sites
-    f32x16 acc[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
-    const unsigned char* xrow = Hl + (2 * wid) * F_PITCH + (l31 + h) * 16;
-    const unsigned char* wrow = Wl + l31 * 64;
-    const int sw = (l31 >> 2) & 3;               // (channel 32 c + l31: the same swizzle for both subtiles)
-#pragma unroll
-    for (int ky = 0; ky < 7; ky++)
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        s16x8 xf[3], wf[2][3];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-          xf[pl] = *reinterpret_cast<const s16x8*>(xrow + pl * F_HPLANE + ky * F_PITCH + s * 32);
-#pragma unroll
-          for (int c = 0; c < 2; c++)
-            wf[c][pl] = *reinterpret_cast<const s16x8*>(wrow + pl * F_WPLANE + (ky * 64 + 32 * c) * 64 + (((2 * s + h) ^ sw) << 4));
-        }
-#pragma unroll
-        for (int tt = 0; tt < 6; tt++)
-#pragma unroll
-          for (int c = 0; c < 2; c++)
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[c][ta[tt]]),
-                                                             __builtin_bit_cast(bf16x8_t, xf[tb[tt]]), acc[c], 0, 0, 0);
-      }
-
-    // ---- epilogue: acc[c][e] = channel 32 c + (e & 3) + 8 (e >> 2) + 4 h of site l31 in output row oy0 + wid
+    if (have_prev) block(T_{}, T_{});
+    else block(T_{}, F_{});
     int b, oy0, ox0;
     tile_of(t, b, oy0, ox0);
-    const int oy = oy0 + wid;
-    unsigned pk[3][2][4][2];                     // [plane][subtile][group][pair]: two packed bf16 each
+    pb = b; poy = oy0 + wid; pox0 = ox0;
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++)
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-          float a = acc[c][4 * g4 + 2 * pr] + bias4[c][g4][2 * pr], bb = acc[c][4 * g4 + 2 * pr + 1] + bias4[c][g4][2 * pr + 1];
-          if (p.leaky) { a = leaky_relu(a); bb = leaky_relu(bb); }
-          const unsigned hh = cvt_pk_bf16(a, bb);
-          const float ra = a - __uint_as_float(hh << 16), rb = bb - __uint_as_float(hh & 0xffff0000u);
-          const unsigned mm = cvt_pk_bf16(ra, rb);
-          const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
-          pk[0][c][g4][pr] = hh; pk[1][c][g4][pr] = mm; pk[2][c][g4][pr] = cvt_pk_bf16(sa, sb);
-        }
-    const int st_site = lane >> 3, st_gr = lane & 7;       // read-back: lane -> (site 8 j + lane / 8, granule lane % 8)
-#pragma unroll
-    for (int pl = 0; pl < 3; pl++) {
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++)
-          *reinterpret_cast<uint2*>(Sl + l31 * F_SPITCH + (32 * c + 8 * g4 + 4 * h) * 2) = make_uint2(pk[pl][c][g4][0], pk[pl][c][g4][1]);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int site = 8 * j + st_site, ox = ox0 + site;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(Sl + site * F_SPITCH + st_gr * 16);
-        const bool ok = oy < p.Ho && ox < p.Wo;
-        const int voff = ok ? (((b * p.Ho + oy) * p.Wo + ox) * p.ldy) * 2 + st_gr * 16 : OOB_MARK;
-        __builtin_amdgcn_raw_buffer_store_b128(v, y_rs, voff, pl * y_pb, 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is read before the next plane overwrites it
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int c = 0; c < 2; c++) accp[c] = acc[c];
+    have_prev = true;
   }
+  if (have_prev) block(F_{}, T_{});
 }
 
 int first7_cus() {
