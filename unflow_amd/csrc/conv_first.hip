@@ -211,7 +211,8 @@ __global__ __launch_bounds__(512) void conv_first7_kernel(const First7Params p) 
       // subtile, odd sites 9-15 of the lower half-wave, the four younger waves (profiles/r04_conv_first.txt) — i.e. single
       // registers of single lanes of the packed planes on their way through the staging slab.  Not the compiler's waits (an
       // explicit vmcnt(0) changes nothing), not type-based aliasing of the slab (may_alias accesses, compiler barriers), not the
-      // opaque inline-asm conversion (the builtin form fails the same way): UNEXPLAINED.  With the regions the layer is
+      // opaque inline-asm conversion (the builtin form fails the same way), not a race against the slab stores' data registers (48
+      // cycles of s_nop behind them change nothing): UNEXPLAINED.  With the regions the layer is
       // bit-identical over 80 full-size launches and to the gather kernel within rounding; they cost 4 us (72 -> 76), and the test
       // replays the full-size layer for bit-identity.
       __builtin_amdgcn_sched_barrier(0);
