@@ -9,8 +9,9 @@ Raw input minibatches (4, rotated) are resident in HBM before the timed region; 
 subtraction) is part of every timed step.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: spawns its own N ranks (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # or under the launcher: ranks read RANK / WORLD_SIZE / MASTER_*
 """
 import argparse
 import json
@@ -44,6 +45,23 @@ CONV_MATH_TEXT = {
 }
 
 
+KITTI_FLOW_HEAD_SCALE = {'flow2': 0.15, 'flow3': 1.0, 'flow4': 3.5, 'flow5': 10.0, 'flow6': 15.0}
+
+
+def kitti_variant_params():
+    """The KITTI training loss of the reference (config_template/config.ini:172-174 over losses.py:43-56): forward-backward
+    consistency + occlusion penalty, the occlusion mask thresholded from the flows."""
+    return dict(flownet='C', pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0, fb_weight=0.2,
+                occ_weight=12.4, mask_occlusion='fb')
+
+
+def kitti_variant_weights(tf_params):
+    """Random-initialised flow heads put out ~2 px at flow2 and ~0.02 px at flow6: the fb mask is then all-occluded on top and
+    empty below.  Rescaled per level (calibrated on the oracle) every level sees 0.3-0.7 px and a mixed mask."""
+    return {k: (v * KITTI_FLOW_HEAD_SCALE[k.split('/')[-2]] if k.endswith('/weights') and k.split('/')[-2] in KITTI_FLOW_HEAD_SCALE else v)
+            for k, v in tf_params.items()}
+
+
 def conv_family_gflop(eng):
     """Algorithmic GFLOP (2*MAC, true channel counts) of all conv/deconv fwd + dgrad + wgrad launches of one step."""
     N = eng.N
@@ -70,6 +88,24 @@ def conv_family_gflop(eng):
                 passes = 3
             tot += f * passes
     return tot, sizes
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU, the job
+    the reference does in-process from its GPU list, run.py:40-49 -> train.py:163-183) by re-executing this script under
+    torch.distributed.run on a free loopback port; the ranks inherit stdout, rank 0 prints the one JSON line.  Returns
+    the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["UNFLOW_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -103,10 +139,15 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32 (default): fp32-equivalent arithmetic (UNFLOW_CONV_MATH picks the kernels); f16: fp16 activations "
                          "and weights into the fp16 MFMA with fp32 accumulation (BASELINE configs[4], use --batch 8)")
+    ap.add_argument("--loss-variant", default="default", choices=["default", "kitti"],
+                    help="kitti: the reference's KITTI training loss (fb_weight 0.2, occ_weight 12.4, mask_occlusion fb) with flow "
+                         "heads rescaled so that the occlusion masks are mixed at every level (SURVEY 8(d) config 2)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="after the K timed steps, keep stepping this long and report it as sustained_value (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if args.dtype == "f16":
         os.environ["UNFLOW_CONV_MATH"] = "f16"
     import torch
@@ -118,6 +159,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("UNFLOW_FORCE_REDUCER") == "1" and "RANK" in os.environ   # test knob
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s); run `python bench.py --gpus %d` (it starts its own "
+                 "ranks) or torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
+    # UNFLOW_DIST_BACKEND=gloo: test knob — several ranks on ONE GPU (RCCL refuses that); same code path, other transport
+    backend = os.environ.get("UNFLOW_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        sys.exit("bench.py: --gpus %d needs %d visible GPUs, this node shows %d (RCCL wants one GPU per rank)" % (world, world, ndev))
+    if backend != "nccl" and ndev:
+        local_rank %= ndev                            # the test transport may stack ranks on the GPUs there are
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # the comm record quotes RCCL's algorithm / protocol / channel lines: INFO logging (init-time lines only) into a file
@@ -128,19 +179,19 @@ def main():
         if os.environ.get("NCCL_DEBUG", "").upper() == "INFO":
             os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/unflow_rccl_%h_%p.log")
         torch.cuda.set_device(local_rank)
-        # UNFLOW_DIST_BACKEND=gloo: test knob — several ranks on ONE GPU (RCCL refuses that); same code path, other transport
-        backend = os.environ.get("UNFLOW_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     B, H, W = args.batch, args.height, args.width
     from unflow_amd.core.engine import DEFAULT_PARAMS
-    eng = FlowNetCEngine(B, H, W, params=dict(DEFAULT_PARAMS, flownet=args.flownet), device=dev, seed=0)   # same weights on every rank
+    net_params = dict(DEFAULT_PARAMS, flownet=args.flownet) if args.loss_variant == "default" else dict(kitti_variant_params(), flownet=args.flownet)
+    eng = FlowNetCEngine(B, H, W, params=net_params, device=dev, seed=0)   # same weights on every rank
+    if args.loss_variant == "kitti":
+        eng.load_tf_params(kitti_variant_weights(eng.export_tf_params()))
     g = torch.Generator().manual_seed(1234 + rank)               # distinct shard per rank
     NBATCH = 4                                                   # raw minibatches resident in HBM, rotated through
     batches = [((torch.rand(B, H, W, 3, generator=g) * 255).to(dev), (torch.rand(B, H, W, 3, generator=g) * 255).to(dev))
@@ -170,7 +221,8 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize()    # drains the communication stream too: the library's own RCCL communicator is idle before the
+        if world > 1:               # process group's collective starts (two communicators on one GPU)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,6 +237,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     loss = eng.loss_acc.item()
+    eng.check_device_faults()       # raises if a stream-K fix-up wait timed out during the timed steps (a wrong tile)
     ms = dt / args.steps * 1e3
     pairs_per_s = world * B * args.steps / dt
     sustained = None
@@ -274,11 +327,13 @@ def measure_roofline(eng, args):
     try:
         for n in names:
             setattr(L, n, wrap(orig[n]))
-        eng.fwd_bwd()              # records the conv-family calls of one step
+        eng._bias_grads = wrap(type(eng)._bias_grads.__get__(eng))     # the bias-gradient pass (column sums of every dz) belongs
+        eng.fwd_bwd()              # records the conv-family calls of one step                    # to conv backward: timed too
         torch.cuda.synchronize()
     finally:
         for n in names:
             setattr(L, n, orig[n])
+        eng.__dict__.pop("_bias_grads", None)
     launches = len(calls)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -320,7 +375,7 @@ def measure_roofline(eng, args):
              "f16": "igemm_pl_gather_kernel / igemm_pl_wgrad_kernel (fp16 planes, csrc/conv_planes.hip)"}.get(
                  eng.math, "igemm_gather_kernel / igemm_wgrad kernel (csrc/conv_igemm.hip)")
     return {"bound": "mfma", "kernel": "%s: gather (%s) + filter gradients (%s) incl. their split-K reduces and "
-                                       "the Cout=2 flow-head kernels: %d layer launches/step"
+                                       "the Cout=2 flow-head kernels and the batched bias-gradient column sums: %d layer launches/step"
                                        % (kname, b3name if (bf16x3 or f16) else f32name, b3name if (wg_b3 or f16) else f32name, launches),
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -446,7 +501,11 @@ def measure_secondary(args):
              ["--flownet", "CSS", "--batch", "2", "--height", "768", "--width", "1024"], None),
             ("FlowNetC f16 B=8 384x512 (BASELINE configs[4])", ["--dtype", "f16", "--batch", "8"],
              "vs the fp32 oracle: loss rel <= 1e-2, final-flow EPE <= 5e-2 px, per-tensor gradient max-rel <= 3e-2 "
-             "(tests/test_f16_gpu.py); the reference has no fp16 path (ops are float-only, correlation_op.cc:134-135)")]
+             "(tests/test_f16_gpu.py); the reference has no fp16 path (ops are float-only, correlation_op.cc:134-135)"),
+            ("FlowNetC B=4 384x512, KITTI training loss: fb_weight 0.2, occ_weight 12.4, mask_occlusion 'fb' (SURVEY 8(d) config 2; "
+             "flow heads rescaled for mixed occlusion masks)", ["--loss-variant", "kitti", "--no-roofline"],
+             "loss rel <= 2e-4, final-flow EPE <= 1e-3 px vs the fp64 oracle (tests/test_parity_fullsize_gpu.py::"
+             "test_flownetc_b4_384x512_kitti_loss_variant_vs_fp64_oracle)")]
     out = []
     for name, extra, tol in cfgs:
         try:

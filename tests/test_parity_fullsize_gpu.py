@@ -4,10 +4,11 @@ The step runs through the same launch path bench.py times (split-K plans and til
 4-launch loss pyramid, two captured hipGraphs) and is compared with the fp64 shadow of the oracle
 (oracle/model_ref.py; torch-CPU autograd) on the same seeded inputs:
 
-  * FlowNetC 384x512, B = 1 and B = 2: loss (rel 1e-4), final flows (EPE 1e-3 px, the north-star bar), EVERY parameter
-    gradient (2e-4 of its max AND 1e-3 mean-relative);
-  * FlowNetC 384x512, B = 4 (the benchmark batch): loss and flows (the B = 4 gradient is tied to the B = 2 one by
-    test_fullsize_gpu.py::test_batch_halves_average_to_full_batch_gradient);
+  * FlowNetC 384x512, B = 1 and B = 4 (the benchmark batch, bench.py's weights and images): loss (rel 1e-4), final flows
+    (EPE 1e-3 px, the north-star bar), EVERY parameter gradient against the untouched fp64 oracle (2e-2 of its max, 3e-3
+    mean-relative) and against the fp64 oracle differentiated along the engine's leaky-ReLU branches (2e-4 / 2e-4), with the
+    number of units on the other side of the kink bounded (<= 1e-5 of the units);
+  * the KITTI loss variant (fb 0.2, occ 12.4, mask_occlusion 'fb') at B = 4, 384x512 with mixed occlusion masks;
   * FlowNetCSS 768x1024, B = 1: end-to-end flows and loss vs the fp32 oracle, and the trained (last) network's flows,
     loss and gradients vs the fp64 oracle fed the engine's own stage-2 flow (isolates the stage from the amplification
     of fp32 noise through the two frozen stages in front of it);
@@ -25,13 +26,28 @@ from parity_util import BranchAligned, check_grads, flownet_c_order, flownet_s_o
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B", [1, 2])
+MAX_FLIP_FRACTION = 1e-5        # leaky-ReLU units allowed on the other side of the kink in fp64 (measured: ~3e-7 of the units)
+
+
+def _bench_or_seeded_inputs(eng, B, H, W):
+    """B = 4: the weights and images bench.py uses (seed 0 / generator 1234); otherwise seeded shifted-frame pairs."""
+    if B == 4:
+        tf_params = eng.init_params(seed=0)
+        g = torch.Generator().manual_seed(1234)
+        return tf_params, torch.rand(B, H, W, 3, generator=g) * 255, torch.rand(B, H, W, 3, generator=g) * 255
+    return (eng.init_params(seed=100 + B),) + images(B, H, W, 200 + B)
+
+
+@pytest.mark.parametrize("B", [1, 4])
 def test_flownetc_step_384x512_vs_fp64_oracle(B, dev):
+    """B = 1 and the BENCHMARK batch B = 4: loss, final flows, and every parameter gradient against BOTH the untouched fp64
+    oracle (loose: set by the leaky-ReLU units within fp32 noise of the kink) and the fp64 oracle differentiated along the
+    engine's branches (tight) — with the number of such units BOUNDED, so that a wrong derivative branch on more than
+    1e-5 of the units (planes_shared.h leaky_grad_from_bits takes the sign from the bf16 hi plane) fails here."""
     from unflow_amd.core.engine import FlowNetCEngine, flow_error_avg
     H, W = 384, 512
     eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
-    tf_params = eng.init_params(seed=100 + B)
-    im1, im2 = images(B, H, W, 200 + B)
+    tf_params, im1, im2 = _bench_or_seeded_inputs(eng, B, H, W)
     loss = graph_step(eng, im1.to(dev), im2.to(dev))
     fw, bw = eng.final_flows()
     got = eng.export_tf_grads()
@@ -41,60 +57,69 @@ def test_flownetc_step_384x512_vs_fp64_oracle(B, dev):
         r = r.float().to(dev)
         assert (a - r).abs().max().item() < 1e-3
         assert flow_error_avg(a, r).item() < 1e-3           # north-star bar: EPE within 1e-3 px of the reference path
-    # (a) the oracle as is (asserted last, loose): set by the handful of leaky-ReLU units whose pre-activation lies within
+    # (a) the oracle as is (loose): set by the handful of leaky-ReLU units whose pre-activation lies within
     # fp32 noise of the kink (parity_util.BranchAligned) — measured 6 of 1.8e7 units, worst element 6e-3, mean 1e-3
     # (b) the oracle differentiated along the branch the engine took at every leaky-ReLU: everything else, tight
     with BranchAligned(eng.act, flownet_c_order(B)) as al:
         _, _, _, grads_al = oracle_step(tf_params, im1, im2, dtype=torch.float64)
     print("B=%d: %d of %d leaky-ReLU units on the other side of the kink in fp64" % (B, al.flips, al.units))
-    worst = check_grads(got, grads_al, tf_params, max_tol=2e-4, mean_tol=2e-4, label="B=%d branch-aligned fp64 oracle:" % B)
+    assert al.flips <= MAX_FLIP_FRACTION * al.units, (al.flips, al.units)
+    # (tensors with <= 64 elements — the 2-element flow-head biases, the 2 -> 2 upsamplers — are sums of a few hundred terms
+    # that cancel heavily: measured 2.1e-4 on flow6/biases at B = 4; bound 2e-3 there)
+    worst = check_grads(got, grads_al, tf_params, max_tol=2e-4, mean_tol=2e-4, small_tol=2e-3 if B == 4 else None,
+                        label="B=%d branch-aligned fp64 oracle:" % B)
     plain = check_grads(got, grads, tf_params, max_tol=2e-2, mean_tol=3e-3, label="B=%d plain fp64 oracle:" % B)
     print("B=%d 384x512: loss rel %.2e; %d of %d leaky-ReLU units on the other side of the kink in fp64; gradients: plain oracle "
           "worst max-rel %.2e mean-rel %.2e, branch-aligned worst max-rel %.2e mean-rel %.2e"
           % (B, abs(loss - loss_ref) / abs(loss_ref), al.flips, al.units, plain[0], plain[1], worst[0], worst[1]))
 
 
-def test_flownetc_b4_384x512_loss_and_flows_vs_oracle(dev):
-    """The benchmark batch.  Forward-only oracle in fp64 (the loss is a 6.3 M-term reduction: the fp32 oracle itself carries
-    ~1e-6); the weights and images are the ones bench.py uses (seed 0 / generator 1234)."""
+def test_flownetc_b4_384x512_kitti_loss_variant_vs_fp64_oracle(dev):
+    """SURVEY 8(d) config 2 at the benchmark shape: the KITTI training loss — forward-backward consistency + occlusion
+    penalty with the occlusion mask thresholded from the flows (losses.py:43-56, config.ini:172-174: fb_weight 0.2,
+    occ_weight 12.4, mask_occlusion 'fb') — B = 4, 384x512, with flow heads rescaled so that every pyramid level sees
+    flows of ~0.3-0.7 px and a MIXED occlusion mask (bench.kitti_variant; the mask fractions are asserted).  Loss and final
+    flows vs the fp64 oracle; parameter gradients vs the branch-aligned fp64 oracle on all but a bounded fraction of elements (a
+    pixel whose |fw + bw_warped|^2 lies within fp32 noise of the threshold carries a different mask bit in fp32 and fp64)."""
+    import bench
     from unflow_amd.core.engine import FlowNetCEngine, flow_error_avg
+    from oracle import model_ref as M
     B, H, W = 4, 384, 512
-    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
-    tf_params = eng.init_params(seed=0)
-    g = torch.Generator().manual_seed(1234)
-    im1 = torch.rand(B, H, W, 3, generator=g) * 255
-    im2 = torch.rand(B, H, W, 3, generator=g) * 255
+    params = bench.kitti_variant_params()
+    eng = FlowNetCEngine(B, H, W, params=params, device=dev, seed=None)
+    tf_params = bench.kitti_variant_weights(eng.init_params(seed=0))
+    eng.load_tf_params(tf_params)
+    im1, im2 = images(B, H, W, 77)
     loss = graph_step(eng, im1.to(dev), im2.to(dev))
     fw, bw = eng.final_flows()
-    loss_ref, ffw, fbw, _ = oracle_step(tf_params, im1, im2, dtype=torch.float64, backward=False)
-    assert abs(loss - loss_ref) <= 1e-4 * abs(loss_ref), (loss, loss_ref)
+    got = eng.export_tf_grads()
+    # the masks must be non-trivial at every level, or this test says nothing about them
+    lfw, lbw = eng.flows()
+    for i, (a, b) in enumerate(zip(lfw, lbw)):
+        s = M.FLOW_SCALE / 2 ** i
+        a, b = a.cpu().double() * s, b.cpu().double() * s
+        bww = M.image_warp(b, a)
+        occ = (M.length_sq(a + bww) > 0.01 * (M.length_sq(a) + M.length_sq(bww)) + 0.5).double().mean().item()
+        print("level %d: mean |flow| %.3f px, fb-occluded fraction %.3f" % (i, a.abs().mean().item(), occ))
+        assert 0.03 < occ < 0.97, (i, occ)
+    with BranchAligned(eng.act, flownet_c_order(B)) as al:
+        loss_ref, ffw, fbw, grads = oracle_step(tf_params, im1, im2, params, dtype=torch.float64)
+    assert al.flips <= MAX_FLIP_FRACTION * al.units, (al.flips, al.units)
+    assert abs(loss - loss_ref) <= 2e-4 * abs(loss_ref), (loss, loss_ref)
     assert flow_error_avg(fw, ffw.float().to(dev)).item() < 1e-3
     assert flow_error_avg(bw, fbw.float().to(dev)).item() < 1e-3
-    assert (fw - ffw.float().to(dev)).abs().max().item() < 1e-3
-    print("B=4 384x512 (bench inputs): loss %.4f oracle %.4f rel %.2e" % (loss, loss_ref, abs(loss - loss_ref) / abs(loss_ref)))
-
-
-def test_flownetc_b4_384x512_gradients_vs_fp64_oracle(dev):
-    """The benchmark batch, every parameter gradient: B = 4 with bench.py's weights and images against
-    the fp64 oracle differentiated along the engine's leaky-ReLU branches (parity_util.BranchAligned; the plain oracle
-    differs only at the handful of units within fp32 noise of the kink, asserted at B = 1 / 2 above)."""
-    from unflow_amd.core.engine import FlowNetCEngine
-    B, H, W = 4, 384, 512
-    eng = FlowNetCEngine(B, H, W, device=dev, seed=None)
-    tf_params = eng.init_params(seed=0)
-    g = torch.Generator().manual_seed(1234)
-    im1 = torch.rand(B, H, W, 3, generator=g) * 255
-    im2 = torch.rand(B, H, W, 3, generator=g) * 255
-    loss = graph_step(eng, im1.to(dev), im2.to(dev))
-    got = eng.export_tf_grads()
-    with BranchAligned(eng.act, flownet_c_order(B)) as al:
-        loss_ref, _, _, grads_al = oracle_step(tf_params, im1, im2, dtype=torch.float64)
-    assert abs(loss - loss_ref) <= 1e-4 * abs(loss_ref), (loss, loss_ref)
-    # (tensors with <= 64 elements — the 2-element flow-head biases, the 2 -> 2 upsamplers — are sums of a few hundred terms
-    # that cancel heavily: measured 2.1e-4 on flow6/biases; bound 2e-3 there)
-    worst = check_grads(got, grads_al, tf_params, max_tol=2e-4, mean_tol=2e-4, small_tol=2e-3, label="B=4 branch-aligned fp64 oracle:")
-    print("B=4 384x512 gradients: %d of %d leaky units flipped in fp64; worst max-rel %.2e mean-rel %.2e"
-          % (al.flips, al.units, worst[0], worst[1]))
+    # mask-bit flips are isolated pixels: per tensor, all but 0.2 % of the elements within 5e-4 of the tensor's max, and the
+    # worst element within 2e-2 (the plain-oracle bound of the default loss)
+    worst = 0.0
+    for k, gr in grads.items():
+        ref = gr.double() - (0.0004 * tf_params[k].double() if k.endswith('/weights') else 0.0)
+        d = (got[k].double().cpu() - ref).abs() / (ref.abs().max() + 1e-30)
+        worst = max(worst, d.max().item())
+        assert d.max().item() < 2e-2, (k, d.max().item())
+        if ref.numel() >= 1024:
+            assert (d > 5e-4).double().mean().item() < 2e-3, (k, (d > 5e-4).double().mean().item())
+    print("B=4 384x512 KITTI loss variant: loss %.4f oracle %.4f rel %.2e; worst gradient element %.2e of its tensor's max; "
+          "%d of %d leaky units flipped" % (loss, loss_ref, abs(loss - loss_ref) / abs(loss_ref), worst, al.flips, al.units))
 
 
 def test_flownet_css_768x1024_vs_oracle(dev):

@@ -325,11 +325,16 @@ def test_conv_first_layer_kernel_planes_only_vs_fp64(case, leaky, dev, lib_optio
         L.conv_fwd(X, wd, w_tr, b.to(dev), Y, 2, leaky, planes_only=True)
         outs.append(_planes_value(Y.pl).cpu())
         if direct and B * H * W >= 8 * 384 * 512:   # the benchmarked shape: six tiles per workgroup, replayed for bit-identity
-            first = Y.pl.clone()                   # (a freely scheduled build of this kernel was wrong in a few lanes, differently every run)
-            for _ in range(10):
+            # round 4's freely scheduled build of this kernel stored 0x40000000 into a few hundred plane elements per launch,
+            # different ones every run (the VMEM store-data hazard behind an SGPR soffset, igemm_shared.h buf_st16_held): 500
+            # launches per activation mode = 1,000 full-size launches, every one bit-identical to the first
+            first = Y.pl.clone()
+            bad = torch.zeros((), dtype=torch.int64, device=dev)
+            for _ in range(500):
                 Y.pl.fill_(0x7fc0)
                 L.conv_fwd(X, wd, w_tr, b.to(dev), Y, 2, leaky, planes_only=True)
-                assert torch.equal(Y.pl, first)
+                bad += (Y.pl != first).sum()
+            assert bad.item() == 0, bad.item()
     scale = y_ref.abs().max().item()
     for o in outs:
         assert not torch.isnan(o).any()

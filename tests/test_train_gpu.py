@@ -110,6 +110,15 @@ for a, b in steps:
     if rank == 0:
         l1.append(r1.step(a.to(dev), b.to(dev), 1e-4).item())
         torch.cuda.synchronize()
+        if len(l1) == 1:
+            # (2a) the exchanged gradient itself, where no optimizer step sits in between (ADVICE r4): the all-reduced flat
+            #      buffer of the ranks x 1/world against the one-process gradient of the concatenated minibatch, first step
+            #      (identical parameters).  Adam's 1/world is fused into the update, so eng.G holds the SUM over the ranks.
+            gsum, gone = eng.G.double() / world, one.G.double()
+            gd = (gsum - gone).abs()
+            gmax = gone.abs().max().item()
+            grad_close = (gd.max().item() / gmax, (gd.mean() / gone.abs().mean()).item())
+            assert grad_close[0] <= 1e-4 and grad_close[1] <= 2e-5, grad_close
         d = (one.P - eng.P).abs()
         frac_close = (d <= 2e-6).float().mean().item()
         assert frac_close > 0.999 and d.max().item() <= 3.1e-4, (len(l1), frac_close, d.max().item())
@@ -119,7 +128,7 @@ for a, b in steps:
 if rank == 0:
     moved = (start - eng.P).abs().max().item()
     assert moved > 1e-4                                            # three Adam steps of 1e-4 did move the weights
-    print("GLOO2_OK", closeness, losses, l1)
+    print("GLOO2_OK", closeness, losses, l1, "reduced gradient vs one process (max-rel, mean-rel):", grad_close)
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -143,6 +152,25 @@ def test_two_ranks_on_one_gpu_over_gloo_match_each_other_and_the_single_process_
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, o[-2000:] + e[-3000:]
     assert "GLOO2_OK" in outs[0][0], outs[0][0][-2000:] + outs[0][1][-2000:]
+
+
+def test_bench_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with NO launcher around it (the command shape the driver uses) starts its two ranks
+    itself and rank 0 prints the one JSON line (reference: one invocation builds all towers from the GPU list, run.py:40-49,
+    train.py:163-183).  One GPU here, so the ranks share it over the gloo test transport."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["UNFLOW_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-secondary",
+                        "--no-cpu-baseline", "--no-alt", "--no-parity", "--no-roofline", "--sustain-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["config"]["global_batch"] == 8
+    assert d["comm"]["params_identical_across_ranks"] is True
+    assert d["value"] > 0 and d["steps"] == 3
 
 
 def test_trainer_forwards_train_all_and_trains_the_first_network(dev):

@@ -34,7 +34,9 @@ class RcclComm:
             _lib.check(self.lib.unflow_comm_unique_id(uid), "comm_unique_id")
         if world > 1:
             box = [bytes(uid.raw)]
-            dist.broadcast_object_list(box, src=0, group=group)
+            # `src` is a GLOBAL rank: the group's own rank 0 (a sub-group need not contain global rank 0)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
             uid = ctypes.create_string_buffer(box[0], 128)
         self.comm = ctypes.c_void_p()
         _lib.check(self.lib.unflow_comm_init(uid, int(world), int(rank), ctypes.byref(self.comm)), "comm_init")
@@ -54,6 +56,12 @@ class RcclComm:
         if self.comm:
             self.lib.unflow_comm_destroy(self.comm)
             self.comm = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _Enqueued:
@@ -91,6 +99,27 @@ class GradAllReducer:
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self.dry = False        # measurement switch (bench.py comm record): reduce_then keeps its stream order but skips the collectives
+
+    def quiesce(self):
+        """Host-side join of the communication stream.  With transport 'rccl' this process holds TWO RCCL communicators on
+        the same GPU (this one and the process group's); collectives of two communicators in flight at once can deadlock
+        unless their order is the same on every rank — so anything that is about to call a torch.distributed collective
+        (Trainer.save's barrier, bench.py's checksums) drains this one first."""
+        if self.cuda and self.rccl is not None:
+            self.stream.synchronize()
+
+    def close(self):
+        """Release the library's communicator (idempotent; the process group is the caller's)."""
+        self.quiesce()
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _issue(self, a, b):
         """One SUM all-reduce of g[a:b], issued with the communication stream current; returns something with .wait()."""

@@ -1158,6 +1158,17 @@ class FlowNetEngine:
                                           cl(self.n_weights), cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1),
                                           cf(beta2), cf(eps), self.stream()), "adam")
 
+    def check_device_faults(self):
+        """Sticky device-side fault counters of the library, read (and cleared) with a host sync: the bounded spins of the
+        stream-K fix-up (csrc/conv_streamk.hip: a waiter that gave up has added a slab that was never written, so an
+        output tile of that launch is WRONG).  Raises instead of returning a count: callers sit at points where the host
+        synchronises anyway (Trainer's display interval and checkpoint, the end of bench.py's timed region)."""
+        n = _lib.lib().unflow_debug_streamk_timeouts()
+        if n != 0:
+            raise RuntimeError("stream-K conv kernels: %d fix-up wait(s) timed out since the last check — results of those "
+                               "launches are wrong; set UNFLOW_OPT_STREAMK=0 and report" % n)
+        return 0
+
     # ------------------------------------------------------------------ composite
     def fwd_bwd(self, im1=None, im2=None):
         if im1 is not None:

@@ -245,6 +245,28 @@ def resize_output_flow(t, height, width, channels=2):
     return torch.stack([r[..., 0] * (width / old_w), r[..., 1] * (height / old_h)], dim=3)
 
 
+def resize_input(t, height, width, resized_h, resized_w):
+    """core/input.py:10-14 (evaluation): the batch-1 image that the input pipeline cropped / zero-padded to (resized_h,
+    resized_w) goes back to its own (height, width) and is then stretched bilinearly onto the network's size."""
+    import torch
+    dev = t.device
+    a = resize_image_with_crop_or_pad(t.reshape(resized_h, resized_w, 3).cpu().numpy(), int(height), int(width))
+    return resize_bilinear_tf1(torch.from_numpy(np.ascontiguousarray(a)).unsqueeze(0).to(dev), resized_h, resized_w)
+
+
+def resize_output_crop(t, height, width, channels):
+    """core/input.py:17-21: a batch-1 ground-truth map cropped / zero-padded back to the frame's own size."""
+    import torch
+    _, oldh, oldw, c = t.shape
+    a = resize_image_with_crop_or_pad(t.reshape(oldh, oldw, c).cpu().numpy(), int(height), int(width))
+    return torch.from_numpy(np.ascontiguousarray(a)).reshape(1, int(height), int(width), channels).to(t.device)
+
+
+def resize_output(t, height, width, channels):
+    """core/input.py:24-25."""
+    return resize_bilinear_tf1(t, int(height), int(width))
+
+
 # ------------------------------------------------------------------------------------- raw-frame input (core/input.py:37-218)
 def frame_name_to_num(name):
     """frame_name_to_num (input.py:37-41): '0000012.png' -> 12, '000.png' -> 0."""

@@ -64,3 +64,15 @@ def second_order_loss(flow):
     check(_lib.lib().unflow_second_order_fwd_bwd(ptr(flow), cf(1.0), ptr(acc), ptr(None), 0, cf(1.0),
                                                  cf(B * H * W * 4), B, H, W, stream()), "second_order_loss")
     return acc[0]
+
+
+def occlusion(flow_fw, flow_bw):
+    """losses.py:125-134: forward-backward occlusion maps (1 = occluded) of a flow pair, NHWC.  Note the reference's
+    magnitude term here is |fw|^2 + |bw|^2 of the UNWARPED fields (compute_losses :43-46 uses the warped partner)."""
+    from .image_warp import image_warp
+    lsq = lambda t: (t * t).sum(3, keepdim=True)       # noqa: E731
+    mag_sq = lsq(flow_fw) + lsq(flow_bw)
+    flow_diff_fw = flow_fw + image_warp(flow_bw, flow_fw)
+    flow_diff_bw = flow_bw + image_warp(flow_fw, flow_bw)
+    occ_thresh = 0.01 * mag_sq + 0.5
+    return (lsq(flow_diff_fw) > occ_thresh).float(), (lsq(flow_diff_bw) > occ_thresh).float()

@@ -1,7 +1,8 @@
 """Mirror of the hot-path parts of src/e2eflow/core/train.py: the training op (get_train_and_loss_ops :147-185:
 AdamOptimizer + towers + average_gradients :388-422), the learning-rate schedule (:225-244) and the loop body
 (:247-251), Trainer.run / train with checkpoint save and resume (:116-145, :186-262; TF checkpoint-V2 bundles written and
-read by core/tf_checkpoint.py).  Evaluation and TF summaries (:265-385) are out of scope.
+read by core/tf_checkpoint.py), and Trainer.eval (:265-385: batch-1 evaluation against KITTI-format ground truth; the TF
+summaries and the plot process around it are out of scope).
 
 One process per GPU.  A training step is
 
@@ -29,23 +30,23 @@ from .engine import FlowNetEngine
 
 
 def learning_rate_at(params, decay_iters):
-    """train.py:225-244: the manual piecewise schedule has priority; else halve every decay_interval after decay_after."""
+    """The schedule of train.py:225-244 as a function of the step index within the run.
+    Manual form (both manual_decay_* keys given) wins: stage k lasts manual_decay_iters[k] steps and uses manual_decay_lrs[k];
+    a step belongs to the first stage whose cumulative end it does not exceed, and — a quirk of the reference's loop kept
+    on purpose — a step past the last stage falls back to stage 0.  Otherwise: constant until decay_after, then divided by
+    2^(floor(step / decay_interval) - decay_after / decay_interval) (a true division: fractional exponents occur)."""
+    from itertools import accumulate
+    base = params.get('learning_rate')
     if 'manual_decay_lrs' in params and 'manual_decay_iters' in params:
-        decay_index, iter_counter = 0, 0
-        for decay_i, manual_decay_iter in enumerate(params['manual_decay_iters']):
-            iter_counter += manual_decay_iter
-            if decay_iters <= iter_counter:
-                decay_index = decay_i
-                break
-        return params['manual_decay_lrs'][decay_index]
-    if 'decay_interval' not in params:
-        return params['learning_rate']
-    decay_interval = params['decay_interval']
-    decay_after = params.get('decay_after', 0)
-    if decay_iters >= decay_after:
-        decay = (decay_iters // decay_interval) - decay_after / decay_interval
-        return params['learning_rate'] / (2 ** decay)
-    return params['learning_rate']
+        stage = next((k for k, end in enumerate(accumulate(params['manual_decay_iters'])) if decay_iters <= end), 0)
+        return params['manual_decay_lrs'][stage]
+    every = params.get('decay_interval')
+    if every is None:
+        return base
+    start = params.get('decay_after', 0)
+    if decay_iters < start:
+        return base
+    return base / 2 ** (decay_iters // every - start / every)
 
 
 # default cuts of the backward pass for the bucketed exchange (layers after which a bucket is released): decoder + conv6_1 +
@@ -198,20 +199,23 @@ class Trainer:
             tensors = {k: v for k, v in tensors.items() if self._in_saved_scope(k)}
             save_checkpoint(os.path.join(ckpt_dir, 'model.ckpt-%d' % global_step), tensors)
         if self.world > 1:
+            if self.runner.reducer is not None:
+                self.runner.reducer.quiesce()       # the library's own communicator drains before the process group's barrier
             dist.barrier()
 
-    def restore(self, ckpt_dir=None):
+    def restore(self, ckpt_dir=None, engine=None):
         """restore_networks (train.py:23-65).  Without a checkpoint in ckpt_dir: the networks named by params['finetune'] (in
         network order) are loaded, the rest keep their initialisation.  With one (continue training): the networks of the
         Saver's scope and their Adam slots come from the checkpoint, and — unless train_all — the frozen networks in front
         again from finetune[:n-1] (the reference's checkpoint of a stacked run does not contain them).  Returns the checkpoint
         prefix or None."""
         from . import tf_checkpoint as T
-        from .input import restore_networks
-        n = len(self.engine.spec)
+        from .input import restore_networks, network_scope
+        engine = self.engine if engine is None else engine
+        n = len(engine.spec)
         finetune = list(self.params.get('finetune') or [])
         if len(finetune) > n:
-            raise ValueError("%d finetune entries for the %d networks of spec %r (train.py:31)" % (len(finetune), n, self.engine.spec))
+            raise ValueError("%d finetune entries for the %d networks of spec %r (train.py:31)" % (len(finetune), n, engine.spec))
         ckpt = T.latest_checkpoint(ckpt_dir) if ckpt_dir is not None else None
         files = [None] * n
         if ckpt is not None:
@@ -219,24 +223,84 @@ class Trainer:
             for i in self._saved_networks():
                 files[i] = ckpt
             external = [] if self.params.get('train_all') else finetune[:n - 1]
-            if not self.params.get('train_all') and not external:
-                # a checkpoint written with every network in it (this trainer before round 4, or a train_all run continued
-                # frozen): take the frozen networks from it rather than leaving them at their initialisation
-                from .input import network_scope
+            if not self.params.get('train_all'):
+                # network by network: a frozen network without a finetune entry comes from the checkpoint when the checkpoint
+                # holds it (written with every network in it: this trainer before round 4, or a train_all run continued
+                # frozen); one that is in neither place would silently run on its random initialisation — say so
                 for i in range(n - 1):
+                    if i < len(external) and external[i] is not None:
+                        continue
                     if any(k.startswith(sc) for k in have for sc in network_scope(i)):
                         files[i] = ckpt
+                    else:
+                        import warnings
+                        warnings.warn("frozen network %d of spec %r is neither in params['finetune'] nor in %s: it keeps its "
+                                      "random initialisation" % (i, engine.spec, ckpt))
         else:
             external = finetune
         for i, f in enumerate(external):       # restored after the checkpoint, like the reference's second loop (:46-63)
-            files[i] = f
+            if f is not None:
+                files[i] = f
         if any(f is not None for f in files):
-            restore_networks(self.engine, self.params, files)
-        if ckpt is not None:
+            restore_networks(engine, self.params, files)
+        if ckpt is not None and engine is self.engine:
             names = [k for k in T.checkpoint_entries(ckpt)[1] if (k.endswith('/Adam') or k.endswith('/Adam_1')) and self._in_saved_scope(k)]
             slots = {k: torch.from_numpy(v) for k, v in T.read_checkpoint(ckpt, names).items()}
-            self.engine.load_tf_adam_slots(slots)
+            engine.load_tf_adam_slots(slots)
         return ckpt
+
+    # ---------------------------------------------------------------------------------------------- train.py:265-385
+    def eval(self, eval_batch_fn, ckpt_dir, num=1, resized=(384, 1280)):
+        """Trainer.eval (train.py:265-385) without the TF summaries / plot process: every batch-1 example of eval_batch_fn()
+        — (im1, im2, input_shape, flow_occ, mask_occ, flow_noc, mask_noc), kitti/input.py:75-82 — is brought from the
+        input pipeline's crop / pad back to its own size and stretched onto the 384 x 1280 network input (resize_input),
+        run through unsupervised_loss(augment=False, return_flow=True) with the networks of the latest checkpoint of
+        ckpt_dir (restore_networks), the final flow is resized to the frame with per-axis rescaling (resize_output_flow) and
+        compared with both ground-truth maps.  Returns what the reference writes to its 'eval_avg' summaries: the averages
+        over the examples of AEE/<name>, outliers/<name> (name = occluded, non-occluded) and the loss; plus global_step
+        and the example count.  `per_example` (list of the per-example values) is kept for tests."""
+        from . import tf_checkpoint as T
+        from .flow_util import flow_error_avg, outlier_pct
+        from .input import resize_input, resize_output_crop, resize_output_flow
+        from .unsupervised import unsupervised_loss
+        assert num == 1                                                       # train.py:266
+        ckpt = T.latest_checkpoint(ckpt_dir)
+        assert ckpt is not None, "No checkpoints to evaluate"                 # train.py:330
+        rh, rw = resized
+        dev = self.engine.dev
+        if getattr(self, '_eval_engine', None) is None or (self._eval_engine.H, self._eval_engine.W) != (rh, rw):
+            eng_params = {k: v for k, v in self.params.items() if k.endswith('_weight') or k in self.ENGINE_KEYS}
+            self._eval_engine = FlowNetEngine(1, rh, rw, params=eng_params or None, device=dev, seed=0)
+        eng = self._eval_engine
+        self.restore(ckpt_dir, engine=eng)
+        names = ['AEE/occluded', 'outliers/occluded', 'AEE/non-occluded', 'outliers/non-occluded', 'loss']
+        sums = [0.0] * len(names)
+        per_example = []
+        for batch in eval_batch_fn():
+            im1, im2, input_shape = (torch.as_tensor(t) for t in batch[:3])
+            truths = [torch.as_tensor(t).float().to(dev) for t in batch[3:]]
+            if len(truths) != 4:
+                raise NotImplementedError()                                   # train.py:306-307
+            height, width = int(input_shape.reshape(-1)[0]), int(input_shape.reshape(-1)[1])
+            a = resize_input(im1.float().to(dev), height, width, rh, rw)
+            b = resize_input(im2.float().to(dev), height, width, rh, rw)
+            loss, flow, flow_bw = unsupervised_loss((a, b), self.params, augment=False, return_flow=True, engine=eng)
+            flow = resize_output_flow(flow, height, width, 2)
+            flow_occ, mask_occ, flow_noc, mask_noc = truths
+            vals = []
+            for gt, mask in ((resize_output_crop(flow_occ, height, width, 2), resize_output_crop(mask_occ, height, width, 1)),
+                             (resize_output_crop(flow_noc, height, width, 2), resize_output_crop(mask_noc, height, width, 1))):
+                vals += [float(flow_error_avg(gt, flow, mask)), float(outlier_pct(gt, flow, mask))]
+            vals.append(float(loss))
+            per_example.append(vals)
+            sums = [s0 + v for s0, v in zip(sums, vals)]
+        n_ex = len(per_example)
+        assert n_ex > 0, "eval_batch_fn() yielded no examples"
+        global_step = int(os.path.basename(ckpt).split('-')[-1])
+        print("-- eval: i = {}".format(global_step))
+        out = {k: s0 / n_ex for k, s0 in zip(names, sums)}
+        out.update(global_step=global_step, num_examples=n_ex, per_example=per_example, names=names)
+        return out
 
     def run(self, min_iter, max_iter, train_batch_fn, ckpt_dir, eval_fn=None):
         """Trainer.run (train.py:116-145): train (at most) from min_iter + 1 to max_iter in chunks of params['save_interval']
@@ -284,8 +348,10 @@ class Trainer:
             loss = self.train_step(im1, im2)
             if i == 1 or i % display == 0:
                 loss = float(loss)
+                self.engine.check_device_faults()       # the host has just synchronised on the loss: read the fault counters
                 log.append((i, loss))
                 print("-- train: i = {}, loss = {}".format(i, loss))
+        self.engine.check_device_faults()               # never checkpoint a run whose kernels reported a fault
         self.save(ckpt_dir, max_iter)
         return log
 

@@ -201,21 +201,22 @@ __global__ __launch_bounds__(512) void conv_first7_kernel(const First7Params p) 
             const u32x4 v = *reinterpret_cast<const u32x4_ma*>(Sl + site * F_SPITCH + st_gr * 16);
             const bool ok = poy < p.Ho && ox < p.Wo;
             const int voff = ok ? (((pb * p.Ho + poy) * p.Wo + ox) * p.ldy) * 2 + st_gr * 16 : OOB_MARK;
-            __builtin_amdgcn_raw_buffer_store_b128(v, y_rs, voff, pl * y_pb, 0);
+            buf_st16_held<0>(v, y_rs, voff, pl * y_pb);
           }
           asm volatile("" ::: "memory");
         }
       }
-      // One scheduling region per tap row.  With the whole block as one region a few hundred to a few thousand elements per launch
-      // come out WRONG, different ones every run but always the same kind — the first channel pair of every group of the second
-      // subtile, odd sites 9-15 of the lower half-wave, the four younger waves (profiles/r04_conv_first.txt) — i.e. single
-      // registers of single lanes of the packed planes on their way through the staging slab.  Not the compiler's waits (an
-      // explicit vmcnt(0) changes nothing), not type-based aliasing of the slab (may_alias accesses, compiler barriers), not the
-      // opaque inline-asm conversion (the builtin form fails the same way), not a race against the slab stores' data registers (48
-      // cycles of s_nop behind them change nothing): UNEXPLAINED.  With the regions the layer is
-      // bit-identical over 80 full-size launches and to the gather kernel within rounding; they cost 4 us (72 -> 76), and the test
-      // replays the full-size layer for bit-identity.
-      __builtin_amdgcn_sched_barrier(0);
+      // (Round 4 needed one scheduling region per tap row here — __builtin_amdgcn_sched_barrier(0) — to be correct, without knowing
+      // why.  Round 5 found why: with the block as one region the register allocator put the NEXT store's address default
+      // (`v_mov_b32 v96, 0x40000000`, the out-of-range mark) into the first data register of the plane store issued one
+      // instruction earlier (`buffer_store_dwordx4 v[96:99], v118, s[28:31], s43 offen`).  A 16-byte store reads its data
+      // registers over several cycles, four lanes of each 16-lane row per cycle; LLVM pads the documented 1 wait state only for
+      // stores WITHOUT an SGPR soffset, and this one has one (the plane offset).  Result: dword 0 = 0x40000000 = bf16 (0, 2.0)
+      // in lanes 12-15 / 28-31 / 44-47 / 60-63 of the second store (sites 8-15) of the middle plane — exactly the recorded
+      // signature: sites 9 / 11 / 13 / 15, channels 32 + 8 g + {0, 1}, errors of 2.0, younger waves more often (issue
+      // arbitration decides whether the v_mov lands in the next cycle).  buf_st16_held (igemm_shared.h) keeps the data registers
+      // allocated past the store; tools/isa_store_hazard.py finds the pattern in the library's assembly: 1 site in the
+      // one-region build of round 4, 0 with the per-row regions, 0 now.  profiles/r05_conv_first_root_cause.txt.)
     }
   };
   using T_ = std::true_type;

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
             u32x4 v;
             v.x = __float_as_uint(acc[i][j][4 * r4]); v.y = __float_as_uint(acc[i][j][4 * r4 + 1]);
             v.z = __float_as_uint(acc[i][j][4 * r4 + 2]); v.w = __float_as_uint(acc[i][j][4 * r4 + 3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, slab_rs, slab_lane + (((i * TN + j) * 4 + r4) * 64) * 16, soff, AUX_SC1);
+            buf_st16_held<AUX_SC1>(v, slab_rs, slab_lane + (((i * TN + j) * 4 + r4) * 64) * 16, soff);
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_sk4_kernel(const PlGathe
             u32x4 v;
             v.x = __float_as_uint(acc[i][j][4 * r4]); v.y = __float_as_uint(acc[i][j][4 * r4 + 1]);
             v.z = __float_as_uint(acc[i][j][4 * r4 + 2]); v.w = __float_as_uint(acc[i][j][4 * r4 + 3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, slab_rs, slab_lane + (((i * TN + j) * 4 + r4) * 64) * 16, soff, AUX_SC1);
+            buf_st16_held<AUX_SC1>(v, slab_rs, slab_lane + (((i * TN + j) * 4 + r4) * 64) * 16, soff);
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();

@@ -259,7 +259,7 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
           if (p.fused_splitk) {   // write-through: the last arriver of the tile reads it from L2 / fabric (splitk_last_arriver)
             u32x4 t;
             t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-            __builtin_amdgcn_raw_buffer_store_b128(t, part_rs, (int)(((size_t)px * p.N + n) * 4), split * (int)(npix_d * p.N * 4), AUX_SC1);
+            buf_st16_held<AUX_SC1>(t, part_rs, (int)(((size_t)px * p.N + n) * 4), split * (int)(npix_d * p.N * 4));
           } else {
             *reinterpret_cast<float4*>(dp) = v;
           }
