@@ -2104,11 +2104,10 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   // 0 and 1 (profiles/r02_xcd_order_per_layer.txt); option xcd_order forces one
   p.order = opt.xcd_order >= 0 && opt.xcd_order <= 2 ? opt.xcd_order : 2;
   const bool halo = pl_halo_ok(p);
-  const bool cf = halo && pl_halo_cf_ok(p, npl);      // the four output-parity classes fused in one workgroup (conv_halo_cf.hip)
   int halo_bn = 128;
   PlPlan pl = plan_pl_gather(p, npl);
   if (halo) {
-    pl.nsplit = cf ? plan_pl_halo_cf(p) : plan_pl_halo(p, npl, &halo_bn);
+    pl.nsplit = plan_pl_halo(p, npl, &halo_bn);
     p.tiles_y = cdiv(p.Hg, TH);
     p.tiles_x = cdiv(p.Wg, TW);
   }
@@ -2125,26 +2124,6 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
     p.vec_epi = p.N % 4 == 0 && (!p.dst || p.ldd % 4 == 0) && ((!p.act_src && !p.act_pl) || p.ld_act % 4 == 0) && (al & 15) == 0 &&
                 (!p.pl.n_planes || p.pl.ld % 4 == 0);
     if (!p.dst && (!p.vec_epi || p.accumulate || !p.pl.n_planes)) return UNFLOW_ERR_UNSUPPORTED;   // planes-only output
-  }
-  if (cf && p.vec_epi) {
-    p.fused_splitk = 0; p.counters = nullptr;
-    const int code = launch_pl_halo_cf(p, st);
-    if (code != UNFLOW_OK) return code;
-    if (p.nsplit > 1) {
-      const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
-      pl_splitk_reduce_epilogue_kernel<<<stream_grid((long)(total / 4)), 256, 0, st>>>(p, 1);
-      return launch_status();
-    }
-    return UNFLOW_OK;
-  }
-  if (cf) {      // scalar epilogue needed: the per-class kernels take it, with their own split
-    pl.nsplit = plan_pl_halo(p, npl, &halo_bn);
-    p.nsplit = pl.nsplit;
-    p.partial = nullptr;
-    if (p.nsplit > 1) {
-      if (!ws || ws_bytes < pl_gather_partial_bytes(p, p.nsplit)) p.nsplit = 1;
-      else p.partial = reinterpret_cast<float*>(ws);
-    }
   }
   if (halo && p.vec_epi && pl_halo_sk_ok(p, npl, halo_bn) && ws && ws_bytes >= pl_halo_sk_ws_bytes())
     return launch_pl_halo_sk(p, ws, ws_bytes, st);      // persistent stream-K form (conv_streamk.hip): no split, no reduce pass
@@ -2413,8 +2392,7 @@ UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const 
 static int pl_gather_nsplit(const GatherGeom& g, int npl) {      // (workspace sizing: the larger of the forms that may run)
   int bn;
   if (!pl_halo_ok(g)) return plan_pl_gather(g, npl).nsplit;
-  const int ns = plan_pl_halo(g, npl, &bn);
-  return pl_halo_cf_ok(g, npl) ? max(ns, plan_pl_halo_cf(g)) : ns;
+  return plan_pl_halo(g, npl, &bn);
 }
 
 UNFLOW_API size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes) {

@@ -21,7 +21,6 @@
   X(streamk4, 0)          /* ... its 4-wave form for the short-item halo layers: 1 where it pays, 2 wherever eligible, 0 off */     \
   X(streamk_groups, 8)    /* ... M groups of its item order (one per XCD); 1: tap class slowest over the whole launch */         \
   X(halo_max_split, 16)   /* split-K of the one-shot halo kernel: at most this many splits */                                      \
-  X(halo_cf, 1)           /* class-fused halo kernel (conv_halo_cf.hip) for the four output-parity classes of stride-2 data gradients / conv_transpose forward */ \
   X(halo_s2, 1)           /* halo kernel also for source-stride-2 layers (four accumulating parity classes) */            \
   X(gather_cfg, -1)       /* force the tile config of the plain gather kernel for N <= 64 layers (1: 128 x 64, 2: 64 x 64) */   \
   X(xcd_swizzle, 1)       /* XCD-contiguous work order */                                                                 \

@@ -319,12 +319,6 @@ inline int pl_halo_pixels(const GatherGeom& p) {
   return p.acc ? (TH + mty - 1) * (TW + mtx - 1) : hp;      // accumulating classes share one halo image (widest row pitch)
 }
 
-// ---- class-fused halo kernel (conv_halo_cf.hip): the four output-parity classes of a stride-2 data gradient / conv_transpose
-// forward in one workgroup (tile = 4 x 32 sites x (4 classes x 32 channels), union halo staged once)
-bool pl_halo_cf_ok(const GatherGeom& p, int npl);               // eligible (option halo_cf)
-int plan_pl_halo_cf(const GatherGeom& p);                       // K split (whole chunks)
-int launch_pl_halo_cf(const PlGatherParams& p, hipStream_t st);      // p.tiles_y / tiles_x / nsplit / partial set
-
 // ---- persistent stream-K halo kernel (conv_streamk.hip)
 bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn);      // eligible and expected to pay (option streamk)
 size_t pl_halo_sk_ws_bytes();                                   // slabs + arrival flags
