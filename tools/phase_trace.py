@@ -83,12 +83,8 @@ def main():
         trace("gather kernel, conv6_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(Xd, wd, td, bd, Yd, 1, True),
               ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
         return
-    if _lib.get_option("halo_pp") > 0:
-        trace("ping-pong halo kernel, conv3_1 forward (2 x 24 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),
-              ["read slot 0", "barrier", "24 mfma", "barrier", "read slot 1 + barrier", "24 mfma + barrier"])
-    else:
-        trace("halo kernel, conv3_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),
-              ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
+    trace("halo kernel, conv3_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),
+          ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
     if _lib.get_option("wgrad_pp") > 0:
         trace("ping-pong filter gradient, conv3_1 (2 x 24 MFMAs per wave and stage):", lambda: L.conv_bwd_filter(X, DZ, dw, 1),
               ["read slot 0", "barrier", "24 mfma", "barrier", "read slot 1 + barrier", "24 mfma + barrier"])

@@ -278,10 +278,6 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
   PHASE_FLUSH;
 
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
-  if (p.fused_splitk) {
-    if (!splitk_last_arriver(p, (cls_id * p.mt + mtile) * p.nt + ntile, pix + BM)) return;
-    splitk_tile_reduce<BM, BN>(p, pix, n0);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ gather kernel, ping-pong form
@@ -782,247 +778,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   }
   PHASE_FLUSH;
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
-  if (p.fused_splitk) {
-    if (!splitk_last_arriver(p, (cls_id * p.mt + mtile_id) * p.nt + ntile, pix + BM)) return;
-    splitk_tile_reduce<BM, BN>(p, pix, n0);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ halo kernel, ping-pong form
-// Two 4-wave instances (neighbouring 4 x 32-site tiles, the same N tile / class / split) in one workgroup, scheduled against
-// each other in HALF-tile slots: read slot (the 12 fragments of one K16 slab -> registers; in the first one also: the next
-// weight tile -> LDS and the loads of the one after it), then a multiply slot (24 MFMAs at raised priority); the second
-// instance runs one slot behind, one workgroup barrier per slot.  (Pairing the unchanged kernel — whole MFMA phases against
-// store phases — was 6 % SLOWER: the phases have to be balanced, profiles/r03_halo_pingpong_per_layer.txt.)  The halos are
-// private and single-buffered: a new chunk's halo (loaded two tiles ahead) is stored at the start of the LAST multiply slot
-// of the old chunk, after every wave of the instance has finished reading it.  The weight tile is shared and
-// double-buffered, unpadded (XOR swizzle only); each instance stores half.  Non-accumulating classes only.
-template <int NPL, bool F16>
-__global__ __launch_bounds__(512, 1) void igemm_pl_halo_pp_kernel(const PlGatherParams p, int HPmax) {
-  constexpr int BM = 128, BN = 128, WM = 64, WN = 64;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int LDP = 32;
-  constexpr int B_PLANE = BN * LDP, B_TILE = NPL * B_PLANE;
-  constexpr int NH = 4;
-  constexpr int NT = NPL == 3 ? 6 : 1;
-  static_assert(NPL == 3 && !F16, "bf16 x 3 only");
-
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem_all[];
-  const int inst = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
-  const int H_PLANE = HPmax * HPITCH;
-  unsigned short* Hh = smem_all + inst * NPL * H_PLANE;
-  unsigned short* Bbase = smem_all + 2 * NPL * H_PLANE;
-  int* pix = reinterpret_cast<int*>(smem_all + 2 * NPL * H_PLANE + 2 * B_TILE) + inst * BM;
-
-  const int wm = wid >> 1, wn = wid & 1;
-  int t, ntile, cls_id, split;
-  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id, split);
-  if (t < 0) return;
-  t = 2 * t + inst;
-  const bool tile_ok = t < p.B * p.tiles_y * p.tiles_x;
-  const TapClass tc = p.cls[cls_id];
-  const int n0 = ntile * BN;
-  const int Cg = p.Cs >> 3;
-  const int nchunk = (Cg + 3) >> 2;
-  const int ch_per = (nchunk + p.nsplit - 1) / p.nsplit;
-  const int ch0 = split * ch_per, ch1 = min(nchunk, (split + 1) * ch_per);
-  const int ntaps = tc.nty * tc.ntx;
-  const int T = max(ch1 - ch0, 0) * ntaps;
-  const int txi = t % p.tiles_x; t /= p.tiles_x;
-  const int tyi = t % p.tiles_y;
-  const int b = t / p.tiles_y;
-  const int y0 = tyi * TH, x0 = txi * TW;
-  const int HC = TW + tc.ntx - 1;
-
-  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
-#pragma unroll
-  for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
-    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
-  }
-  const int kq = tid & 3;
-  const int lds2 = p.lds * 2;
-  int h_off[NH];
-  {
-    const int dmy = p.dstep > 0 ? tc.dy0 : tc.dy0 - (tc.nty - 1);
-    const int dmx = p.dstep > 0 ? tc.dx0 : tc.dx0 - (tc.ntx - 1);
-    const int HRc = TH + tc.nty - 1;
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-      const int hp = (tid >> 2) + 64 * j;
-      const int hy = hp / HC, hx = hp - hy * HC;
-      const int y = (y0 + hy) * p.sp + dmy, x = (x0 + hx) * p.sp + dmx;
-      const bool ok = tile_ok && hy < HRc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-      h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
-    }
-  }
-  if (tid < BM) {
-    const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
-    pix[tid] = (tile_ok && yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px : -1;
-  }
-  const int b_r = 64 * inst + (tid >> 2);       // this instance's half of the weight tile
-  const int b_row = n0 + b_r < p.N ? (n0 + b_r) * p.Cs * 2 + kq * 16 : OOB_MARK;
-
-  // walkers over the block's K tiles (chunk-major, then tap): L = the tile the next load_b() requests, M = the tile multiplied
-  int l_chunk = ch0, l_ty = 0, l_tx = 0, l_left = T;
-  int m_ty = 0, m_tx = 0;
-  u32x4 rh[NH][NPL], rb[NPL];
-  auto load_b = [&]() {                          // weights of tile L; returns whether tile L opens a chunk; advances L
-    const int widx = (tc.ky0 + l_ty * p.kstep) * p.KW + tc.kx0 + l_tx * p.kstep;
-    const bool ok = l_left > 0 && l_chunk * 4 + kq < Cg;
-    const int voff = ok ? b_row + widx * p.N * p.Cs * 2 + l_chunk * 64 : OOB_MARK;
-#pragma unroll
-    for (int pl = 0; pl < NPL; pl++) rb[pl] = buf_ld16(w_rs[pl], voff);
-  };
-  auto load_h = [&]() {                          // the halo of chunk l_chunk
-    const bool okc = l_left > 0 && l_chunk * 4 + kq < Cg;
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-      const int voff = okc ? h_off[j] + l_chunk * 64 : OOB_MARK;
-#pragma unroll
-      for (int pl = 0; pl < NPL; pl++) rh[j][pl] = buf_ld16(src_rs[pl], voff);
-    }
-  };
-  auto l_advance = [&]() {
-    l_tx++;
-    if (l_tx == tc.ntx) { l_tx = 0; l_ty++; }
-    if (l_ty == tc.nty) { l_ty = 0; l_chunk++; }
-    l_left--;
-  };
-  auto swz = [](int row, int g) { return row * LDP + 8 * (g ^ ((row >> 2) & 3)); };
-  auto store_b = [&](int buf) {
-#pragma unroll
-    for (int pl = 0; pl < NPL; pl++) *reinterpret_cast<u32x4*>(Bbase + buf * B_TILE + pl * B_PLANE + swz(b_r, kq)) = rb[pl];
-  };
-  auto store_h = [&]() {
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-      const int hp = (tid >> 2) + 64 * j;
-      if (hp < HPmax) {
-#pragma unroll
-        for (int pl = 0; pl < NPL; pl++) *reinterpret_cast<u32x4*>(Hh + pl * H_PLANE + hp * HPITCH + kq * 8) = rh[j][pl];
-      }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  int a_rd[TM];
-#pragma unroll
-  for (int i = 0; i < TM; i++) {
-    const int sidx = wm * WM + i * 32 + l31;
-    a_rd[i] = ((sidx >> TWL) * HC + (sidx & (TW - 1))) * HPITCH + lh * 8;
-  }
-  const int b_rd = (wn * WN + l31) * LDP;
-  const int gsw = lh ^ ((l31 >> 2) & 3);
-  const int c_hy0 = p.dstep > 0 ? 0 : tc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : tc.ntx - 1;
-
-  s16x8 av[TM][NPL], bv[TN][NPL];
-  auto read_frags = [&](int buf, int slab) {     // the tile multiplied now: tap (m_ty, m_tx) of the halo, weight buffer `buf`
-    const int tapoff = ((c_hy0 + m_ty * p.dstep) * HC + c_hx0 + m_tx * p.dstep) * HPITCH;
-#pragma unroll
-    for (int pl = 0; pl < NPL; pl++) {
-#pragma unroll
-      for (int j = 0; j < TN; j++)
-        bv[j][pl] = *reinterpret_cast<const s16x8*>(Bbase + buf * B_TILE + pl * B_PLANE + b_rd + j * 32 * LDP + 8 * (gsw ^ (2 * slab)));
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-        av[i][pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
-    }
-  };
-  auto multiply = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int tt = 0; tt < NT; tt++)
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], tt);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto slot_end = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  if (T > 0) {
-    // tile 0: its halo and its half of the weights -> LDS; tile 1's weights (and halo, if it opens a chunk) requested
-    load_h();
-    load_b();
-    l_advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_h();
-    store_b(0);
-    bool h_pending = l_left > 0 && l_ty == 0 && l_tx == 0;     // tile 1 opens a chunk (one tap per chunk): its halo is in flight
-    if (h_pending) load_h();
-    load_b();
-    l_advance();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    slot_end();
-    if (inst == 1) slot_end();
-    PHASE_DECL;
-#pragma unroll 1
-    for (int kk = 0; kk < T; kk++) {
-      PHASE_STAMP(6);
-      // ---- read slot 0: slab 0 of tile kk; tile kk + 1's weights -> the other buffer; request tile kk + 2
-      read_frags(kk & 1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tile kk + 1's weights (and a pending halo) are in registers
-      store_b((kk + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const bool store_halo_now = h_pending;                    // the halo of the chunk tile kk + 1 opens: stored in this tile's LAST slot
-      // (rh keeps the pending halo until the last multiply slot of this tile; the loads below only overwrite rb — unless tile
-      // kk + 2 opens a chunk itself, which needs rh: then this tile's halo store comes first, see below)
-      const bool next_opens = l_left > 0 && l_ty == 0 && l_tx == 0;   // tile kk + 2 opens a chunk
-      load_b();
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PHASE_STAMP(0);    // read slot 0
-      slot_end();
-      PHASE_STAMP(1);    // barrier
-      multiply();                                               // slab 0
-      PHASE_STAMP(2);    // 24 MFMAs
-      slot_end();
-      PHASE_STAMP(3);    // barrier
-      // ---- read slot 1: slab 1 of tile kk
-      read_frags(kk & 1, 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every halo read of this tile has returned
-      slot_end();
-      PHASE_STAMP(4);    // read slot 1 + barrier
-      if (store_halo_now) {                                     // the old chunk is done: its successor's halo -> LDS
-        store_h();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      h_pending = false;
-      if (next_opens) {                                         // tile kk + 2's halo: requested now that rh is free
-        load_h();
-        h_pending = true;
-      }
-      l_advance();
-      __builtin_amdgcn_sched_barrier(0);
-      multiply();                                               // slab 1
-      slot_end();
-      m_tx++;
-      if (m_tx == tc.ntx) { m_tx = 0; m_ty++; }
-      if (m_ty == tc.nty) m_ty = 0;
-    }
-    PHASE_FLUSH;
-    if (inst == 0) slot_end();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();                               // both instances are done with the LDS tiles: the epilogue stages through them
-  if (!tile_ok) return;
-  pl_gather_epilogue<WM, WN>(p, acc, pix, smem_all + inst * (4 * 32 * (WN + 4) * 2), wm, wn, wid, lane, n0, split);
 }
 
 // (Round 3 measured and dropped, profiles/r03_halo_tall_ab.txt: a 256-site (8 x 32) form of this kernel with 8 waves per
@@ -1911,7 +1666,6 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   // a K loop of a few tiles (FlowNetC's first layer: 7) is all prologue and epilogue: more, smaller workgroups in flight
   // (conv1 forward 98 -> 91 us)
   if (pl.cfg == 1 && KT <= 8) pl.cfg = 2;
-  if (unflow::options().gather_cfg >= 0 && unflow::options().gather_cfg <= 2 && p.N <= 64) pl.cfg = unflow::options().gather_cfg;   // A/B
   const int bm = pl.cfg == 2 ? 64 : 128, bn = pl.cfg == 0 ? 128 : 64;
   const int slots = 256 * pl_blocks_per_cu(bm, bn, npl);
   const long blocks = ((M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ncls;
@@ -1931,16 +1685,11 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
   return pl;
 }
 
-inline size_t pl_gather_counter_bytes(const GatherGeom& p) {      // arrival counters of the fused split-K (64 x 64 tiles at worst)
-  const size_t M = (size_t)p.B * p.Hg * p.Wg;
-  const size_t halo_tiles = (size_t)p.B * (p.Hg / 4 + 1) * (p.Wg / 32 + 1);     // 4 x 32-site tiles, ragged edges included
-  return ((((M + 63) / 64 + 8) + halo_tiles) * ((p.N + 63) / 64) * p.ncls * sizeof(int) + 255) & ~(size_t)255;
-}
 inline size_t pl_gather_slab_bytes(const GatherGeom& p, int nsplit) {
   return (((size_t)nsplit * p.B * p.Hd * p.Wd * p.N * sizeof(float)) + 255) & ~(size_t)255;
 }
 inline size_t pl_gather_partial_bytes(const GatherGeom& p, int nsplit) {
-  return nsplit > 1 ? pl_gather_slab_bytes(p, nsplit) + pl_gather_counter_bytes(p) : 0;
+  return nsplit > 1 ? pl_gather_slab_bytes(p, nsplit) : 0;
 }
 
 // workgroups of a launch (q.mt, q.nt set): order 2 pads the M tiles to whole groups
@@ -1981,7 +1730,6 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   q.mt = cdiv(M, BM); q.nt = cdiv(p.N, BN);
   pl_gather_tiles2d<BM>(q);
   const int grid = pl_grid(q);
-  if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * q.ncls * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
   igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q);
   return launch_status();
 }
@@ -2050,32 +1798,7 @@ inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
   }
   if (p.acc) maxtaps = sumtaps;                                       // a block walks every class
   const int max_by_k = max(1, min(min(16, max(1, unflow::options().halo_max_split)), nchunk * maxtaps / 16));      // >= 16 K tiles per split, whole chunks
-  if (bn == 128 && unflow::options().halo_pp > 0 && npl == 3 && !p.acc &&
-      2 * 3 * pl_halo_pixels(p) * HPITCH * 2 + 2 * 3 * 128 * 32 * 2 + 2 * 128 * 4 <= 160 * 1024) {      // (= pl_halo_pp_ok, declared below)
-    const long pairs = (((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) + 1) / 2) * cdiv(p.N, bn) * pl_grid_classes(p);
-    return min(nchunk, fill_one_round(pairs, 256, max_by_k));
-  }
   return min(nchunk, fill_one_round(blocks, 256 * per_cu, max_by_k));
-}
-
-// ping-pong form of the 128 x 128 halo kernel: two tiles per 512-thread workgroup, one workgroup per CU
-inline int pl_halo_pp_smem(const GatherGeom& p) { return 2 * 3 * pl_halo_pixels(p) * HPITCH * 2 + 2 * 3 * 128 * 32 * 2 + 2 * 128 * 4; }
-inline bool pl_halo_pp_ok(const GatherGeom& p, int npl, int bn) {
-  return unflow::options().halo_pp > 0 && npl == 3 && bn == 128 && !p.acc && pl_halo_pp_smem(p) <= 160 * 1024;
-}
-int launch_pl_halo_pp(const PlGatherParams& p, hipStream_t st) {
-  const int hp = pl_halo_pixels(p);
-  const int smem = pl_halo_pp_smem(p);
-  static int smem_set = 0;
-  if (smem > smem_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_pp_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    smem_set = smem;
-  }
-  PlGatherParams q = p;
-  q.mt = cdiv(p.B * p.tiles_y * p.tiles_x, 2); q.nt = cdiv(p.N, 128);
-  const int grid = pl_grid(q);
-  igemm_pl_halo_pp_kernel<3, false><<<grid, 512, smem, st>>>(q, hp);
-  return launch_status();
 }
 
 template <int BN, int WN, int NPL, bool F16>
@@ -2091,7 +1814,6 @@ int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   PlGatherParams q = p;
   q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
   const int grid = pl_grid(q);
-  if (q.fused_splitk && hipMemsetAsync(q.counters, 0, (size_t)q.mt * q.nt * pl_grid_classes(q) * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
   igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<grid, 256, smem, st>>>(q, hp);
   return launch_status();
 }
@@ -2101,8 +1823,8 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   if (p.src_inv == 0.f) p.src_inv = 1.f;
   p.xcd = opt.xcd_swizzle;
   // order 2 (M groups per XCD, M tile fastest inside) measured best or tied on every layer of FlowNetC 384x512 B=4 against
-  // 0 and 1 (profiles/r02_xcd_order_per_layer.txt); option xcd_order forces one
-  p.order = opt.xcd_order >= 0 && opt.xcd_order <= 2 ? opt.xcd_order : 2;
+  // 0 and 1 (profiles/r02_xcd_order_per_layer.txt)
+  p.order = 2;
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
   PlPlan pl = plan_pl_gather(p, npl);
@@ -2127,28 +1849,15 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   }
   if (halo && p.vec_epi && pl_halo_sk_ok(p, npl, halo_bn) && ws && ws_bytes >= pl_halo_sk_ws_bytes())
     return launch_pl_halo_sk(p, ws, ws_bytes, st);      // persistent stream-K form (conv_streamk.hip): no split, no reduce pass
-  if (halo && p.vec_epi && pl_halo_sk4_ok(p, npl, halo_bn) && ws && ws_bytes >= pl_halo_sk_ws_bytes())
-    return launch_pl_halo_sk4(p, halo_bn, ws, ws_bytes, st);      // ... its 4-wave form
-  {
-    // option fused_splitk = n: in-kernel reduction (splitk_last_arriver) for tiles with up to n slices.  Default 0 = always the
-    // chip-wide reduce kernel: measured on MI355X (FlowNetC 384x512 B=4) the fused form is bit-identical but not faster —
-    // n = 4: 597 vs 599 image-pairs/s, n = 16 with release/acquire fences: 521 vs 590 — although the reduce launches cost
-    // 0.69 ms of the step (no-reduce ablation): what they cost is the second pass over the partials, which
-    // one block per tile does no faster than 256 CUs.  Kept as a tested alternative.
-    const int fused = opt.fused_splitk;
-    p.fused_splitk = p.nsplit > 1 && p.nsplit <= fused && p.vec_epi && pl_gather_slab_bytes(p, p.nsplit) < 0x3fffffffu && !(pl.pp && !halo) && !(halo && pl_halo_pp_ok(p, npl, halo_bn));
-    p.counters = p.fused_splitk ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + pl_gather_slab_bytes(p, p.nsplit)) : nullptr;
-  }
   int code;
   if (halo) {
-    if (npl == 3 && pl_halo_pp_ok(p, npl, halo_bn)) code = launch_pl_halo_pp(p, st);
-    else if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
+    if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
     else code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
   } else {
     code = pl.pp ? launch_pl_gather_pp(p, st) : npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   }
   if (code != UNFLOW_OK) return code;
-  if (p.nsplit > 1 && !p.fused_splitk) {
+  if (p.nsplit > 1) {
     const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
     pl_splitk_reduce_epilogue_kernel<<<stream_grid((long)(p.vec_epi ? total / 4 : total)), 256, 0, st>>>(p, p.vec_epi);
     return launch_status();

@@ -400,318 +400,6 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
 }
 
 
-// ------------------------------------------------------------------------------------------------ 4-wave form
-// The same range walk on the ONE-SHOT halo kernel's workgroup (conv_planes.hip: igemm_pl_halo_kernel — 256 threads, one
-// 4 x 32-site tile, single LDS stage, the next K tile's loads between the MFMA groups of this one): two (BN = 128) or three
-// (BN = 64) workgroups share a CU, so one's segment boundary (prologue, epilogue, slab hand-off) hides under the other's K
-// loop.  For the layers whose items are SHORT — the output-parity classes of the stride-2 data gradients and of
-// conv_transpose forward (16 .. 72 K tiles per item), conv2's forward, the N = 64 decoder level — where the one-shot launch
-// packs uneven blocks onto its slots (conv4's data gradient: 384 blocks of 16 / 32 / 32 / 64 K tiles on 512 slots) and the
-// 8-wave form above exposes every boundary.  Items are single tiles here (plan field mtp = M tiles).
-template <int BN, int WN, bool ACC>
-__global__ __launch_bounds__(256, 2) void igemm_pl_halo_sk4_kernel(const PlGatherParams p, const SkPlan sk, int HPmax) {
-  constexpr int BM = 128, WM = 64, NPL = 3;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
-  constexpr int B_PLANE = BN * LDH;
-  constexpr int NB = BN / 64;
-  constexpr int NH = 4;
-  constexpr int NT = 6;
-  constexpr int SLAB = 4 * TM * TN * 4 * 64 * 16;       // bytes per workgroup: the accumulators as they lie in registers
-
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  const int H_PLANE = HPmax * HPITCH;
-  unsigned short* Hh = smem16;
-  unsigned short* Bh = Hh + NPL * H_PLANE;
-  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_halo_main_bytes(BN, WN, NPL, HPmax));
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x, p.xcd);
-  const unsigned pos_begin = sk_pos(sk, wg), pos_end = sk_pos(sk, wg + 1);
-  if (pos_begin >= pos_end) return;
-
-  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
-#pragma unroll
-  for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
-    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
-  }
-  const __amdgpu_buffer_rsrc_t slab_rs = make_rsrc(sk.slabs, (size_t)sk.G * SLAB);
-  const int kq = tid & 3;
-  const int lds2 = p.lds * 2;
-  const int Cg = p.Cs >> 3;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
-  const int gsw = lh ^ ((l31 >> 2) & 3);
-  const int slab_lane = (wid * (TM * TN * 4) * 64 + lane) * 16;
-  auto swz = [](int row, int g) { return row * LDH + 8 * (g ^ ((row >> 2) & 3)); };
-
-#pragma unroll 1
-  for (unsigned pos = pos_begin; pos < pos_end;) {
-    int cls_id, ntile, mtile, k0;
-    sk_decode(sk, pos, cls_id, ntile, mtile, k0);
-    const int nk = sk.nchunk * sk.ntaps[ACC ? 0 : cls_id];
-    const int k1 = min(nk, k0 + (int)(pos_end - pos));
-    const unsigned item_end = pos - (unsigned)k0 + (unsigned)nk;
-    pos += (unsigned)(k1 - k0);
-    int cls0 = cls_id, kc0 = k0;
-    if (ACC) {
-      cls0 = 0;
-      for (;;) {
-        const int nkc = sk.nchunk * p.cls[cls0].nty * p.cls[cls0].ntx;
-        if (kc0 < nkc || cls0 + 1 >= p.ncls) break;
-        kc0 -= nkc;
-        cls0++;
-      }
-    }
-    const int T = k1 - k0;
-    const int n0 = ntile * BN;
-    int t = mtile;
-    const int txi = t % p.tiles_x; t /= p.tiles_x;
-    const int tyi = t % p.tiles_y;
-    const int b = t / p.tiles_y;
-    const int y0 = tyi * TH, x0 = txi * TW;
-    int HC = TW + p.cls[cls0].ntx - 1;
-    if (ACC)
-      for (int c = 0; c < p.ncls; c++) HC = max(HC, TW + p.cls[c].ntx - 1);
-
-    __syncthreads();       // the previous segment's epilogue is done with LDS
-    TapClass ltc = p.cls[cls0];
-    int h_off[NH];
-    auto set_load_class = [&]() {
-      const int dmy = p.dstep > 0 ? ltc.dy0 : ltc.dy0 - (ltc.nty - 1);
-      const int dmx = p.dstep > 0 ? ltc.dx0 : ltc.dx0 - (ltc.ntx - 1);
-      const int HRc = TH + ltc.nty - 1, HCc = TW + ltc.ntx - 1;
-#pragma unroll
-      for (int j = 0; j < NH; j++) {
-        const int hp = (tid >> 2) + 64 * j;
-        const int hy = hp / HC, hx = hp - hy * HC;
-        const int y = (y0 + hy) * p.sp + dmy, x = (x0 + hx) * p.sp + dmx;
-        const bool ok = hy < HRc && hx < HCc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-        h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
-      }
-    };
-    set_load_class();
-    if (tid < BM) {
-      const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
-      pix[tid] = (yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + ltc.py) * p.Wd + xg * p.so + ltc.px : -1;
-    }
-    int b_row[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      const int n = n0 + (tid >> 2) + 64 * i;
-      b_row[i] = n < p.N ? n * p.Cs * 2 + kq * 16 : OOB_MARK;
-    }
-
-    u32x4 rh[NH][NPL], rb[NB][NPL];
-    // the K tile the loads target: (class ld_c,) chunk, tap — the one multiplied next
-    const int ntaps0 = ltc.nty * ltc.ntx;
-    const int tap0 = kc0 % ntaps0;
-    int ld_c = cls0, ld_chunk = kc0 / ntaps0, ld_ty = tap0 / ltc.ntx, ld_tx = tap0 % ltc.ntx;
-    bool ld_live = true;
-    auto load_b = [&](int i) {
-      const int widx = (ltc.ky0 + ld_ty * p.kstep) * p.KW + ltc.kx0 + ld_tx * p.kstep;
-      const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
-      const int voff = ok ? b_row[i] + widx * p.N * p.Cs * 2 + ld_chunk * 64 : OOB_MARK;
-#pragma unroll
-      for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
-    };
-    auto load_h = [&](int j) {
-      const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
-      const int voff = ok ? h_off[j] + ld_chunk * 64 : OOB_MARK;
-#pragma unroll
-      for (int pl = 0; pl < NPL; pl++) rh[j][pl] = buf_ld16(src_rs[pl], voff);
-    };
-    auto ld_advance = [&](int kk_next) {
-      ld_tx++;
-      if (ld_tx == ltc.ntx) { ld_tx = 0; ld_ty++; }
-      if (ld_ty == ltc.nty) { ld_ty = 0; ld_chunk++; }
-      if (ACC && ld_chunk == sk.nchunk && ld_c + 1 < p.ncls) {
-        ld_chunk = 0;
-        ld_c++;
-        ltc = p.cls[ld_c];
-        set_load_class();
-      }
-      ld_live = kk_next + 1 < T;
-    };
-    auto store_b = [&]() {
-#pragma unroll
-      for (int i = 0; i < NB; i++)
-#pragma unroll
-        for (int pl = 0; pl < NPL; pl++)
-          *reinterpret_cast<u32x4*>(Bh + pl * B_PLANE + swz((tid >> 2) + 64 * i, kq)) = rb[i][pl];
-    };
-    auto store_h = [&]() {
-#pragma unroll
-      for (int j = 0; j < NH; j++) {
-        const int hp = (tid >> 2) + 64 * j;
-        if (hp < HPmax) {
-#pragma unroll
-          for (int pl = 0; pl < NPL; pl++)
-            *reinterpret_cast<u32x4*>(Hh + pl * H_PLANE + hp * HPITCH + kq * 8) = rh[j][pl];
-        }
-      }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int j = 0; j < TN; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    int a_rd[TM];
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-      const int sidx = wm * WM + i * 32 + l31;
-      a_rd[i] = ((sidx >> TWL) * HC + (sidx & (TW - 1))) * HPITCH + lh * 8;
-    }
-
-    // tile 0 of the segment: its chunk's halo (whole, wherever in the chunk the range starts) and its weights
-    int ty = ld_ty, tx = ld_tx;                      // tap of the tile being multiplied, and its class's tap (0, 0) position
-    int c_hy0 = p.dstep > 0 ? 0 : ltc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : ltc.ntx - 1;
-#pragma unroll
-    for (int j = 0; j < NH; j++) load_h(j);
-#pragma unroll
-    for (int i = 0; i < NB; i++) load_b(i);
-    ld_advance(0);
-    store_h();
-    store_b();
-    __syncthreads();
-    constexpr int NGROUP = 2 * TM * NT;
-    constexpr int NPIECE = NB + NH;
-    constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
-#pragma unroll 1
-    for (int kk = 0; kk < T; kk++) {
-      const int tapoff = ((c_hy0 + ty * p.dstep) * HC + c_hx0 + tx * p.dstep) * HPITCH;
-      const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
-      auto piece = [&](int step) {
-        if (step < NB) load_b(step);
-        else if (step < NB + NH && new_chunk) load_h(step - NB);
-      };
-      if constexpr (BN == 128) {
-        s16x8 bv[2][TN][NPL], av[2][NPL];
-        auto read_b = [&](int slab) {
-#pragma unroll
-          for (int pl = 0; pl < NPL; pl++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-              bv[slab & 1][j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-        };
-        auto read_a = [&](int step) {
-          const int slab = step / TM, i = step % TM;
-#pragma unroll
-          for (int pl = 0; pl < NPL; pl++)
-            av[step & 1][pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
-        };
-        read_b(0);
-        read_a(0);
-#pragma unroll
-        for (int step = 0; step < 2 * TM; step++) {
-          const int slab = step / TM, i = step % TM;
-          if (step + 1 < 2 * TM) {
-            if ((step + 1) / TM != slab) read_b(slab + 1);
-            read_a(step + 1);
-          }
-#pragma unroll
-          for (int t2 = 0; t2 < NT; t2++) {
-#pragma unroll
-            for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
-#pragma unroll
-            for (int q = 0; q < PPG; q++) piece((step * NT + t2) * PPG + q);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int slab = 0; slab < 2; slab++) {
-          s16x8 bv[TN][NPL];
-#pragma unroll
-          for (int pl = 0; pl < NPL; pl++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-              bv[j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-#pragma unroll
-          for (int i = 0; i < TM; i++) {
-            s16x8 av[NPL];
-#pragma unroll
-            for (int pl = 0; pl < NPL; pl++)
-              av[pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
-#pragma unroll
-            for (int t2 = 0; t2 < NT; t2++) {
-#pragma unroll
-              for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av, bv[j], acc[i][j], t2);
-#pragma unroll
-              for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
-      }
-      __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
-      store_b();
-      if (new_chunk) store_h();
-      __syncthreads();
-      ty = ld_ty; tx = ld_tx;
-      c_hy0 = p.dstep > 0 ? 0 : ltc.nty - 1;
-      c_hx0 = p.dstep > 0 ? 0 : ltc.ntx - 1;
-      ld_advance(kk + 1);
-    }
-
-    if (k0 > 0) {
-      const int soff = wg * SLAB;
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; r4++) {
-            u32x4 v;
-            v.x = __float_as_uint(acc[i][j][4 * r4]); v.y = __float_as_uint(acc[i][j][4 * r4 + 1]);
-            v.z = __float_as_uint(acc[i][j][4 * r4 + 2]); v.w = __float_as_uint(acc[i][j][4 * r4 + 3]);
-            buf_st16_held<AUX_SC1>(v, slab_rs, slab_lane + (((i * TN + j) * 4 + r4) * 64) * 16, soff);
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(sk.flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    if (k1 < nk) {
-#pragma unroll 1
-      for (int w2 = wg + 1; w2 < sk.G; w2++) {
-        const unsigned pa = sk_pos(sk, w2);
-        if (pa >= item_end) break;
-        if (sk_pos(sk, w2 + 1) <= pa) continue;
-        if (threadIdx.x == 0) {
-          int spins = 0;
-          while (__hip_atomic_load(sk.flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > SK_SPIN_LIMIT) { atomicAdd(&g_sk_timeouts, 1); break; }
-          }
-        }
-        __syncthreads();
-        const int soff = w2 * SLAB;
-        u32x4 v[TM * TN * 4];
-#pragma unroll
-        for (int q = 0; q < TM * TN * 4; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(slab_rs, slab_lane + q * 64 * 16, soff, AUX_SC1);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-              const u32x4 t4 = v[(i * TN + j) * 4 + r4];
-              acc[i][j][4 * r4] += __uint_as_float(t4.x); acc[i][j][4 * r4 + 1] += __uint_as_float(t4.y);
-              acc[i][j][4 * r4 + 2] += __uint_as_float(t4.z); acc[i][j][4 * r4 + 3] += __uint_as_float(t4.w);
-            }
-      }
-    }
-    pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, 0);
-  }
-}
-
 }  // namespace
 
 namespace igemm {
@@ -777,7 +465,7 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
     smem_set = smem;
   }
   PlGatherParams q = p;
-  q.nsplit = 1; q.partial = nullptr; q.fused_splitk = 0; q.counters = nullptr;
+  q.nsplit = 1; q.partial = nullptr;
   SkPlan sk{};
   sk_plan_of(p, sk);
   if (!sk_fill(sk, unflow::options().streamk_groups)) return UNFLOW_ERR_UNSUPPORTED;
@@ -787,55 +475,6 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
   if (p.acc) igemm_pl_halo_sk_kernel<3, false, true><<<sk.G, 512, smem, st>>>(q, sk, hp);
   else igemm_pl_halo_sk_kernel<3, false, false><<<sk.G, 512, smem, st>>>(q, sk, hp);
   return launch_status();
-}
-
-static int sk4_blocks_per_cu(int bn) { (void)bn; return 2; }      // (the BN = 64 body needs 182 registers: two waves per SIMD)
-static int sk4_slab_bytes(int bn) { return bn == 128 ? 4 * 16 * 64 * 16 : 4 * 8 * 64 * 16; }
-
-static void sk4_plan_of(const GatherGeom& p, int bn, SkPlan& sk) {
-  sk_plan_of(p, sk);
-  sk.G = sk_workgroups() * sk4_blocks_per_cu(bn);
-  sk.nt = cdiv(p.N, bn);
-  sk.mtp = (int)((long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW));      // items are single tiles
-}
-
-bool pl_halo_sk4_ok(const GatherGeom& p, int npl, int bn) {
-  const int o = unflow::options().streamk4;
-  if (o <= 0 || npl != 3 || (bn != 128 && bn != 64) || (p.acc && p.dstep != 1)) return false;
-  if (pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, 3, pl_halo_pixels(p)) + 128 * 4 + 16 > (160 * 1024) / sk4_blocks_per_cu(bn)) return false;
-  SkPlan sk{};
-  sk4_plan_of(p, bn, sk);
-  if (!sk_fill(sk, unflow::options().streamk_groups)) return false;
-  if ((size_t)sk.G * sk4_slab_bytes(bn) + (size_t)sk.G * sizeof(int) + 256 > pl_halo_sk_ws_bytes()) return false;
-  return o >= 2 || sk.wall >= 16u * (unsigned)sk.G;
-}
-
-template <int BN, int WN>
-static int launch_sk4(const PlGatherParams& q, const SkPlan& sk, int hp, hipStream_t st) {
-  const int smem = pl_halo_main_bytes(BN, WN, 3, hp) + 128 * 4 + 16;
-  static int smem_set = 0;
-  if (smem > smem_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk4_kernel<BN, WN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk4_kernel<BN, WN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    smem_set = smem;
-  }
-  if (q.acc) igemm_pl_halo_sk4_kernel<BN, WN, true><<<sk.G, 256, smem, st>>>(q, sk, hp);
-  else igemm_pl_halo_sk4_kernel<BN, WN, false><<<sk.G, 256, smem, st>>>(q, sk, hp);
-  return launch_status();
-}
-
-int launch_pl_halo_sk4(const PlGatherParams& p, int bn, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (!ws || ws_bytes < pl_halo_sk_ws_bytes()) return UNFLOW_ERR_WORKSPACE;
-  PlGatherParams q = p;
-  q.nsplit = 1; q.partial = nullptr; q.fused_splitk = 0; q.counters = nullptr;
-  SkPlan sk{};
-  sk4_plan_of(p, bn, sk);
-  if (!sk_fill(sk, unflow::options().streamk_groups)) return UNFLOW_ERR_UNSUPPORTED;
-  sk.slabs = reinterpret_cast<float*>(ws);
-  sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)sk.G * sk4_slab_bytes(bn));
-  if (hipMemsetAsync(sk.flags, 0, (size_t)sk.G * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
-  const int hp = pl_halo_pixels(p);
-  return bn == 128 ? launch_sk4<128, 64>(q, sk, hp, st) : launch_sk4<64, 32>(q, sk, hp, st);
 }
 
 }  // namespace igemm

@@ -16,16 +16,11 @@
   X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
   X(conv1_direct, 1)      /* FlowNetC's first layer on its own kernel (conv_first.hip: rows staged once per tile, filter resident) */ \
   X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \
-  X(halo_pp, 0)           /* ping-pong pairing of the 128 x 128 halo kernel (two tiles per 512-thread workgroup) */                \
   X(streamk, 1)           /* persistent stream-K halo kernel (conv_streamk.hip): 1 where it pays, 2 wherever eligible, 0 off */     \
-  X(streamk4, 0)          /* ... its 4-wave form for the short-item halo layers: 1 where it pays, 2 wherever eligible, 0 off */     \
   X(streamk_groups, 8)    /* ... M groups of its item order (one per XCD); 1: tap class slowest over the whole launch */         \
   X(halo_max_split, 16)   /* split-K of the one-shot halo kernel: at most this many splits */                                      \
   X(halo_s2, 1)           /* halo kernel also for source-stride-2 layers (four accumulating parity classes) */            \
-  X(gather_cfg, -1)       /* force the tile config of the plain gather kernel for N <= 64 layers (1: 128 x 64, 2: 64 x 64) */   \
   X(xcd_swizzle, 1)       /* XCD-contiguous work order */                                                                 \
-  X(xcd_order, -1)        /* force work_decode order 0 / 1 / 2 (-1: per-kernel default) */                                \
-  X(fused_splitk, 0)      /* n > 0: in-kernel split-K reduction for tiles with up to n slices */                          \
   X(wgrad_dma, 1)         /* LDS-DMA filter-gradient kernel (0: register-staged) */                                       \
   X(wgrad_pp, 1)          /* ping-pong filter-gradient kernel (8 waves): 1 where it pays, 3 wherever eligible, 0 off */                                           \
   X(corr_nb, 1)           /* narrow-band correlation forward kernel */                                                    \

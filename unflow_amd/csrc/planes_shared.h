@@ -27,8 +27,6 @@ struct PlGatherParams : GatherGeom {
   int nsplit;
   int leaky, accumulate;
   float src_inv;               // 1 / (scale of the source planes x scale of the weight planes): applied to the finished sums
-  int* counters;               // fused split-K: one arrival counter per (class, M tile, N tile), zeroed before the launch
-  int fused_splitk;
   int vec_epi;                 // every row of dst / partial / act_src / output planes is 16-byte (planes: 8-byte) aligned, N % 4 == 0
   int tiles_y, tiles_x;        // halo kernel: 4 x 32-site tiles per image
   int xcd;                     // XCD-contiguous work order (xcd_remap + work_decode)
@@ -146,64 +144,7 @@ __device__ __forceinline__ void epi_store8(const PlGatherParams& p, size_t px, i
   store_planes8(p.pl, px, n, v0, v1);
 }
 
-// Split-K without a second kernel (tiles with few slices): after its partial tile is stored, a block takes a ticket on its
-// tile's counter; the block that draws nsplit - 1 (every slice of the tile is then in memory) sums the nsplit partial tiles
-// in slice order — the result does not depend on which block arrives last, and equals the separate reduce kernel's bit for
-// bit — and applies the epilogue.  Hand-off (cdna_hip_programming.md §5 / §6 G16, write-through form): partial tiles are
-// stored with sc1 (write-through) 16-byte buffer stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0 relaxed
-// agent-scope ticket; the last arriver reads the slabs with sc1 loads (served by L2 / fabric, never a stale L1 line).
-// No cache-wide fence: a release fence per block (buffer_wbl2) made every split launch ~40 us slower than the separate
-// reduce pass it was meant to replace.  Correct for any placement of a tile's slices over CUs / XCDs.  The counters are
-// zeroed by a memset node ahead of the launch.  Returns true in the block that has to reduce (all threads, after a barrier).
-__device__ __forceinline__ bool splitk_last_arriver(const PlGatherParams& p, int tile_id, int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  return *flag == p.nsplit - 1;
-}
-
 constexpr int AUX_SC1 = 16;    // cache-policy bits of the raw buffer intrinsics: sc1 = write-through store / L1-bypassing load
-
-// the last arriver's pass over its BM x BN tile: fixed-order sum of the partials + epilogue; EU float4 per thread in flight
-// per slice (a single block has to keep >= 8-16 loads per lane outstanding to read the slabs at a useful rate)
-template <int BM, int BN>
-__device__ __forceinline__ void splitk_tile_reduce(const PlGatherParams& p, const int* pix, int n0) {
-  constexpr int QPR = BN / 4;
-  constexpr int PER = BM * QPR / 256;              // float4 per thread: 16 / 8 / 4
-  constexpr int EU = PER < 4 ? PER : 4;
-  const size_t slab_f = (size_t)p.B * p.Hd * p.Wd * p.N;      // floats per split
-  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.partial, slab_f * 4 * (size_t)p.nsplit);
-  const int slab_b = (int)(slab_f * 4);
-#pragma unroll 1
-  for (int e0 = 0; e0 < PER; e0 += EU) {
-    int off[EU], px[EU], nn[EU];
-    float4 v[EU];
-#pragma unroll
-    for (int u = 0; u < EU; u++) {
-      const int e = threadIdx.x + 256 * (e0 + u);
-      const int row = e / QPR;
-      nn[u] = n0 + 4 * (e % QPR);
-      px[u] = pix[row];
-      const bool ok = px[u] >= 0 && nn[u] < p.N;
-      off[u] = ok ? (px[u] * p.N + nn[u]) * 4 : OOB_MARK;       // out of range: zeros, and the store below is skipped
-      if (!ok) px[u] = -1;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll 4
-    for (int s2 = 0; s2 < p.nsplit; s2++) {
-#pragma unroll
-      for (int u = 0; u < EU; u++) {
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], s2 * slab_b, AUX_SC1);
-        v[u].x += __uint_as_float(t.x); v[u].y += __uint_as_float(t.y);
-        v[u].z += __uint_as_float(t.z); v[u].w += __uint_as_float(t.w);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < EU; u++)
-      if (px[u] >= 0) epi_store4(p, (size_t)px[u], nn[u], v[u]);
-  }
-}
 
 // Epilogue shared by the gather kernels: bias / leaky-ReLU / accumulate / leaky derivative, fp32 result + output planes, or
 // the split-K partial.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -224,7 +165,6 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
     constexpr int QPR = WN / 4, RPI = 64 / QPR;
     float* stg = reinterpret_cast<float*>(smem16) + wid * (32 * EP);
     const size_t npix_d = (size_t)p.B * p.Hd * p.Wd;
-    const __amdgpu_buffer_rsrc_t part_rs = make_rsrc(p.partial, to_partial ? npix_d * p.N * 4 * (size_t)p.nsplit : 0);
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -254,16 +194,7 @@ __device__ __forceinline__ void pl_gather_epilogue(const PlGatherParams& p, f32x
         const int px = pix[wm * WM + i * 32 + rr];
         const int n = n0 + wn * WN + 4 * q;
         if (px < 0 || n >= p.N) continue;
-        {
-          float* dp = p.partial + ((size_t)split * npix_d + px) * p.N + n;
-          if (p.fused_splitk) {   // write-through: the last arriver of the tile reads it from L2 / fabric (splitk_last_arriver)
-            u32x4 t;
-            t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-            buf_st16_held<AUX_SC1>(t, part_rs, (int)(((size_t)px * p.N + n) * 4), split * (int)(npix_d * p.N * 4));
-          } else {
-            *reinterpret_cast<float4*>(dp) = v;
-          }
-        }
+        *reinterpret_cast<float4*>(p.partial + ((size_t)split * npix_d + px) * p.N + n) = v;
       }
     }
     return;
@@ -323,8 +254,5 @@ inline int pl_halo_pixels(const GatherGeom& p) {
 bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn);      // eligible and expected to pay (option streamk)
 size_t pl_halo_sk_ws_bytes();                                   // slabs + arrival flags
 int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st);      // p.tiles_y / tiles_x set
-// ... and its 4-wave form (two / three workgroups per CU, one 128-site tile each): the short-item layers
-bool pl_halo_sk4_ok(const GatherGeom& p, int npl, int bn);
-int launch_pl_halo_sk4(const PlGatherParams& p, int bn, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace igemm
