@@ -95,7 +95,7 @@ def main():
     # forward_warp (ops/forward_warp_op.cu.cc:16-125): 12 B/px forward (flow in, splat sum out), 20 B/px backward; the work is
     # the <= 81 taps per source pixel, not the bytes — the HBM fraction is reported all the same (DESIGN.md has the tap-rate bound)
     fw_out = torch.empty(N, H, W, 1, device=dev)
-    fw_ws = torch.empty(npx * 2, dtype=torch.float32, device=dev)       # 64-bit fixed-point sums of the deterministic mode
+    fw_ws = torch.empty(lib.unflow_forward_warp_workspace_bytes(N, H, W, 1) // 4 + 64, dtype=torch.float32, device=dev)   # 64-bit sums + the far-source bins
     flow_50 = (torch.rand(N, H, W, 2, generator=g) * 100 - 50).to(dev)
     for nm, fl in (("smooth field, sigma 4 px", flow), ("i.i.d. N(0,4^2)", flow_iid), ("i.i.d. U(-50,50) px", flow_50)):
         for det in (1, 0):

@@ -127,8 +127,12 @@ int unflow_image_warp_bwd(const float* dout, const float* im, int ld_im, const f
                           int C, unflow_stream_t stream);
 
 /* ops/forward_warp_op.cu.cc:16-65.  deterministic == 0: float-atomic scatter like the reference
- * (summation order varies run to run).  deterministic != 0: the same scatter accumulated in 2^40-scaled
- * 64-bit integers (order-independent, bit-reproducible); needs workspace >= 8*B*H*W bytes. */
+ * (summation order varies run to run).  deterministic != 0: the same scatter accumulated in 2^31-scaled
+ * 64-bit integers (order-independent, bit-reproducible); needs workspace >= 8*B*H*W bytes.
+ * With workspace >= unflow_forward_warp_workspace_bytes (either mode) sources whose 9 x 9 footprint leaves their
+ * tile's LDS window are binned by target tile and gathered without global atomics (flows of tens of pixels: 10x faster);
+ * with less, the same sums are formed with global atomics. */
+size_t unflow_forward_warp_workspace_bytes(int B, int H, int W, int deterministic);
 int unflow_forward_warp_fwd(const float* flows, float* out, int B, int H, int W, int deterministic,
                             void* workspace, size_t workspace_bytes, unflow_stream_t stream);
 int unflow_forward_warp_bwd(const float* dout, const float* flows, float* dflows, int B, int H, int W,

@@ -189,6 +189,44 @@ def test_forward_warp_vs_oracle(kind, dev, oracle_lib):
     close(tfl.grad, oracle_lib.forward_warp_grad(go, fl), 1e-5)
 
 
+@pytest.mark.parametrize("field", ["torn", "mixed"])
+def test_forward_warp_far_sources_binned_by_target_tile(field, dev, oracle_lib):
+    """Flows of tens of pixels tear a source tile apart: most footprints leave the tile's LDS window.  With the full workspace
+    (unflow_forward_warp_workspace_bytes) such sources are binned by 32 x 32 target tile and gathered without global atomics;
+    with the minimum workspace their taps are global atomics.  Both must give the oracle's sums; in deterministic mode the two
+    paths must agree BIT FOR BIT (the same fixed-point terms, integer sums) and be stable run to run."""
+    import ctypes
+    from unflow_amd import _lib, ops
+    from unflow_amd._lib import check, ptr, stream
+    rs = np.random.RandomState(29)
+    B, H, W = 3, 100, 170                                   # ragged against the 64 x 16 source tiles and the 32 x 32 target tiles
+    if field == "torn":
+        fl = (rs.rand(B, H, W, 2) * 100 - 50).astype(np.float32)
+    else:                                                   # a coherent field with a fifth of the pixels flung far away
+        fl = (rs.randn(B, H, W, 2) * 1.5 + np.array([6.0, -3.0])).astype(np.float32)
+        far = rs.rand(B, H, W) < 0.2
+        fl[far] += (rs.rand(int(far.sum()), 2) * 160 - 80).astype(np.float32)
+    ref = oracle_lib.forward_warp(fl)
+    tfl = t(fl, dev)
+    lib = _lib.lib()
+    npx = B * H * W
+    full = lib.unflow_forward_warp_workspace_bytes(B, H, W, 1)
+    assert full > 8 * npx
+    outs = {}
+    for det in (1, 0):
+        for name, nbytes in (("binned", full), ("atomics", 8 * npx)):
+            ws = torch.empty(nbytes // 4 + 16, dtype=torch.float32, device=dev)
+            out = torch.full((B, H, W, 1), 7.0, device=dev)
+            for rep in range(3):
+                check(lib.unflow_forward_warp_fwd(ptr(tfl), ptr(out), B, H, W, det, ptr(ws), _lib.csz(nbytes), stream()), "forward_warp")
+                close(out, ref, 1e-5)
+                if det:
+                    assert torch.equal(out, outs.setdefault((det, name), out.clone())), (name, rep)      # bit-reproducible
+    assert torch.equal(outs[(1, "binned")], outs[(1, "atomics")])
+    # the autograd op takes the binned path
+    assert torch.equal(ops.forward_warp(tfl, deterministic=True), outs[(1, "binned")])
+
+
 @pytest.mark.parametrize("scale", [2, 4])
 def test_downsample_vs_oracle(scale, dev, oracle_lib):
     from unflow_amd import ops

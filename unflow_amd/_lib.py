@@ -43,6 +43,7 @@ def lib():
         _lib.unflow_conv_workspace_bytes.restype = ctypes.c_size_t
         _lib.unflow_conv_pl_workspace_bytes.restype = ctypes.c_size_t
         _lib.unflow_weight_planes_elems.restype = ctypes.c_size_t
+        _lib.unflow_forward_warp_workspace_bytes.restype = ctypes.c_size_t
         _lib.unflow_option_names.restype = ctypes.c_char_p
         _apply_env_options(_lib)
     return _lib

@@ -933,7 +933,7 @@ class FlowNetEngine:
                 if need_fwarp:      # forward_warp(flow*scale) (losses.py:28-29), deterministic accumulation
                     check(lib.unflow_scale(ptr(flow), cf(fs), ptr(lv['fscaled']), cl(flow.numel()), st), "scale")
                     fwm = lv['fwmap']
-                    ws = workspace(8 * N * h * w, self.dev, slot=2)
+                    ws = workspace(lib.unflow_forward_warp_workspace_bytes(N, h, w, 1), self.dev, slot=2)
                     check(lib.unflow_forward_warp_fwd(ptr(lv['fscaled']), ptr(fwm), N, h, w, 1, ptr(ws),
                                                       _lib.csz(ws.numel() * 4), st), "forward_warp")
                 a = acc() if (with_grad and wt('fb')) else 0

@@ -396,12 +396,34 @@ constexpr int FW_SPT = FW_TX * FW_TY / 256;           // sources per thread
 constexpr float FW_Q = 2147483648.f;                  // 2^31
 constexpr double FW_QINV = 1.0 / 2147483648.0;
 
-template <bool DET>
+// FAR: a source whose footprint does not lie inside the window as a whole is not scattered here at all — its linear index goes
+// to `far_list` (one global atomic per tile reserves the slots) and the binned gather below takes it; without FAR (no
+// workspace for the bins) its out-of-window taps take the global atomics directly, as before.
+constexpr int FB_T = 32;                              // target tile edge of the far path (>= 9: a footprint touches at most 2 x 2 tiles)
+constexpr int FB_MAP = 16;                            // a source tile's far sources are counted in an LDS map of 16 x 16 target tiles first
+
+// target tiles (<= 2 x 2) of a footprint -> callback(global tile index, index in the workgroup's map or -1)
+template <typename F>
+__device__ __forceinline__ void fb_tiles(const FwFoot& f, int b, int tt_x, int tt_y, int m0x, int m0y, F&& cb) {
+  const int tx0 = f.x_lo / FB_T, tx1 = f.x_hi / FB_T, ty0 = f.y_lo / FB_T, ty1 = f.y_hi / FB_T;
+  for (int ty = ty0; ty <= ty1; ty++)
+    for (int tx = tx0; tx <= tx1; tx++) {
+      const int rx = tx - m0x, ry = ty - m0y;
+      const bool in = (unsigned)rx < (unsigned)FB_MAP && (unsigned)ry < (unsigned)FB_MAP;
+      cb((b * tt_y + ty) * tt_x + tx, in ? ry * FB_MAP + rx : -1);
+    }
+}
+
+template <bool DET, bool FAR>
 __global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __restrict__ flow, unsigned long long* __restrict__ acc,
                                                                 float* __restrict__ outf, int B, int H, int W, int tiles_x,
-                                                                int tiles_y) {
+                                                                int tiles_y, int* __restrict__ far_count, int* __restrict__ far_list,
+                                                                int* __restrict__ bin_cnt, int4* __restrict__ tile_far, int tt_x, int tt_y) {
   __shared__ unsigned long long win[FW_WX * FW_WY];
   __shared__ int s_org[3];
+  __shared__ int s_far[FAR ? FW_TX * FW_TY : 1];
+  __shared__ int s_map[FAR ? FB_MAP * FB_MAP : 1];      // far sources per target tile around this source tile's window
+  __shared__ int s_nfar, s_base;
   const int tid = threadIdx.x;
   const int ntiles = B * tiles_y * tiles_x;
   for (int tile = (int)xcd_block(); tile < ntiles; tile += gridDim.x) {
@@ -410,6 +432,8 @@ __global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __r
     const int tyi = t % tiles_y;
     const int b = t / tiles_y;
     if (tid < 3) s_org[tid] = 0;
+    if (FAR && tid == 0) s_nfar = 0;
+    if (FAR) s_map[tid] = 0;
     for (int e = tid; e < FW_WX * FW_WY; e += 256) win[e] = 0ull;
     __syncthreads();
     // the thread's sources: (x, y + 4 k)
@@ -441,19 +465,33 @@ __global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __r
     if ((tid & 63) == 0) { atomicAdd(&s_org[0], mx); atomicAdd(&s_org[1], my); atomicAdd(&s_org[2], mc); }
     __syncthreads();
     const int cnt = s_org[2];
-    if (cnt == 0) { __syncthreads(); continue; }       // no source of this tile reaches the image
+    if (cnt == 0) {                                    // no source of this tile reaches the image (uniform: nothing to flush)
+      if (FAR && tid == 0) tile_far[tile] = make_int4(0, 0, 0, 0);
+      __syncthreads();
+      continue;
+    }
     const int wx0 = s_org[0] / (2 * cnt) - FW_WX / 2, wy0 = s_org[1] / (2 * cnt) - FW_WY / 2;
+    // origin of the 16 x 16 target-tile map: centred on the window (floor division: the window may start left of / above the image)
+    const int m0x = ((wx0 + FW_WX / 2) >> 5) - FB_MAP / 2, m0y = ((wy0 + FW_WY / 2) >> 5) - FB_MAP / 2;
 #pragma unroll 1
     for (int k = 0; k < FW_SPT; k++) {
       const FwFoot f = foot(k);                 // (the flow is read a second time: L2 / L1 hit)
       if (!f.ok) continue;
+      const int lx0 = f.x_lo - wx0, ly0 = f.y_lo - wy0;
+      if (FAR && !(lx0 >= 0 && f.x_hi - wx0 < FW_WX && ly0 >= 0 && f.y_hi - wy0 < FW_WY)) {
+        s_far[atomicAdd(&s_nfar, 1)] = (int)(img + (long)(sy0 + 4 * k) * W + sx);      // the binned gather takes the whole source
+        fb_tiles(f, b, tt_x, tt_y, m0x, m0y, [&](int gt, int mi) {
+          if (mi >= 0) atomicAdd(&s_map[mi], 1);       // counted per workgroup first: ~30 global atomics per source tile, not ~1300
+          else atomicAdd(bin_cnt + gt, 1);
+        });
+        continue;
+      }
       float wxv[9];
 #pragma unroll
       for (int j = 0; j < 9; j++) {
         const float dx = (float)(f.x_lo + j) - f.tx;
         wxv[j] = expf(-(dx * dx) / 2.0f);
       }
-      const int lx0 = f.x_lo - wx0, ly0 = f.y_lo - wy0;
       if (f.x_hi - f.x_lo == 8 && f.y_hi - f.y_lo == 8 && lx0 >= 0 && lx0 + 8 < FW_WX && ly0 >= 0 && ly0 + 8 < FW_WY) {
         // the common case — a whole 9 x 9 footprint inside the window: no per-tap tests, constant LDS offsets
         unsigned long long* base = win + ly0 * FW_WX + lx0;
@@ -492,6 +530,22 @@ __global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __r
       }
     }
     __syncthreads();
+    if (FAR) {
+      const int nf = s_nfar;
+      if (nf > 0) {
+        if (tid == 0) s_base = atomicAdd(far_count, nf);
+        const int c = s_map[tid];
+        if (c > 0) {
+          const int ty = m0y + tid / FB_MAP, tx = m0x + tid % FB_MAP;      // (inside the image: footprints are clipped to it)
+          atomicAdd(bin_cnt + (b * tt_y + ty) * tt_x + tx, c);
+        }
+        __syncthreads();
+        for (int e = tid; e < nf; e += 256) far_list[s_base + e] = s_far[e];
+        if (tid == 0) tile_far[tile] = make_int4(s_base, nf, m0x, m0y);
+      } else if (tid == 0) {
+        tile_far[tile] = make_int4(0, 0, 0, 0);
+      }
+    }
     for (int e = tid; e < FW_WX * FW_WY; e += 256) {
       const unsigned long long v = win[e];
       if (v == 0ull) continue;
@@ -499,6 +553,136 @@ __global__ __launch_bounds__(256) void forward_warp_tile_kernel(const float* __r
       const long g = img + (long)(wy0 + ly) * W + (wx0 + lx);      // inside the image: every tap was clipped to it
       if (DET) atomicAdd(acc + g, v);
       else atomicAdd(outf + g, (float)((double)v * FW_QINV));
+    }
+    __syncthreads();
+  }
+}
+
+// ---- far sources: counting sort by TARGET tile, then a gather without global atomics ----------------------------------------
+// A field that tears a source tile apart (|flow| of tens of pixels, uncorrelated) leaves most footprints outside the tile's
+// window; as global atomics those taps cost 81 memory-side read-modify-writes per source (22 ms at 16 x 768 x 1024, U(-50, 50)).
+// Instead: (1) the tile kernel lists such sources and (2) counts them into the 32 x 32-pixel TARGET tiles their footprints touch
+// (<= 2 x 2: a footprint is 9 pixels wide) — per workgroup in an LDS map of 16 x 16 tiles first, (3) an exclusive scan turns the
+// counts into bin offsets, (4) the sources are written into their bins, (5) one workgroup per target tile sums the taps of its bin's sources that fall inside the
+// tile in LDS (64-bit fixed point, as above) and adds the tile to the output with plain stores — every pixel has one owner, and
+// integer sums do not depend on the order of a bin's entries: bit-reproducible like the window path.  Everything is sized and
+// looped from device-side counts: no host synchronisation, graph-capturable.
+__device__ __forceinline__ FwFoot fw_foot_of(const float* __restrict__ flow, int src, int H, int W) {
+  const int x = src % W, y = (src / W) % H;
+  const float2 fl = reinterpret_cast<const float2*>(flow)[src];
+  return fw_footprint(x, y, fl.x, fl.y, W, H);
+}
+
+// (4) one workgroup per SOURCE tile writes its far sources into their bins: the (source, target tile) pairs are counted in the
+// LDS map again, each touched bin's range is reserved with ONE global atomic on its cursor, and the pairs take consecutive
+// slots of that range.  The order of a bin's entries varies run to run; the integer sums of the gather do not.
+__global__ __launch_bounds__(256) void forward_warp_fill_kernel(const float* __restrict__ flow, const int* __restrict__ far_list,
+                                                                const int4* __restrict__ tile_far, int* __restrict__ cursor,
+                                                                const int* __restrict__ off, int* __restrict__ entries, int H, int W,
+                                                                int tt_x, int tt_y, int ntiles, int tiles_per_image) {
+  __shared__ int s_map[FB_MAP * FB_MAP], s_res[FB_MAP * FB_MAP];
+  for (int tile = (int)xcd_block(); tile < ntiles; tile += gridDim.x) {
+    const int4 tf = tile_far[tile];
+    const int base = tf.x, nf = tf.y, m0x = tf.z, m0y = tf.w;
+    if (nf == 0) continue;                              // (uniform)
+    const int b = tile / tiles_per_image;
+    s_map[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nf; e += 256) {
+      const FwFoot f = fw_foot_of(flow, far_list[base + e], H, W);
+      fb_tiles(f, b, tt_x, tt_y, m0x, m0y, [&](int gt, int mi) { if (mi >= 0) atomicAdd(&s_map[mi], 1); });
+    }
+    __syncthreads();
+    {
+      const int c = s_map[threadIdx.x];
+      if (c > 0) {
+        const int gt = (b * tt_y + m0y + threadIdx.x / FB_MAP) * tt_x + m0x + threadIdx.x % FB_MAP;
+        s_res[threadIdx.x] = off[gt] + atomicAdd(cursor + gt, c);
+      }
+      s_map[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nf; e += 256) {
+      const int src = far_list[base + e];
+      const FwFoot f = fw_foot_of(flow, src, H, W);
+      fb_tiles(f, b, tt_x, tt_y, m0x, m0y, [&](int gt, int mi) {
+        const int slot = mi >= 0 ? s_res[mi] + atomicAdd(&s_map[mi], 1) : off[gt] + atomicAdd(cursor + gt, 1);
+        entries[slot] = src;
+      });
+    }
+    __syncthreads();
+  }
+}
+
+// exclusive scan of the bin counts (one workgroup); leaves the counts zeroed for their second life as cursors
+__global__ __launch_bounds__(1024) void forward_warp_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int ntt) {
+  __shared__ int part[1024];
+  const int per = (ntt + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(ntt, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; i++) s += cnt[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int i = lo; i < hi; i++) {
+    const int c = cnt[i];
+    off[i] = run;
+    run += c;
+    cnt[i] = 0;
+  }
+  if (threadIdx.x == 1023) off[ntt] = part[1023];
+}
+
+template <bool DET>
+__global__ __launch_bounds__(256) void forward_warp_gather_kernel(const float* __restrict__ flow, const int* __restrict__ off,
+                                                                  const int* __restrict__ entries, unsigned long long* __restrict__ acc,
+                                                                  float* __restrict__ outf, int H, int W, int tt_x, int tt_y, int ntt) {
+  __shared__ unsigned long long win[FB_T * FB_T];
+  for (int t = (int)xcd_block(); t < ntt; t += gridDim.x) {
+    const int e0 = off[t], e1 = off[t + 1];
+    if (e0 == e1) continue;                            // (uniform)
+    for (int e = threadIdx.x; e < FB_T * FB_T; e += 256) win[e] = 0ull;
+    __syncthreads();
+    const int tx = t % tt_x, ty = (t / tt_x) % tt_y, b = t / (tt_x * tt_y);
+    const int X0 = tx * FB_T, Y0 = ty * FB_T;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+      const FwFoot f = fw_foot_of(flow, entries[e], H, W);
+      float wxv[9];                                    // separable weights, the same two expf per tap as the window path: same bits
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const float dx = (float)(f.x_lo + j) - f.tx;
+        wxv[j] = expf(-(dx * dx) / 2.0f);
+      }
+      const int lx0 = f.x_lo - X0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int ny = f.y_lo + i;
+        if (ny > f.y_hi || ny < Y0 || ny >= Y0 + FB_T) continue;
+        const float dy = (float)ny - f.ty;
+        const float wy = expf(-(dy * dy) / 2.0f);
+        unsigned long long* row = win + (ny - Y0) * FB_T + lx0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+          const int nx = f.x_lo + j;
+          if (nx > f.x_hi || nx < X0 || nx >= X0 + FB_T) continue;
+          atomicAdd(row + j, (unsigned long long)(unsigned)(wy * wxv[j] * FW_Q + 0.5f));
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < FB_T * FB_T; e += 256) {
+      const unsigned long long v = win[e];
+      const int y = Y0 + e / FB_T, x = X0 + e % FB_T;
+      if (v == 0ull || y >= H || x >= W) continue;
+      const long gidx = ((long)b * H + y) * W + x;
+      if (DET) acc[gidx] += v;                         // this pixel's only writer in this launch; the tile kernel's atomics are done
+      else outf[gidx] += (float)((double)v * FW_QINV);
     }
     __syncthreads();
   }
@@ -559,27 +743,82 @@ __global__ void forward_warp_ranges_kernel(const float* __restrict__ flow, int* 
   }
 }
 
+// workspace layout: [64-bit sums, deterministic only][far count (64 B)][bin counts / cursors][bin offsets + 1][per source tile: list
+// range + map origin][far list][bin entries]
+struct FwWs {
+  size_t acc, count, cnt, off, tfar, list, entries, total;
+  int tt_x, tt_y, ntt;
+};
+static FwWs fw_ws_layout(int B, int H, int W, int deterministic) {
+  FwWs w{};
+  const size_t npx = (size_t)B * H * W;
+  w.tt_x = cdiv(W, FB_T); w.tt_y = cdiv(H, FB_T); w.ntt = B * w.tt_x * w.tt_y;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t o = 0;
+  w.acc = o; o += deterministic ? al(sizeof(unsigned long long) * npx) : 0;
+  w.count = o; o += 256;
+  w.cnt = o; o += al(sizeof(int) * (size_t)w.ntt);
+  w.off = o; o += al(sizeof(int) * ((size_t)w.ntt + 1));
+  w.tfar = o; o += al(sizeof(int4) * (size_t)B * cdiv(H, FW_TY) * cdiv(W, FW_TX));
+  w.list = o; o += al(sizeof(int) * npx);
+  w.entries = o; o += al(sizeof(int) * 4 * npx);       // a footprint touches at most 2 x 2 target tiles
+  w.total = o;
+  return w;
+}
+
+UNFLOW_API size_t unflow_forward_warp_workspace_bytes(int B, int H, int W, int deterministic) {
+  if (B <= 0 || H <= 0 || W <= 0 || (long)B * H * W >= (1L << 31)) return 0;
+  return fw_ws_layout(B, H, W, deterministic).total;
+}
+
 UNFLOW_API int unflow_forward_warp_fwd(const float* flows, float* out, int B, int H, int W, int deterministic,
                                        void* workspace, size_t workspace_bytes, unflow_stream_t stream) {
   if (!flows || !out) return UNFLOW_ERR_NULL;
   if (B < 0 || H < 0 || W < 0) return UNFLOW_ERR_SHAPE;
   const long npx = (long)B * H * W;
   if (npx == 0) return UNFLOW_OK;
+  if (npx >= (1L << 31)) return UNFLOW_ERR_UNSUPPORTED;
   const int tiles_x = cdiv(W, FW_TX), tiles_y = cdiv(H, FW_TY);
   const int ntiles = B * tiles_y * tiles_x;
   const int grid = ntiles < 2048 ? ntiles : 2048;
+  hipStream_t st = as_stream(stream);
   if (deterministic) {
     if (!workspace) return UNFLOW_ERR_NULL;
     if (workspace_bytes < sizeof(unsigned long long) * (size_t)npx) return UNFLOW_ERR_WORKSPACE;
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace);
-    if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * npx, as_stream(stream)) != hipSuccess)
-      return UNFLOW_ERR_LAUNCH;
-    forward_warp_tile_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(flows, acc, nullptr, B, H, W, tiles_x, tiles_y);
-    forward_warp_fixed_to_float_kernel<<<stream_grid(npx), 256, 0, as_stream(stream)>>>(acc, out, npx);
-  } else {
-    if (hipMemsetAsync(out, 0, sizeof(float) * npx, as_stream(stream)) != hipSuccess) return UNFLOW_ERR_LAUNCH;
-    forward_warp_tile_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(flows, nullptr, out, B, H, W, tiles_x, tiles_y);
   }
+  // With the full workspace (unflow_forward_warp_workspace_bytes) far sources go through the binned gather; with the minimum
+  // (8 bytes per pixel, deterministic; none otherwise) their taps are global atomics — same result, slower on torn fields.
+  const FwWs w = fw_ws_layout(B, H, W, deterministic);
+  const bool far = workspace && workspace_bytes >= w.total;
+  char* base = reinterpret_cast<char*>(workspace);
+  unsigned long long* acc = deterministic ? reinterpret_cast<unsigned long long*>(base + w.acc) : nullptr;
+  int* far_count = far ? reinterpret_cast<int*>(base + w.count) : nullptr;
+  int* cnt = far ? reinterpret_cast<int*>(base + w.cnt) : nullptr;
+  int* off = far ? reinterpret_cast<int*>(base + w.off) : nullptr;
+  int* far_list = far ? reinterpret_cast<int*>(base + w.list) : nullptr;
+  int4* tile_far = far ? reinterpret_cast<int4*>(base + w.tfar) : nullptr;
+  int* entries = far ? reinterpret_cast<int*>(base + w.entries) : nullptr;
+  if (deterministic) {
+    if (hipMemsetAsync(acc, 0, sizeof(unsigned long long) * npx, st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  } else {
+    if (hipMemsetAsync(out, 0, sizeof(float) * npx, st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  }
+  if (far && hipMemsetAsync(base + w.count, 0, (w.off - w.count), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;      // far count + bin counts
+  if (deterministic) {
+    if (far) forward_warp_tile_kernel<true, true><<<grid, 256, 0, st>>>(flows, acc, nullptr, B, H, W, tiles_x, tiles_y, far_count, far_list, cnt, tile_far, w.tt_x, w.tt_y);
+    else forward_warp_tile_kernel<true, false><<<grid, 256, 0, st>>>(flows, acc, nullptr, B, H, W, tiles_x, tiles_y, nullptr, nullptr, nullptr, nullptr, 0, 0);
+  } else {
+    if (far) forward_warp_tile_kernel<false, true><<<grid, 256, 0, st>>>(flows, nullptr, out, B, H, W, tiles_x, tiles_y, far_count, far_list, cnt, tile_far, w.tt_x, w.tt_y);
+    else forward_warp_tile_kernel<false, false><<<grid, 256, 0, st>>>(flows, nullptr, out, B, H, W, tiles_x, tiles_y, nullptr, nullptr, nullptr, nullptr, 0, 0);
+  }
+  if (far) {
+    forward_warp_scan_kernel<<<1, 1024, 0, st>>>(cnt, off, w.ntt);
+    forward_warp_fill_kernel<<<grid, 256, 0, st>>>(flows, far_list, tile_far, cnt, off, entries, H, W, w.tt_x, w.tt_y, ntiles, tiles_y * tiles_x);
+    const int ggrid = w.ntt < 4096 ? w.ntt : 4096;
+    if (deterministic) forward_warp_gather_kernel<true><<<ggrid, 256, 0, st>>>(flows, off, entries, acc, nullptr, H, W, w.tt_x, w.tt_y, w.ntt);
+    else forward_warp_gather_kernel<false><<<ggrid, 256, 0, st>>>(flows, off, entries, nullptr, out, H, W, w.tt_x, w.tt_y, w.ntt);
+  }
+  if (deterministic) forward_warp_fixed_to_float_kernel<<<stream_grid(npx), 256, 0, st>>>(acc, out, npx);
   return launch_status();
 }
 

@@ -169,7 +169,8 @@ class _ForwardWarp(torch.autograd.Function):
             raise ValueError("flows must have 2 channels")
         ctx.save_for_backward(flows)
         out = torch.empty((B, H, W, 1), dtype=torch.float32, device=flows.device)
-        ws = workspace(8 * B * H * W, flows.device) if deterministic else None
+        # full workspace: far-flung sources are binned by target tile instead of scattered with global atomics (either mode)
+        ws = workspace(_lib.lib().unflow_forward_warp_workspace_bytes(B, H, W, int(bool(deterministic))), flows.device)
         check(_lib.lib().unflow_forward_warp_fwd(ptr(flows), ptr(out), B, H, W, int(bool(deterministic)), ptr(ws),
                                                  _lib.csz(0 if ws is None else ws.numel() * 4), stream()),
               "forward_warp")
