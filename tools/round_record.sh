@@ -16,10 +16,8 @@ head -5 gpurun_out/rec_bench_kernel_stats.csv | cut -c1-160
 PMC_TIMEOUT=150 bash tools/pmc_run.sh gpurun_out/rec_pmc "FETCH_SIZE" "WRITE_SIZE"
 python tools/pmc_traffic.py gpurun_out/rec_pmc/pass1 gpurun_out/rec_pmc/pass2 > gpurun_out/rec_pmc_traffic.json 2> gpurun_out/rec_pmc_traffic.err; head -c 300 gpurun_out/rec_pmc_traffic.json; grep -A4 conv_family gpurun_out/rec_pmc_traffic.json
 ( RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 UNFLOW_FORCE_REDUCER=1 timeout 600 python bench.py --gpus 1 --no-secondary --no-cpu-baseline --no-alt --no-parity --no-roofline > gpurun_out/rec_comm_record_forced_world1.json 2> gpurun_out/rec_comm.err )
-# two ranks on the ONE GPU of the box (RCCL refuses that: gloo transport, same host code / streams / buckets)
-for r in 1 0; do
-  ( RANK=$r WORLD_SIZE=2 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29521 UNFLOW_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-alt --no-parity --no-roofline > gpurun_out/rec_2ranks_rank$r.out 2> gpurun_out/rec_2ranks_rank$r.err ) &
-done
-wait
-grep '^{"metric"' gpurun_out/rec_2ranks_rank0.out > gpurun_out/rec_bench_2ranks_gloo_one_gpu.json; tail -c 700 gpurun_out/rec_bench_2ranks_gloo_one_gpu.json
+# two ranks on the ONE GPU of the box, started by bench.py itself (no launcher around it: the command shape the driver uses);
+# RCCL refuses two ranks on one device: gloo transport, same host code / streams / buckets
+( UNFLOW_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-alt --no-parity --no-roofline > gpurun_out/rec_2ranks.out 2> gpurun_out/rec_2ranks.err )
+grep '^{"metric"' gpurun_out/rec_2ranks.out > gpurun_out/rec_bench_2ranks_gloo_one_gpu.json; tail -c 700 gpurun_out/rec_bench_2ranks_gloo_one_gpu.json
 rm -rf gpurun_out/rec_prof gpurun_out/rec_pmc/pass*/ 2>/dev/null; ls gpurun_out | head -30
