@@ -240,3 +240,23 @@ def test_part_buckets_and_frozen_ranges_partition_the_parameters(spec, extra, cu
             for l in st.layers:
                 inside = lo <= (l.dw.data_ptr() - eng.G.data_ptr()) // 4 < hi
                 assert inside == (l.name in names), (k, l.name)
+
+
+def test_bench_self_launch_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` with no launcher around it starts its own ranks (bench.py::self_launch); on a box with fewer
+    GPUs than ranks every rank must refuse loudly and the command must fail — not hang, not fall back to fewer ranks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs here: the refusal path does not apply")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                               "UNFLOW_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 visible GPUs" in (r.stdout + r.stderr)
+    assert '{"metric"' not in r.stdout
