@@ -299,14 +299,6 @@ inline int build_conv_dgrad(GatherGeom& p, int B, int H, int W, int Cin, int Cou
     if (nty == 0 || ntx == 0) return UNFLOW_ERR_UNSUPPORTED;
     p.cls[c] = TapClass{nty, ntx, (py + pt - ky0) / 2, (px + pl - kx0) / 2, ky0, kx0, py, px};
   }
-  // Longest class first.  One-class-per-workgroup launches walk the classes in this order (work_decode: class slower than the
-  // tiles), and a launch of 1.5 rounds of resident workgroups ends when its last-started blocks end: 5 x 5 stride 2 has 4 / 6 / 6 / 9
-  // taps by parity — with the 9-tap class LAST conv3's data gradient (768 blocks on 512 slots) ran 120 tap-units for 75 of work.
-  // A class names its own output parity (py, px), so the order is free.
-  for (int i = 1; i < 4; i++)
-    for (int j = i; j > 0 && p.cls[j].nty * p.cls[j].ntx > p.cls[j - 1].nty * p.cls[j - 1].ntx; j--) {
-      const TapClass t = p.cls[j]; p.cls[j] = p.cls[j - 1]; p.cls[j - 1] = t;
-    }
   return UNFLOW_OK;
 }
 
