@@ -32,7 +32,12 @@ def timeit(fn, reps=20):
     return ts[len(ts) // 2] * 1e3   # us
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""      # print only the rows whose name contains this (every row is still measured)
+
+
 def report(name, nbytes, us, extra=None):
+    if ONLY and ONLY not in name:
+        return
     gbs = nbytes / us / 1e3
     out = {"op": name, "algorithmic_MB": round(nbytes / 1e6, 1), "us": round(us, 1), "GB/s": round(gbs, 1),
            "frac_of_8TBs": round(gbs / HBM_PEAK, 3)}

@@ -439,6 +439,21 @@ CORR_PL_CASES = [
 CORR_RW_CASES = [c for c in CORR_PL_CASES if c[1] in (128, 256) and not (c[4]['max_displacement'] // c[4]['stride_2'] <= 6 and c[3] / c[4]['stride_2'] > 32)]
 
 
+# the cases the row-shared narrow-band kernel takes by default (stride_2 = 1, r <= 4, several site tiles, C % 32 == 0); with
+# corr_rs = 0 they run on corr_fwd_nb_kernel (C % 64 == 0) or the streaming kernel
+CORR_RS_CASES = [c for c in CORR_PL_CASES if c[4]['stride_2'] == 1 and c[4]['max_displacement'] <= 4 and c[3] > 32 and c[1] % 32 == 0]
+
+
+@pytest.mark.parametrize("case", CORR_RS_CASES + [(4, 256, 21, 200, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),
+                                                   (2, 96, 10, 77, dict(kernel_size=1, max_displacement=3, pad=3, stride_1=1, stride_2=1))])
+def test_correlation_planes_fwd_row_shared_and_narrow_band_kernels_vs_oracle(case, dev, oracle_lib, lib_option):
+    """The +-4 / 81-channel cost volume (and r = 2, 3): the row-shared kernel (default; incl. row groups of 4 with a ragged last
+    group, 9 site tiles, C = 96: three chunks) and, with corr_rs = 0, the kernels it replaced."""
+    test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib)
+    lib_option("corr_rs", 0)
+    test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib)
+
+
 @pytest.mark.parametrize("case", CORR_RW_CASES)
 def test_correlation_planes_fwd_wide_band_kernel_vs_oracle(case, dev, oracle_lib, lib_option):
     """The K-split wide-band kernel on the shapes the wave-pair kernel takes by default."""

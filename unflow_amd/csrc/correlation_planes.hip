@@ -323,6 +323,144 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_nb_kernel(const CorrPlParams 
 }
 
 
+// ------------------------------------------------------------------------------- narrow-band forward, rows shared (round 5)
+// corr_fwd_nb_kernel fetches every f1 row once per OUTPUT row that needs it: 2r+1 = 9 times for the +-4 cost volume — 4.5 GB
+// through L2 -> LDS for 0.6 GB of planes at 16 x 96 x 128 x 256, and that stream, not the matrix cores, paces it (339 us).
+// Here a workgroup (4 waves) owns RS_R = 4 consecutive output rows of one 24-site tile, one row per wave, and walks the
+// channels in chunks of 32: per chunk the RS_R + 2r f1 rows the four output rows share are brought in ONCE (LDS-DMA, 64
+// contiguous bytes per site and plane, source-side XOR swizzle for conflict-free b128 fragment reads) and every wave multiplies
+// its own f0 fragments (straight from L2 to registers: one row, used by all 2r+1 displacement rows) against its 2r+1 rows of
+// them.  The 2r+1 Grams of a wave stay in its accumulators over all chunks (9 x 16 registers), so nothing is exchanged between
+// waves and no partial bands travel through LDS; f1 traffic drops 9 -> 3 fetches per row.  Two workgroups per CU (72 KB of
+// LDS each): one multiplies while the other waits for its chunk.  stride_2 = 1, r <= 4, C % 32 == 0.
+constexpr int RS_R = 4, RS_MAXG = 9;
+constexpr int RS_ROWS = RS_R + RS_MAXG - 1;             // f1 rows of a chunk (r = 4: 12)
+constexpr int RS_PLANE = RS_ROWS * 32 * 64;             // bytes per plane: [row][32 sites][64 B]
+constexpr int RS_SMEM = 3 * RS_PLANE;                   // 73,728 B; the epilogue's band staging (4 x 24 x 81 floats) reuses it
+
+__global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned char* f1s = reinterpret_cast<unsigned char*>(lds);
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l31 = lane & 31, h = lane >> 5;
+  // work order: XCD-contiguous, site tiles fastest, then row groups, then samples
+  int b = xcd_remap(blockIdx.x, gridDim.x, 1);
+  const int ia = b % p.nA; b /= p.nA;
+  const int ngr = (p.oh + RS_R - 1) / RS_R;
+  const int gy = b % ngr;
+  const int n = b / ngr;
+  const int i0 = ia * p.vr;                             // first owned site (output x) of the tile
+  const int oy0 = gy * RS_R, oy = oy0 + wid;            // this wave's output row
+  const int n1 = (n + p.shift) % p.B;
+  const int ld2 = p.ld * 2;
+  const int nrows = RS_R + p.gw - 1;                    // f1 rows of a chunk
+  const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
+  u32x4 f1_rs[3];
+  __amdgpu_buffer_rsrc_t f0_rs[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    f0_rs[pl] = make_rsrc(p.f0 + pl * p.ps, recs);
+    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
+  }
+  const unsigned f1_addr = lds_addr(f1s);
+  // f0 fragment offset of the lane: site i0 + l31 (Gram rows past the owned sites are never read out: zeros, no traffic), granule h
+  int a_off;
+  {
+    const int xs = p.off + i0 + l31, ys = oy + p.off;
+    const bool ok = l31 < p.vr && (unsigned)xs < (unsigned)p.W && (unsigned)ys < (unsigned)p.H && oy < p.oh;
+    a_off = ok ? ((n * p.H + ys) * p.W + xs) * ld2 + h * 16 : OOB_MARK;
+  }
+  // DMA units of a chunk: (f1 row j, half hh of its 32 sites) -> 16 sites x 64 B = 1 KB, lane-linear in LDS: lane i fills slot
+  // i & 3 of site 16 hh + (i >> 2) with granule slot ^ ((site >> 2) & 3).  Wave w takes units w, w + 4, ...
+  const int d_site = lane >> 2, d_slot = lane & 3;
+  int d_off[2 * RS_ROWS / 4];
+#pragma unroll
+  for (int k = 0; k < 2 * RS_ROWS / 4; k++) {
+    const int unit = wid + 4 * k, j = unit >> 1, hh = unit & 1;
+    const int site = 16 * hh + d_site;
+    const int g = d_slot ^ ((site >> 2) & 3);
+    const int xs = p.off + i0 - p.r + site, yy = oy0 + p.off - p.r + j;
+    const bool ok = j < nrows && (unsigned)xs < (unsigned)p.W && (unsigned)yy < (unsigned)p.H;
+    d_off[k] = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + g * 16 : OOB_MARK;
+  }
+  f32x16 acc[RS_MAXG];
+#pragma unroll
+  for (int j = 0; j < RS_MAXG; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  // B fragment of (row jj, slab u): lane (site l31, half h) holds granule 2u + h of its site
+  const unsigned char* b_rd = f1s + (wid * 32 + l31) * 64;
+  const int bsw = (l31 >> 2) & 3;
+  const int nchunk = p.C >> 5;
+  for (int c = 0; c < nchunk; c++) {
+    __syncthreads();                                   // every wave is done with the previous chunk's rows
+#pragma unroll
+    for (int k = 0; k < 2 * RS_ROWS / 4; k++) {
+      const int unit = wid + 4 * k;
+      const unsigned d = f1_addr + (unsigned)(unit * 1024);
+      dma3(d_off[k] + c * 64, f1_rs[0], f1_rs[1], f1_rs[2], d, d + RS_PLANE, d + 2 * RS_PLANE);
+    }
+    s16x8 af[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) af[u][pl] = __builtin_bit_cast(s16x8, buf_ld16(f0_rs[pl], a_off + c * 64 + u * 32));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the rows has landed (and its f0 fragments)
+    __syncthreads();                                   // ... and everybody else's
+    s16x8 bf[2][2][3];
+    auto rd = [&](int j, s16x8 (&f)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+          f[u][pl] = *reinterpret_cast<const s16x8*>(b_rd + pl * RS_PLANE + j * (32 * 64) + (((2 * u + h) ^ bsw) << 4));
+    };
+    rd(0, bf[0]);
+#pragma unroll
+    for (int j = 0; j < RS_MAXG; j++) {
+      if (j < p.gw) {
+        if (j + 1 < p.gw) rd(j + 1, bf[(j + 1) & 1]);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
+                                                            __builtin_bit_cast(bf16x8, bf[j & 1][u][tb[tt]]), acc[j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                     // the f1 rows are dead: their LDS becomes the band staging
+  // acc[j][e] of lane (column l31, half h) is G[li][l31], li = (e & 3) + 8 (e >> 2) + 4 h; column l31 is site i0 - r + l31, so
+  // the band offset index of entry (li, l31) is l31 - li.  Staging [site][displacement row][offset], one area per wave.
+  const int g2 = p.gw * p.gw;
+  float* stg = reinterpret_cast<float*>(lds) + wid * (p.vr * g2);
+#pragma unroll
+  for (int j = 0; j < RS_MAXG; j++)
+    if (j < p.gw) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int li = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int oi = l31 - li;
+        if (li < p.vr && oi >= 0 && oi < p.gw) stg[li * g2 + j * p.gw + oi] = acc[j][e];
+      }
+    }
+  // (wave-private: the same wave reads it back — LDS operations of one wave complete in order)
+  if (oy < p.oh) {
+    const float cf = (float)p.C;
+    const float inv_g2 = 1.0f / (float)g2;
+    float* orow = p.out + ((size_t)n * p.oh + oy) * p.ow * p.ld_out;
+    for (int idx = lane; idx < p.vr * g2; idx += 64) {
+      // idx = (li, rem); the quotient is exact in fp32 at these sizes
+      const int li = (int)(((float)idx + 0.5f) * inv_g2), rem = idx - li * g2;
+      const int ox = i0 + li;
+      if (ox >= p.ow) break;
+      orow[(size_t)ox * p.ld_out + rem] = stg[idx] / cf;
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------- wide-band forward by DMA
 // FlowNetC's own cost volume (r = 10: the band of a 32-site tile covers most of its Gram and reaches into the neighbour
 // tiles).  corr_fwd_pl_kernel streams the f1 fragments from L2 at 32 cache lines per load instruction, ~64 cycles of the
@@ -1242,6 +1380,14 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   const int nq = (span + g.s2 - 1) / g.s2;
   corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
   const bool al16 = in0->ld % 8 == 0 && ((reinterpret_cast<uintptr_t>(in0->base) | reinterpret_cast<uintptr_t>(in1->base)) & 15) == 0;
+  if (p.joff != 0 && g.s2 == 1 && g.r <= 4 && p.vr == 32 - 2 * g.r && C % 32 == 0 && al16 && unflow::options().corr_rs) {
+    // rows shared by a workgroup (4 output rows, chunks of 32 channels): a third of the narrow-band kernel's f1 traffic
+    static const hipError_t rs_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
+    (void)rs_attr;
+    corr_fwd_rs_kernel<<<B * p.nA * ((g.oh + RS_R - 1) / RS_R), 256, RS_SMEM, st>>>(p);
+    return launch_status();
+  }
   if (p.joff != 0 && C % 64 == 0 && C <= 256 && al16 && corr_nb_enabled()) {
     // (16-byte granules; with ld % 64 == 0 and a 128-byte-aligned base — the step's feature buffers — every DMA
     // instruction moves 8 whole cache lines)
