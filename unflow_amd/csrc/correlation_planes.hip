@@ -338,6 +338,8 @@ constexpr int RS_ROWS = RS_R + RS_MAXG - 1;             // f1 rows of a chunk (r
 constexpr int RS_PLANE = RS_ROWS * 32 * 64;             // bytes per plane: [row][32 sites][64 B]
 constexpr int RS_SMEM = 3 * RS_PLANE;                   // 73,728 B; the epilogue's band staging (4 x 24 x 81 floats) reuses it
 
+template <int GW>                                      // 2r + 1: compile-time, so that the step loop has no branches (a conditional
+                                                       // fragment read makes hipcc wait for ALL outstanding LDS reads at the join)
 __global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned char* f1s = reinterpret_cast<unsigned char*>(lds);
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams 
   const int oy0 = gy * RS_R, oy = oy0 + wid;            // this wave's output row
   const int n1 = (n + p.shift) % p.B;
   const int ld2 = p.ld * 2;
-  const int nrows = RS_R + p.gw - 1;                    // f1 rows of a chunk
+  constexpr int nrows = RS_R + GW - 1;                    // f1 rows of a chunk
   const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
   u32x4 f1_rs[3];
   __amdgpu_buffer_rsrc_t f0_rs[3];
@@ -384,9 +386,9 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams 
     const bool ok = j < nrows && (unsigned)xs < (unsigned)p.W && (unsigned)yy < (unsigned)p.H;
     d_off[k] = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + g * 16 : OOB_MARK;
   }
-  f32x16 acc[RS_MAXG];
+  f32x16 acc[GW];
 #pragma unroll
-  for (int j = 0; j < RS_MAXG; j++)
+  for (int j = 0; j < GW; j++)
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
   constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
@@ -419,33 +421,30 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams 
     };
     rd(0, bf[0]);
 #pragma unroll
-    for (int j = 0; j < RS_MAXG; j++) {
-      if (j < p.gw) {
-        if (j + 1 < p.gw) rd(j + 1, bf[(j + 1) & 1]);
+    for (int j = 0; j < GW; j++) {
+      if (j + 1 < GW) rd(j + 1, bf[(j + 1) & 1]);
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+      for (int u = 0; u < 2; u++)
 #pragma unroll
-          for (int tt = 0; tt < 6; tt++)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
-                                                            __builtin_bit_cast(bf16x8, bf[j & 1][u][tb[tt]]), acc[j], 0, 0, 0);
-      }
+        for (int tt = 0; tt < 6; tt++)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[u][ta[tt]]),
+                                                          __builtin_bit_cast(bf16x8, bf[j & 1][u][tb[tt]]), acc[j], 0, 0, 0);
     }
   }
   __syncthreads();                                     // the f1 rows are dead: their LDS becomes the band staging
   // acc[j][e] of lane (column l31, half h) is G[li][l31], li = (e & 3) + 8 (e >> 2) + 4 h; column l31 is site i0 - r + l31, so
   // the band offset index of entry (li, l31) is l31 - li.  Staging [site][displacement row][offset], one area per wave.
-  const int g2 = p.gw * p.gw;
+  constexpr int g2 = GW * GW;
   float* stg = reinterpret_cast<float*>(lds) + wid * (p.vr * g2);
 #pragma unroll
-  for (int j = 0; j < RS_MAXG; j++)
-    if (j < p.gw) {
+  for (int j = 0; j < GW; j++) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int li = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int oi = l31 - li;
-        if (li < p.vr && oi >= 0 && oi < p.gw) stg[li * g2 + j * p.gw + oi] = acc[j][e];
-      }
+    for (int e = 0; e < 16; e++) {
+      const int li = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int oi = l31 - li;
+      if (li < p.vr && oi >= 0 && oi < GW) stg[li * g2 + j * GW + oi] = acc[j][e];
     }
+  }
   // (wave-private: the same wave reads it back — LDS operations of one wave complete in order)
   if (oy < p.oh) {
     const float cf = (float)p.C;
@@ -1380,12 +1379,21 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   const int nq = (span + g.s2 - 1) / g.s2;
   corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
   const bool al16 = in0->ld % 8 == 0 && ((reinterpret_cast<uintptr_t>(in0->base) | reinterpret_cast<uintptr_t>(in1->base)) & 15) == 0;
-  if (p.joff != 0 && g.s2 == 1 && g.r <= 4 && p.vr == 32 - 2 * g.r && C % 32 == 0 && al16 && unflow::options().corr_rs) {
-    // rows shared by a workgroup (4 output rows, chunks of 32 channels): a third of the narrow-band kernel's f1 traffic
-    static const hipError_t rs_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM);
+  if (p.joff != 0 && g.s2 == 1 && g.r >= 1 && g.r <= 4 && p.vr == 32 - 2 * g.r && C % 32 == 0 && al16 && unflow::options().corr_rs) {
+    // rows shared by a workgroup (4 output rows, double-buffered chunks of 32 channels): a third of the narrow-band kernel's f1 traffic
+    static const hipError_t rs_attr[4] = {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM)};
     (void)rs_attr;
-    corr_fwd_rs_kernel<<<B * p.nA * ((g.oh + RS_R - 1) / RS_R), 256, RS_SMEM, st>>>(p);
+    const int rs_grid = B * p.nA * ((g.oh + RS_R - 1) / RS_R);
+    switch (g.gw) {
+      case 3: corr_fwd_rs_kernel<3><<<rs_grid, 256, RS_SMEM, st>>>(p); break;
+      case 5: corr_fwd_rs_kernel<5><<<rs_grid, 256, RS_SMEM, st>>>(p); break;
+      case 7: corr_fwd_rs_kernel<7><<<rs_grid, 256, RS_SMEM, st>>>(p); break;
+      default: corr_fwd_rs_kernel<9><<<rs_grid, 256, RS_SMEM, st>>>(p); break;
+    }
     return launch_status();
   }
   if (p.joff != 0 && C % 64 == 0 && C <= 256 && al16 && corr_nb_enabled()) {
