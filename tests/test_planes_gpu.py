@@ -447,8 +447,13 @@ CORR_RS_CASES = [c for c in CORR_PL_CASES if c[4]['stride_2'] == 1 and c[4]['max
 @pytest.mark.parametrize("case", CORR_RS_CASES + [(4, 256, 21, 200, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),
                                                    (2, 96, 10, 77, dict(kernel_size=1, max_displacement=3, pad=3, stride_1=1, stride_2=1))])
 def test_correlation_planes_fwd_row_shared_and_narrow_band_kernels_vs_oracle(case, dev, oracle_lib, lib_option):
-    """The +-4 / 81-channel cost volume (and r = 2, 3): the row-shared kernel (default; incl. row groups of 4 with a ragged last
-    group, 9 site tiles, C = 96: three chunks) and, with corr_rs = 0, the kernels it replaced."""
+    """The +-4 / 81-channel cost volume (and r = 2, 3): the default kernels (r = 4: f1 rows streamed through an LDS ring, row
+    groups of 8 with a ragged last group, 9 site tiles, a ragged last tile; r < 4: the row-shared kernel, groups of 4; C = 96:
+    three chunks), into a concat buffer and as a dense cost volume (16-byte stores); with corr_rs = 1 the row-shared kernel at
+    r = 4 too, with corr_rs = 0 the kernels both replaced."""
+    test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib)
+    test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib, ld_extra=0)
+    lib_option("corr_rs", 1)
     test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib)
     lib_option("corr_rs", 0)
     test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib)
@@ -462,9 +467,10 @@ def test_correlation_planes_fwd_wide_band_kernel_vs_oracle(case, dev, oracle_lib
 
 
 @pytest.mark.parametrize("case", CORR_PL_CASES)
-def test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib):
+def test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib, ld_extra=3):
     """unflow_correlation_nhwc_fwd_pl (bf16 matrix cores, six-term split) vs the scalar C oracle of CorrelateData
-    (ops/correlation_op.cu.cc:51-117), paired like the training step (sample n with (n + N/2) % N)."""
+    (ops/correlation_op.cu.cc:51-117), paired like the training step (sample n with (n + N/2) % N).  The output rows carry
+    `ld_extra` foreign channels behind the cost volume (the step writes it into a concat buffer); 0 = a dense cost volume."""
     from unflow_amd import _lib
     from unflow_amd._lib import check, ptr, stream
     N, C, H, W, attrs = case
@@ -473,17 +479,18 @@ def test_correlation_planes_fwd_vs_oracle(case, dev, oracle_lib):
     feat = torch.from_numpy(rs.randn(N, H, W, C).astype(np.float32))
     F = make_pt(feat, dev, 3, extra=8)
     oc, oh, ow = oracle_lib.correlation_out_shape(H, W, **attrs)
-    out = torch.zeros(N, oh, ow, oc + 3, device=dev)
+    out = torch.zeros(N, oh, ow, oc + ld_extra, device=dev)
     out[..., :oc] = float('nan')            # every output is written (also the all-zero Grams outside the image)
     a = attrs
     check(_lib.lib().unflow_correlation_nhwc_fwd_pl(ptr(F.t), ptr(F.t), F.t.stride(2), _lib.planes_of(F.pl), _lib.planes_of(F.pl),
-                                                    B, ptr(out), oc + 3, N, C, H, W, a['kernel_size'], a['max_displacement'],
+                                                    B, ptr(out), oc + ld_extra, N, C, H, W, a['kernel_size'], a['max_displacement'],
                                                     a['pad'], a['stride_1'], a['stride_2'], stream()), "correlation_pl")
     x = np.ascontiguousarray(feat.numpy().transpose(0, 3, 1, 2))
     ref = oracle_lib.correlation(x, np.ascontiguousarray(np.roll(x, -B, axis=0)), **attrs)
     got = out[..., :oc].permute(0, 3, 1, 2).cpu().numpy()
     assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
-    assert out[..., oc:].abs().max().item() == 0
+    if ld_extra:
+        assert out[..., oc:].abs().max().item() == 0
 
 
 # (B, H, W, Cin, Cout, k, stride): shapes whose forward / data gradient split K (few output tiles, deep K)

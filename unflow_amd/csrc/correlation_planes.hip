@@ -460,6 +460,212 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams 
   }
 }
 
+// ------------------------------------------------------------------------------- +-4 forward, f1 rows as a stream (round 5)
+// The row-shared kernel above alternates fetch and multiply per chunk (two workgroups per CU hide each other's fetch at best
+// half of the time) and still reads every f1 row three times; per-dispatch counters put it at 1.0 GB from HBM and 1.5 GB
+// through L2 for 0.6 GB of planes, 4.3 TB/s with the matrix cores idle 55 % of the time.  Here ONE workgroup per CU (8 waves,
+// one output row each: RG_R = 8 rows of a 24-site tile, 16 f1 rows per chunk: two fetches per row) treats LDS as a ring of
+// RG_NS = 24 row slots (6 KB each: [plane][32 sites][64 B]) that the (chunk, row) stream runs through in order: row (c, r) sits
+// in slot (16 c + r) mod 24, is first needed at step max(0, r - 7) of its chunk (step j: wave w multiplies its f0 fragments
+// with row w + j) and is dead after step min(r, 8) — so the slots of chunk c free up while chunk c is multiplied and take
+// chunk c + 1 with a lead of five or more steps, the whole time:
+//   step 0: [wait rows 0..11 of c] barrier, request rows 0..7 of c + 1 (slots of rows 8..15 of c - 1) and the f0 fragments of c + 1
+//   step 4: [wait rows 12..15 of c] barrier, request rows 8..11 of c + 1 (slots of rows 0..3 of c)
+//   step 8:                         barrier, request rows 12..15 of c + 1 (slots of rows 4..7 of c)
+// Every wave issues the same number of loads at every point (2 + 1 + 1 three-plane DMA units of 1 KB per plane, then 6 fragment
+// loads), so the waits are immediates: vmcnt(3) at step 0 (the step-8 request may still be out), vmcnt(12) at step 4.  All
+// loads are inline asm — the compiler's own bookkeeping would wait for everything at the first use of a fragment — and the
+// fragment registers are tied through the wait statement.  Past the last chunk the requests are out of range (zeros, no traffic).
+// Products: v_mfma_f32_16x16x32_bf16 — a chunk's 32 channels are ONE instruction deep, and the band (9 offsets of 24 owned sites)
+// wastes less of 16 x 16 blocks than of a 32 x 32 Gram: per f1 row three products (f0 sites 0..15 x staged sites 0..15 and
+// 16..31, f0 sites 16..23 x staged sites 16..31), 3 x 6 terms x 16 cycles = 288 instead of 2 x 6 x 32 = 384, and the three
+// accumulators alternate (a wait or a read between two MFMAs on the SAME accumulator costs ~43 cycles on gfx950, between
+// different ones ~6).  Lane l of an operand holds granule l >> 4 (8 channels) of site l & 15; staged granule q of site s sits in
+// slot q ^ swz(s) of the site's 64 bytes, which makes every 16-lane group of the b128 fragment reads hit 16 distinct bank slots.
+// (Measured and dropped, profiles/r05_corr_ring.txt: one PERSISTENT workgroup per CU walking 4-5 items with the ring running
+// across item boundaries and the band staged in the slot of the wave's last row — the band stores and the next item's first
+// chunk overlap the products, but the workgroups of an XCD drift apart, neighbours stop meeting in L2 (1.17 GB from HBM instead
+// of 0.90) and the kernel is slower, 218 against 206 us; odd row groups run bottom-up so that vertical neighbours ask for their
+// shared rows at the same step: no fewer bytes.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RG_R = 8, RG_GW = 9, RG_ROWS = RG_R + RG_GW - 1, RG_NS = 24;
+constexpr int RG_SLOT = 3 * 32 * 64;                    // bytes per slot
+constexpr int RG_SMEM = RG_NS * RG_SLOT;                // 147,456 B; the epilogue's band staging (8 x 24 x 81 floats) reuses it
+
+__device__ __forceinline__ u32x4 asm_ld16(u32x4 rs, int voff) {
+  u32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(512, 1) void corr_fwd_ring_kernel(const CorrPlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned char* f1s = reinterpret_cast<unsigned char*>(lds);
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l15 = lane & 15, q = lane >> 4;
+  int b = xcd_remap(blockIdx.x, gridDim.x, 1);          // XCD-contiguous: site tiles fastest, then row groups, then samples
+  const int ia = b % p.nA; b /= p.nA;
+  const int ngr = (p.oh + RG_R - 1) / RG_R;
+  const int gy = b % ngr;
+  const int n = b / ngr;
+  const int i0 = ia * 24;
+  const int oy0 = gy * RG_R, oy = oy0 + wid;
+  const int n1 = (n + p.shift) % p.B;
+  const int ld2 = p.ld * 2;
+  const int nchunk = p.C >> 5;
+  const size_t recs = (((size_t)p.B * p.H * p.W - 1) * (size_t)p.ld + (size_t)p.C) * 2;
+  u32x4 f0_rs[3], f1_rs[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    f0_rs[pl] = raw_rsrc(p.f0 + pl * p.ps, recs);
+    f1_rs[pl] = raw_rsrc(p.f1 + pl * p.ps, recs);
+  }
+  const unsigned f1_addr = lds_addr(f1s);
+  auto swz = [](int site) { return (0x72 >> (((site >> 2) & 3) * 2)) & 3; };   // {0, 2, 3, 1}[(site >> 2) & 3]
+  // f0 fragments: row tile rt holds sites 16 rt + l15 (owned: < 24), granule q
+  int a_off[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++) {
+    const int s0 = 16 * rt + l15;
+    const int xs = p.off + i0 + s0, ys = oy + p.off;
+    const bool ok = s0 < 24 && (unsigned)xs < (unsigned)p.W && (unsigned)ys < (unsigned)p.H && oy < p.oh;
+    a_off[rt] = ok ? ((n * p.H + ys) * p.W + xs) * ld2 + q * 16 : OOB_MARK;
+  }
+  // this wave's DMA units: rows (wid >> 1) + 4 k, k = 0..3, half wid & 1 of the row's 32 sites (16 sites x 64 B per plane):
+  // lane i fills slot i & 3 of site 16 hh + (i >> 2) with source granule (i & 3) ^ swz(site)
+  const int hh = wid & 1;
+  int d_off[4];
+  {
+    const int site = 16 * hh + (lane >> 2);
+    const int g = (lane & 3) ^ swz(site);
+    const int xs = p.off + i0 - p.r + site;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int yy = oy0 + p.off - p.r + (wid >> 1) + 4 * k;
+      const bool ok = (unsigned)xs < (unsigned)p.W && (unsigned)yy < (unsigned)p.H;
+      d_off[k] = ok ? ((n1 * p.H + yy) * p.W + xs) * ld2 + g * 16 : OOB_MARK;
+    }
+  }
+  // request row (wid >> 1) + 4 k of chunk cc (cbx = (16 cc) mod 24: slot of its row 0)
+  auto request = [&](int k, int cc, int cbx) __attribute__((always_inline)) {
+    int sl = cbx + (wid >> 1) + 4 * k;
+    sl = sl >= RG_NS ? sl - RG_NS : sl;
+    const unsigned d = f1_addr + (unsigned)(sl * RG_SLOT + hh * 1024);
+    dma3(cc < nchunk ? d_off[k] + cc * 64 : OOB_MARK, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 2048, d + 4096);
+  };
+  u32x4 afn[2][3];                                     // f0 fragments of the NEXT chunk, in flight
+  auto request_a = [&](int cc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+      const int off = cc < nchunk ? a_off[rt] + cc * 64 : OOB_MARK;
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) afn[rt][pl] = asm_ld16(f0_rs[pl], off);
+    }
+  };
+  f32x4 acc[RG_GW][3];
+#pragma unroll
+  for (int j = 0; j < RG_GW; j++)
+#pragma unroll
+    for (int pr = 0; pr < 3; pr++) acc[j][pr] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+  constexpr int prt[3] = {0, 0, 1}, pct[3] = {0, 1, 1};                   // product -> (f0 row tile, f1 column tile)
+  // fragment of column tile ct: site 16 ct + l15 (the swizzle repeats every 16 sites: tile 1 = tile 0 + 1 KB)
+  const unsigned char* b_rd = f1s + l15 * 64 + ((q ^ swz(l15)) << 4);
+
+  // chunk 0 in the steady state's order: rows 0..7, fragments, rows 8..11, rows 12..15
+  request(0, 0, 0); request(1, 0, 0);
+  request_a(0);
+  request(2, 0, 0);
+  request(3, 0, 0);
+  int cb = 0;                                          // (16 c) mod 24
+  for (int c = 0; c < nchunk; c++) {
+    int cbn = cb + 16;
+    cbn = cbn >= RG_NS ? cbn - RG_NS : cbn;
+    // ---- step 0
+    asm volatile("s_waitcnt vmcnt(3)"
+                 : "+v"(afn[0][0]), "+v"(afn[0][1]), "+v"(afn[0][2]), "+v"(afn[1][0]), "+v"(afn[1][1]), "+v"(afn[1][2])::"memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    s16x8 af[2][3];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) af[rt][pl] = __builtin_bit_cast(s16x8, afn[rt][pl]);
+    request(0, c + 1, cbn); request(1, c + 1, cbn);
+    request_a(c + 1);
+    s16x8 bf[2][2][3];                                 // [step parity][column tile][plane]
+    auto rd = [&](int j, s16x8 (&f)[2][3]) __attribute__((always_inline)) {
+      int sl = cb + wid + j;
+      sl = sl >= RG_NS ? sl - RG_NS : sl;
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) f[ct][pl] = *reinterpret_cast<const s16x8*>(b_rd + sl * RG_SLOT + ct * 1024 + pl * 2048);
+    };
+    rd(0, bf[0]);
+#pragma unroll
+    for (int j = 0; j < RG_GW; j++) {
+      if (j == 4 || j == 8) {
+        if (j == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        request(j == 4 ? 2 : 3, c + 1, cbn);
+      }
+      if (j + 1 < RG_GW) rd(j + 1, bf[(j + 1) & 1]);
+#pragma unroll
+      for (int tt = 0; tt < 6; tt++)
+#pragma unroll
+        for (int pr = 0; pr < 3; pr++)
+          acc[j][pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[prt[pr]][ta[tt]]),
+                                                              __builtin_bit_cast(bf16x8, bf[j & 1][pct[pr]][tb[tt]]), acc[j][pr], 0, 0, 0);
+    }
+    cb = cbn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the out-of-range requests past the last chunk write zeros: let them land
+  __syncthreads();                                     // the ring is dead: its LDS becomes the band staging
+  // acc[j][pr][e] of lane (column l15, quarter q) is the product of f0 site s0 = 16 rt + 4 q + e and staged site s1 = 16 ct + l15
+  // (x = i0 - 4 + s1): band offset index s1 - s0.  Staging [site][displacement row][offset], one area per wave.
+  constexpr int g2 = RG_GW * RG_GW;
+  float* stg = reinterpret_cast<float*>(lds) + wid * (24 * g2);
+#pragma unroll
+  for (int pr = 0; pr < 3; pr++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int s0 = 16 * prt[pr] + 4 * q + e;
+      const int oi = 16 * pct[pr] + l15 - s0;
+      if (s0 < 24 && oi >= 0 && oi < RG_GW) {            // (one predicate per (product, e): the displacement rows inside)
+        float* w = stg + s0 * g2 + oi;
+#pragma unroll
+        for (int j = 0; j < RG_GW; j++) w[j * RG_GW] = acc[j][pr][e];
+      }
+    }
+  // (wave-private: the same wave reads it back — LDS operations of one wave complete in order)
+  if (oy < p.oh) {
+    const float cf = (float)p.C;
+    float* orow = p.out + ((size_t)n * p.oh + oy) * p.ow * p.ld_out;
+    const int cnt = min(24, p.ow - i0) * g2;             // the tile's band entries of this row
+    float* dst = orow + (size_t)i0 * p.ld_out;
+    if (p.ld_out == g2 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      // dense output rows: the tile's entries are one contiguous run — 16 bytes per lane (the stores are issue-bound)
+      const f32x4* src4 = reinterpret_cast<const f32x4*>(stg);
+      f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
+      for (int v = lane; v < (cnt >> 2); v += 64) {
+        f32x4 x = src4[v];
+        x[0] /= cf; x[1] /= cf; x[2] /= cf; x[3] /= cf;
+        dst4[v] = x;
+      }
+      for (int t = (cnt & ~3) + lane; t < cnt; t += 64) dst[t] = stg[t] / cf;
+    } else {
+      const float inv_g2 = 1.0f / (float)g2;
+      for (int idx = lane; idx < cnt; idx += 64) {
+        const int li = (int)(((float)idx + 0.5f) * inv_g2), rem = idx - li * g2;   // exact at these sizes
+        dst[(size_t)li * p.ld_out + rem] = stg[idx] / cf;
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------------------- wide-band forward by DMA
 // FlowNetC's own cost volume (r = 10: the band of a 32-site tile covers most of its Gram and reaches into the neighbour
 // tiles).  corr_fwd_pl_kernel streams the f1 fragments from L2 at 32 cache lines per load instruction, ~64 cycles of the
@@ -1379,6 +1585,14 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   const int nq = (span + g.s2 - 1) / g.s2;
   corr_pl_tiles(nq, g.r, &p.nA, &p.T, &p.vr, &p.joff);
   const bool al16 = in0->ld % 8 == 0 && ((reinterpret_cast<uintptr_t>(in0->base) | reinterpret_cast<uintptr_t>(in1->base)) & 15) == 0;
+  if (p.joff != 0 && g.s2 == 1 && g.r == 4 && p.vr == 24 && C % 32 == 0 && al16 && unflow::options().corr_rs >= 2) {
+    // the +-4 cost volume: f1 rows streamed through an LDS ring, one 8-row workgroup per CU
+    static const hipError_t rg_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_ring_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, RG_SMEM);
+    (void)rg_attr;
+    corr_fwd_ring_kernel<<<B * p.nA * ((g.oh + RG_R - 1) / RG_R), 512, RG_SMEM, st>>>(p);
+    return launch_status();
+  }
   if (p.joff != 0 && g.s2 == 1 && g.r >= 1 && g.r <= 4 && p.vr == 32 - 2 * g.r && C % 32 == 0 && al16 && unflow::options().corr_rs) {
     // rows shared by a workgroup (4 output rows, double-buffered chunks of 32 channels): a third of the narrow-band kernel's f1 traffic
     static const hipError_t rs_attr[4] = {
