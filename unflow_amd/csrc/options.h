@@ -24,7 +24,7 @@
   X(wgrad_dma, 1)         /* LDS-DMA filter-gradient kernel (0: register-staged) */                                       \
   X(wgrad_pp, 1)          /* ping-pong filter-gradient kernel (8 waves): 1 where it pays, 3 wherever eligible, 0 off */                                           \
   X(corr_nb, 1)           /* narrow-band correlation forward kernel */                                                    \
-  X(corr_rs, 2)           /* ... its row-shared form (4 output rows per workgroup, 32-channel chunks; stride_2 = 1, r <= 4) */ \
+  X(corr_rs, 2)           /* ... stride_2 = 1, r <= 4: 1 = rows shared by a 4-row workgroup, 2 = at r = 4 an LDS ring of rows */ \
   X(corr_wb, 1)           /* wide-band correlation forward kernel */                                                      \
   X(corr_rw, 1)           /* ... its wave-pair-per-row form (C = 128 / 256) */                                            \
   X(corr_bwd_b128, 1)     /* 16-byte band loads in the correlation backward */                                            \
