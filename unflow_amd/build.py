@@ -20,6 +20,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # instruction is NOT the demonstrated cause; the flags changed the code (and the timing) of the one kernel that flaked, and that
 # kernel was replaced in round 3 by flow_wgrad_batched_kernel.  A workspace race would have looked the same; none was found
 # (every deferred filter gradient owns its scratch slot, core/engine.py ws_slot 3 +; the 100-replay stress test is the guard).
+# Round 5 re-audited it with what the conv_first incident taught: the round-2 sources (84ebc76~1) rebuilt with the
+# round-2 flags contain the recorded instruction in tiny_deconv_wgrad_kernel<2,2> (global_load_dwordx2 v[80:81], v[80:81] /
+# s_waitcnt vmcnt(0) / the two v_pk_mul_f32), and tools/isa_store_hazard.py finds NO wide buffer store behind an SGPR offset
+# anywhere in that build - the store-data hazard is not the cause of this one.  It stays unexplained; the flags stay because the
+# step is faster with them, and a compiler bump is guarded by the replay stress test, not by this comment.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
