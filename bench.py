@@ -546,7 +546,9 @@ def _pmc_traffic():
     correction, WRITE_SIZE; both calibrated to 1.00 on the Adam kernel in the same trace, tools/pmc_traffic.py).
     PMC needs its own rocprofv3 runs, so this is read from profiles/, not collected inside bench.py."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')))
+    # the latest round's file; within a round the end-of-round record (rNN_end_*) over the mid-round one
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')),
+                   key=lambda f: (os.path.basename(f)[:3], '_end_' in os.path.basename(f)))
     if not files:
         return {"traffic": None}
     d = json.load(open(files[-1]))
