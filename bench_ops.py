@@ -3,6 +3,7 @@
 fraction is meaningful (inside the training step they run on <= 96x128 pyramid levels and are launch-latency bound).
 Prints one JSON object per op: algorithmic bytes (SURVEY 8d per-pixel figures), time (HIP events on the launch
 stream, median of 20), GB/s and the fraction of the 8 TB/s HBM3E peak (6.3 TB/s is the measured streaming ceiling)."""
+import ctypes
 import json
 import sys
 import os
@@ -156,6 +157,27 @@ def main():
     nbbp = N2 * h2 * w2 * (81 * 4 + 2 * 256 * 6 + 256 * 4)
     us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd_pl(ptr(gco2), 84, ptr(f2), ptr(f2), 256, planes_of(F2.pl), planes_of(F2.pl), N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
     report("correlation_nhwc_bwd_pl 81ch N=16 96x128 (fused g0+g1)", nbbp, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
+    # the reference op's own boundary: two NCHW fp32 tensors in, NCHW out (ops/correlation_op.cc) — transposes to NHWC, operand
+    # planes built in the workspace, the planes kernels, transpose back.  With only the fp32 part of the workspace: the fp32 kernels.
+    del F2, f2, co2, gco2, gf2
+    for (nm, Bc, Cc, Hc, Wc, md, s2, oc) in (("81ch (md=4, stride_2=1) B=8 96x128", 8, 256, 96, 128, 4, 1, 81), ("441ch (md=20, stride_2=2) B=4 48x64", 4, 256, 48, 64, 20, 2, 441)):
+        xa = torch.randn(Bc, Cc, Hc, Wc, generator=g).to(dev)
+        xb = torch.randn(Bc, Cc, Hc, Wc, generator=g).to(dev)
+        oo = torch.empty(Bc, oc, Hc, Wc, device=dev)
+        lib.unflow_correlation_workspace_bytes.restype = ctypes.c_size_t
+        wsb = lib.unflow_correlation_workspace_bytes(Bc, Cc, Hc, Wc, 1, md, md, 1, s2)
+        ws = torch.empty(wsb // 4 + 64, device=dev)
+        fp32_only = (4 * xa.numel() + oo.numel()) * 4
+        nbr = (2 * xa.numel() + oo.numel()) * 4
+        for label, nbytes in (("planes in the workspace", wsb), ("fp32 part of the workspace only", fp32_only)):
+            us = timeit(lambda: check(lib.unflow_correlation_fwd(ptr(xa), ptr(xb), ptr(oo), Bc, Cc, Hc, Wc, 1, md, md, 1, s2, ptr(ws), ctypes.c_size_t(nbytes), st)))
+            report("correlation_fwd NCHW fp32 tensors (reference op boundary) %s, %s" % (nm, label), nbr, us)
+        go = torch.randn(Bc, oc, Hc, Wc, generator=g).to(dev)
+        ga, gb = torch.empty_like(xa), torch.empty_like(xb)
+        for label, nbytes in (("planes in the workspace", wsb), ("fp32 part of the workspace only", fp32_only)):
+            us = timeit(lambda: check(lib.unflow_correlation_bwd(ptr(go), ptr(xa), ptr(xb), ptr(ga), ptr(gb), Bc, Cc, Hc, Wc, 1, md, md, 1, s2, ptr(ws), ctypes.c_size_t(nbytes), st)))
+            report("correlation_bwd NCHW fp32 tensors (reference op boundary) %s, %s" % (nm, label), nbr + 2 * xa.numel() * 4, us)
+        del xa, xb, oo, ws, go, ga, gb
 
 
 if __name__ == "__main__":

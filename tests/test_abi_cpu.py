@@ -66,7 +66,11 @@ def test_workspace_queries(lib):
     small = lib.unflow_conv_workspace_bytes(8, 192, 256, 64, 128, 5, 2)      # conv2: plenty of tiles, wgrad split only
     deep = lib.unflow_conv_workspace_bytes(8, 6, 8, 1024, 1024, 3, 1)        # conv6_1: split-K partials
     assert 0 < small < 1 << 30 and 0 < deep < 1 << 30
-    assert lib.unflow_correlation_workspace_bytes(1, 256, 48, 64, 1, 20, 20, 1, 2) == (4 * 256 * 48 * 64 + 441 * 48 * 64) * 4
+    # NHWC fp32 copies of in0, in1, g0, g1 and dout, + the bf16 x 3 operand planes of the two inputs where the matrix-core
+    # kernels take the shape (kernel_size 1, stride_1 1, pad >= max_displacement, C % 16 == 0)
+    fp32_part = (4 * 256 * 48 * 64 + 441 * 48 * 64) * 4
+    assert lib.unflow_correlation_workspace_bytes(1, 256, 48, 64, 1, 20, 20, 1, 2) == fp32_part + 2 * 3 * 256 * 48 * 64 * 2 + 256
+    assert lib.unflow_correlation_workspace_bytes(1, 20, 48, 64, 1, 20, 20, 1, 2) == (4 * 20 * 48 * 64 + 441 * 48 * 64) * 4   # C % 16 != 0
 
 
 def test_product_path_never_imports_the_oracle():

@@ -260,12 +260,33 @@ UNFLOW_API int unflow_correlation_nhwc_bwd_pl(const float* dout, int ld_dout, co
                                      C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, stream);
 }
 
+// Operand planes of the two inputs inside the workspace of the reference-layout entry points: [input][plane][pixel][C] bf16,
+// 256-byte aligned behind the fp32 part.  0 when the plane kernels do not take the shape.
+static size_t corr_ws_plane_bytes(const CorrGeom& g, int B, int C, int H, int W) {
+  if (g.k != 1 || g.s1 != 1 || g.md - g.pad > 0 || C % 16 != 0 || C > 1024) return 0;
+  return 2 * 3 * (size_t)B * H * W * C * 2 + 256;
+}
+// builds them from the NHWC fp32 copies a, b; returns false (nothing launched) when there is no room
+static bool corr_ws_planes(const CorrGeom& g, const float* a, const float* b, void* ws_end_fp32, size_t bytes_left, int B, int C, int H,
+                           int W, unflow_planes* pa, unflow_planes* pb, unflow_stream_t stream) {
+  const size_t need = corr_ws_plane_bytes(g, B, C, H, W);
+  if (!need || bytes_left < need) return false;
+  const size_t npix = (size_t)B * H * W;
+  unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws_end_fp32) + 255) & ~(uintptr_t)255);
+  *pa = unflow_planes{base, (long)(npix * C), C, 3, 0.f};
+  *pb = unflow_planes{base + 3 * npix * C * 2, (long)(npix * C), C, 3, 0.f};
+  return unflow_planes_from_f32(a, C, (long)npix, C, C, pa, stream) == UNFLOW_OK &&
+         unflow_planes_from_f32(b, C, (long)npix, C, C, pb, stream) == UNFLOW_OK;
+}
+
 UNFLOW_API size_t unflow_correlation_workspace_bytes(int B, int C, int H, int W, int kernel_size,
                                                      int max_displacement, int pad, int stride_1, int stride_2) {
   CorrGeom g;
   if (corr_status(H, W, kernel_size, max_displacement, pad, stride_1, stride_2, &g) != UNFLOW_OK) return 0;
   const size_t in_e = (size_t)B * H * W * C, out_e = (size_t)B * g.oh * g.ow * g.oc;
-  return (4 * in_e + out_e) * sizeof(float);  // bwd: in0,in1,g0,g1 + dout (fwd needs 2*in + out)
+  // bwd: in0,in1,g0,g1 + dout (fwd needs 2*in + out) as NHWC fp32, + the two inputs' bf16 x 3 operand planes when the matrix-core
+  // kernels of correlation_planes.hip take the shape (the entry points below use them iff the workspace has room for them)
+  return (4 * in_e + out_e) * sizeof(float) + corr_ws_plane_bytes(g, B, C, H, W);
 }
 
 UNFLOW_API int unflow_correlation_fwd(const float* in0, const float* in1, float* out, int B, int C, int H, int W,
@@ -286,8 +307,16 @@ UNFLOW_API int unflow_correlation_fwd(const float* in0, const float* in1, float*
   int code;
   if ((code = transpose_bcn(in0, a, B, C, H * W, s)) != UNFLOW_OK) return code;
   if ((code = transpose_bcn(in1, b, B, C, H * W, s)) != UNFLOW_OK) return code;
-  code = unflow_correlation_nhwc_fwd(a, b, C, 0, o, g.oc, B, C, H, W, kernel_size, max_displacement, pad, stride_1,
-                                     stride_2, stream);
+  // with room for them in the workspace (unflow_correlation_workspace_bytes asks for it): operand planes and the matrix-core
+  // kernels of the training step; otherwise the fp32 kernels
+  unflow_planes pa, pb;
+  const size_t used = (2 * in_e + out_e) * sizeof(float);
+  if (corr_ws_planes(g, a, b, o + out_e, workspace_bytes - used, B, C, H, W, &pa, &pb, stream))
+    code = unflow_correlation_nhwc_fwd_pl(a, b, C, &pa, &pb, 0, o, g.oc, B, C, H, W, kernel_size, max_displacement, pad, stride_1,
+                                          stride_2, stream);
+  else
+    code = unflow_correlation_nhwc_fwd(a, b, C, 0, o, g.oc, B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2,
+                                       stream);
   if (code != UNFLOW_OK) return code;
   return transpose_bcn(o, out, B, g.oh * g.ow, g.oc, s);
 }
@@ -314,8 +343,14 @@ UNFLOW_API int unflow_correlation_bwd(const float* dout, const float* in0, const
   if ((code = transpose_bcn(in0, a, B, C, H * W, s)) != UNFLOW_OK) return code;
   if ((code = transpose_bcn(in1, b, B, C, H * W, s)) != UNFLOW_OK) return code;
   if ((code = transpose_bcn(dout, d, B, g.oc, g.oh * g.ow, s)) != UNFLOW_OK) return code;
-  code = unflow_correlation_nhwc_bwd(d, g.oc, a, b, C, 0, ga, gb, C, 0, B, C, H, W, kernel_size, max_displacement, pad,
-                                     stride_1, stride_2, stream);
+  unflow_planes pa, pb;
+  const size_t used = (4 * in_e + out_e) * sizeof(float);
+  if (corr_ws_planes(g, a, b, d + out_e, workspace_bytes - used, B, C, H, W, &pa, &pb, stream))
+    code = unflow_correlation_nhwc_bwd_pl(d, g.oc, a, b, C, &pa, &pb, 0, ga, gb, C, 0, B, C, H, W, kernel_size, max_displacement, pad,
+                                          stride_1, stride_2, stream);
+  else
+    code = unflow_correlation_nhwc_bwd(d, g.oc, a, b, C, 0, ga, gb, C, 0, B, C, H, W, kernel_size, max_displacement, pad, stride_1,
+                                       stride_2, stream);
   if (code != UNFLOW_OK) return code;
   if ((code = transpose_bcn(ga, grad0, B, H * W, C, s)) != UNFLOW_OK) return code;
   return transpose_bcn(gb, grad1, B, H * W, C, s);
