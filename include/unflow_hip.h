@@ -73,8 +73,8 @@ int unflow_correlation_out_shape(int H, int W, int kernel_size, int max_displace
 /* Bytes of scratch the NCHW entry points ask for: channels-last fp32 staging copies (in0, in1, g0, g1, dout: the minimum they
  * accept) + room for the two inputs' bf16 x 3 operand planes where the matrix-core kernels take the shape (kernel_size 1,
  * stride_1 1, pad >= max_displacement, C % 16 == 0).  With the full size the entry points build the planes and run the
- * kernels of the training step (81-channel +-4 volume, 8 x 256 x 96 x 128: 364 / 684 us forward / backward instead of
- * 895 / 1259); with the minimum they run the fp32-input kernels. */
+ * kernels of the training step (81-channel +-4 volume, 8 x 256 x 96 x 128: 271 / 652 us forward / backward instead of
+ * 912 / 1298); with the minimum they run the fp32-input kernels. */
 size_t unflow_correlation_workspace_bytes(int B, int C, int H, int W, int kernel_size,
                                           int max_displacement, int pad, int stride_1, int stride_2);
 

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "options.h"
 #include "correlation_geom.h"
+#include "igemm_shared.h"   // split3
 
 // ------------------------------------------------------------------ generic forward
 // One 256-thread block per output pixel: the k*k*C patch of in0 is staged in LDS once, then the
@@ -140,6 +141,34 @@ __global__ void transpose_bcn_kernel(const float* __restrict__ in, float* __rest
   }
 }
 
+// [B, C, HW] fp32 -> the tensor's three bf16 operand planes [plane][B * HW][C] (and, with `nhwc`, its channels-last fp32 copy
+// in the same pass): 64 channels x 32 sites per workgroup through LDS, 128-byte rows on the way out.  C % 16 == 0.
+__global__ __launch_bounds__(256) void transpose_bcn_planes_kernel(const float* __restrict__ in, unsigned short* __restrict__ pl,
+                                                                    long plane_stride, float* __restrict__ nhwc, int C, int S) {
+  __shared__ float tile[64][33];
+  const size_t b = blockIdx.z;
+  const int c0 = blockIdx.y * 64, s0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 64; j += 8) {
+    const int c = c0 + j, sx = s0 + tx;
+    tile[j][tx] = (c < C && sx < S) ? in[(b * C + c) * S + sx] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {                   // site s0 + j: lane tx writes channels c0 + 2 tx, + 1
+    const int sx = s0 + j, c = c0 + 2 * tx;
+    if (sx >= S || c >= C) continue;
+    const float v0 = tile[2 * tx][j], v1 = tile[2 * tx + 1][j];
+    unsigned short h0, m0, l0, h1, m1, l1;
+    igemm::split3(v0, h0, m0, l0);
+    igemm::split3(v1, h1, m1, l1);
+    const size_t e = (b * S + sx) * (size_t)C + c;
+    *reinterpret_cast<unsigned*>(pl + e) = h0 | ((unsigned)h1 << 16);
+    *reinterpret_cast<unsigned*>(pl + plane_stride + e) = m0 | ((unsigned)m1 << 16);
+    *reinterpret_cast<unsigned*>(pl + 2 * plane_stride + e) = l0 | ((unsigned)l1 << 16);
+    if (nhwc) *reinterpret_cast<float2*>(nhwc + e) = make_float2(v0, v1);
+  }
+}
+
 static int transpose_bcn(const float* in, float* out, int B, int R, int S, hipStream_t st) {
   dim3 grid(cdiv(S, 32), cdiv(R, 32), B);
   transpose_bcn_kernel<<<grid, 256, 0, st>>>(in, out, R, S);
@@ -266,17 +295,22 @@ static size_t corr_ws_plane_bytes(const CorrGeom& g, int B, int C, int H, int W)
   if (g.k != 1 || g.s1 != 1 || g.md - g.pad > 0 || C % 16 != 0 || C > 1024) return 0;
   return 2 * 3 * (size_t)B * H * W * C * 2 + 256;
 }
-// builds them from the NHWC fp32 copies a, b; returns false (nothing launched) when there is no room
-static bool corr_ws_planes(const CorrGeom& g, const float* a, const float* b, void* ws_end_fp32, size_t bytes_left, int B, int C, int H,
-                           int W, unflow_planes* pa, unflow_planes* pb, unflow_stream_t stream) {
+// lays them out behind the fp32 part; returns false when there is no room (or the shape is not theirs)
+static bool corr_ws_planes(const CorrGeom& g, void* ws_end_fp32, size_t bytes_left, int B, int C, int H, int W, unflow_planes* pa,
+                           unflow_planes* pb) {
   const size_t need = corr_ws_plane_bytes(g, B, C, H, W);
   if (!need || bytes_left < need) return false;
   const size_t npix = (size_t)B * H * W;
   unsigned char* base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(ws_end_fp32) + 255) & ~(uintptr_t)255);
   *pa = unflow_planes{base, (long)(npix * C), C, 3, 0.f};
   *pb = unflow_planes{base + 3 * npix * C * 2, (long)(npix * C), C, 3, 0.f};
-  return unflow_planes_from_f32(a, C, (long)npix, C, C, pa, stream) == UNFLOW_OK &&
-         unflow_planes_from_f32(b, C, (long)npix, C, C, pb, stream) == UNFLOW_OK;
+  return true;
+}
+// NCHW input -> planes (+ the channels-last fp32 copy when `nhwc` is given) in one pass
+static int transpose_to_planes(const float* in, const unflow_planes& p, float* nhwc, int B, int C, int S, hipStream_t st) {
+  dim3 grid(cdiv(S, 32), cdiv(C, 64), B);
+  transpose_bcn_planes_kernel<<<grid, 256, 0, st>>>(in, reinterpret_cast<unsigned short*>(p.base), p.plane_stride, nhwc, C, S);
+  return launch_status();
 }
 
 UNFLOW_API size_t unflow_correlation_workspace_bytes(int B, int C, int H, int W, int kernel_size,
@@ -305,18 +339,21 @@ UNFLOW_API int unflow_correlation_fwd(const float* in0, const float* in1, float*
   float* o = b + in_e;
   hipStream_t s = as_stream(stream);
   int code;
-  if ((code = transpose_bcn(in0, a, B, C, H * W, s)) != UNFLOW_OK) return code;
-  if ((code = transpose_bcn(in1, b, B, C, H * W, s)) != UNFLOW_OK) return code;
-  // with room for them in the workspace (unflow_correlation_workspace_bytes asks for it): operand planes and the matrix-core
-  // kernels of the training step; otherwise the fp32 kernels
+  // with room for them in the workspace (unflow_correlation_workspace_bytes asks for it): operand planes straight from the NCHW
+  // inputs and the matrix-core kernels of the training step; otherwise channels-last fp32 copies and the fp32 kernels
   unflow_planes pa, pb;
   const size_t used = (2 * in_e + out_e) * sizeof(float);
-  if (corr_ws_planes(g, a, b, o + out_e, workspace_bytes - used, B, C, H, W, &pa, &pb, stream))
-    code = unflow_correlation_nhwc_fwd_pl(a, b, C, &pa, &pb, 0, o, g.oc, B, C, H, W, kernel_size, max_displacement, pad, stride_1,
-                                          stride_2, stream);
-  else
+  if (corr_ws_planes(g, o + out_e, workspace_bytes - used, B, C, H, W, &pa, &pb) && corr_pl_supported(g, C, &pa, &pb) &&
+      corr_pl_fits_32bit(&pa, B, H, W, g.oc, g)) {
+    if ((code = transpose_to_planes(in0, pa, nullptr, B, C, H * W, s)) != UNFLOW_OK) return code;
+    if ((code = transpose_to_planes(in1, pb, nullptr, B, C, H * W, s)) != UNFLOW_OK) return code;
+    code = corr_pl_fwd(&pa, &pb, 0, o, g.oc, B, C, H, W, g, s);
+  } else {
+    if ((code = transpose_bcn(in0, a, B, C, H * W, s)) != UNFLOW_OK) return code;
+    if ((code = transpose_bcn(in1, b, B, C, H * W, s)) != UNFLOW_OK) return code;
     code = unflow_correlation_nhwc_fwd(a, b, C, 0, o, g.oc, B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2,
                                        stream);
+  }
   if (code != UNFLOW_OK) return code;
   return transpose_bcn(o, out, B, g.oh * g.ow, g.oc, s);
 }
@@ -340,17 +377,21 @@ UNFLOW_API int unflow_correlation_bwd(const float* dout, const float* in0, const
   float* d = gb + in_e;
   hipStream_t s = as_stream(stream);
   int code;
-  if ((code = transpose_bcn(in0, a, B, C, H * W, s)) != UNFLOW_OK) return code;
-  if ((code = transpose_bcn(in1, b, B, C, H * W, s)) != UNFLOW_OK) return code;
   if ((code = transpose_bcn(dout, d, B, g.oc, g.oh * g.ow, s)) != UNFLOW_OK) return code;
   unflow_planes pa, pb;
   const size_t used = (4 * in_e + out_e) * sizeof(float);
-  if (corr_ws_planes(g, a, b, d + out_e, workspace_bytes - used, B, C, H, W, &pa, &pb, stream))
+  if (corr_ws_planes(g, d + out_e, workspace_bytes - used, B, C, H, W, &pa, &pb)) {
+    // planes (and the fp32 copies the entry point falls back to when the planes kernel does not take the shape) in one pass
+    if ((code = transpose_to_planes(in0, pa, a, B, C, H * W, s)) != UNFLOW_OK) return code;
+    if ((code = transpose_to_planes(in1, pb, b, B, C, H * W, s)) != UNFLOW_OK) return code;
     code = unflow_correlation_nhwc_bwd_pl(d, g.oc, a, b, C, &pa, &pb, 0, ga, gb, C, 0, B, C, H, W, kernel_size, max_displacement, pad,
                                           stride_1, stride_2, stream);
-  else
+  } else {
+    if ((code = transpose_bcn(in0, a, B, C, H * W, s)) != UNFLOW_OK) return code;
+    if ((code = transpose_bcn(in1, b, B, C, H * W, s)) != UNFLOW_OK) return code;
     code = unflow_correlation_nhwc_bwd(d, g.oc, a, b, C, 0, ga, gb, C, 0, B, C, H, W, kernel_size, max_displacement, pad, stride_1,
                                        stride_2, stream);
+  }
   if (code != UNFLOW_OK) return code;
   if ((code = transpose_bcn(ga, grad0, B, H * W, C, s)) != UNFLOW_OK) return code;
   return transpose_bcn(gb, grad1, B, H * W, C, s);
