@@ -445,7 +445,11 @@ CORR_RS_CASES = [c for c in CORR_PL_CASES if c[4]['stride_2'] == 1 and c[4]['max
 
 
 @pytest.mark.parametrize("case", CORR_RS_CASES + [(4, 256, 21, 200, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),
-                                                   (2, 96, 10, 77, dict(kernel_size=1, max_displacement=3, pad=3, stride_1=1, stride_2=1))])
+                                                   (2, 96, 10, 77, dict(kernel_size=1, max_displacement=3, pad=3, stride_1=1, stride_2=1)),
+                                                   # the ring kernel (r = 4): one chunk, three chunks, pad > displacement
+                                                   (2, 32, 9, 50, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),
+                                                   (2, 96, 17, 33, dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)),
+                                                   (2, 64, 9, 40, dict(kernel_size=1, max_displacement=4, pad=6, stride_1=1, stride_2=1))])
 def test_correlation_planes_fwd_row_shared_and_narrow_band_kernels_vs_oracle(case, dev, oracle_lib, lib_option):
     """The +-4 / 81-channel cost volume (and r = 2, 3): the default kernels (r = 4: f1 rows streamed through an LDS ring, row
     groups of 8 with a ragged last group, 9 site tiles, a ragged last tile; r < 4: the row-shared kernel, groups of 4; C = 96:
