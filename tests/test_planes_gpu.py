@@ -624,7 +624,11 @@ def test_wgrad_planes_vs_fp64(case, dev, lib_option):
 
 @pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1),
                                   # narrow-band tiling (correlation_planes.hip: corr_pl_tiles)
-                                  (1, 64, 6, 131, 4, 1), (2, 64, 5, 100, 6, 1), (1, 128, 7, 101, 8, 2)])
+                                  (1, 64, 6, 131, 4, 1), (2, 64, 5, 100, 6, 1), (1, 128, 7, 101, 8, 2),
+                                  # C % 256 == 0 (band operand shared by the four channel-group waves of a workgroup): 3 site tiles at
+                                  # r = 4, the wide band at r = 10, odd row counts in both row classes, r = 4 in two classes, C = 512
+                                  (2, 256, 13, 70, 4, 1), (1, 256, 7, 30, 10, 1), (1, 256, 9, 40, 20, 2), (1, 256, 7, 101, 8, 2),
+                                  (1, 512, 6, 33, 8, 2)])
 def test_correlation_planes_bwd_vs_fp32_kernel(case, dev):
     """unflow_correlation_nhwc_bwd_pl (feature operand from the bf16 planes through LDS-DMA + transposing reads, band operand
     split in registers, six terms on the bf16 matrix cores) vs the fp32-MFMA backward of the same library (itself checked
@@ -652,3 +656,13 @@ def test_correlation_planes_bwd_vs_fp32_kernel(case, dev):
     check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(dout), oc, ptr(F.t), ptr(F.t), F.t.stride(2), None, None, B, ptr(g_ref),
                                                     ptr(None), C, 1, N, C, H, W, 1, md, md, 1, s2, stream()), "correlation_bwd")
     assert rel_err(g_pl, g_ref) < 2e-5
+    # the two gradients kept apart (grad0 / grad1 of the reference op), planes against fp32 kernels
+    ga, gb = torch.full((N, H, W, C), float('nan'), device=dev), torch.full((N, H, W, C), float('nan'), device=dev)
+    ra, rb = torch.zeros(N, H, W, C, device=dev), torch.zeros(N, H, W, C, device=dev)
+    check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(dout), oc, ptr(F.t), ptr(F.t), F.t.stride(2), _lib.planes_of(F.pl),
+                                                    _lib.planes_of(F.pl), B, ptr(ga), ptr(gb), C, 0, N, C, H, W, 1, md, md, 1, s2,
+                                                    stream()), "correlation_bwd_pl")
+    check(_lib.lib().unflow_correlation_nhwc_bwd_pl(ptr(dout), oc, ptr(F.t), ptr(F.t), F.t.stride(2), None, None, B, ptr(ra),
+                                                    ptr(rb), C, 0, N, C, H, W, 1, md, md, 1, s2, stream()), "correlation_bwd")
+    assert rel_err(ga, ra) < 2e-5 and rel_err(gb, rb) < 2e-5
+
