@@ -120,6 +120,41 @@ def test_correlation_flownetc_shape_full(dev, oracle_lib):
     close(tb.grad, g1, 2e-4)
 
 
+def test_correlation_reference_boundary_with_and_without_plane_room(dev, oracle_lib):
+    """unflow_correlation_fwd / _bwd (the reference op's NCHW boundary): with the workspace unflow_correlation_workspace_bytes
+    asks for, operand planes are built in it and the matrix-core kernels run; with the fp32 part alone the fp32 kernels do —
+    both against the oracle, and one byte less than the fp32 part is refused."""
+    import ctypes
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, ptr, stream
+    L = _lib.lib()
+    B, C, H, W = 2, 64, 10, 37
+    attrs = dict(kernel_size=1, max_displacement=4, pad=4, stride_1=1, stride_2=1)
+    args = (1, 4, 4, 1, 1)
+    rs = np.random.RandomState(11)
+    a = rs.randn(B, C, H, W).astype(np.float32)
+    b = rs.randn(B, C, H, W).astype(np.float32)
+    ref = oracle_lib.correlation(a, b, **attrs)
+    go = rs.randn(*ref.shape).astype(np.float32)
+    g0r, g1r = oracle_lib.correlation_grad(go, a, b, **attrs)
+    ta, tb, tg = t(a, dev), t(b, dev), t(go, dev)
+    full = L.unflow_correlation_workspace_bytes(B, C, H, W, *args)
+    fp32_part = (4 * a.size + ref.size) * 4
+    assert full > fp32_part
+    ws = torch.zeros(full // 4 + 64, device=dev)
+    for nbytes in (full, fp32_part):
+        out = torch.full(ref.shape, float('nan'), device=dev)
+        check(L.unflow_correlation_fwd(ptr(ta), ptr(tb), ptr(out), B, C, H, W, *args, ptr(ws), ctypes.c_size_t(nbytes), stream()))
+        close(out, ref, 1e-5)
+        g0, g1 = torch.full(a.shape, float('nan'), device=dev), torch.full(a.shape, float('nan'), device=dev)
+        check(L.unflow_correlation_bwd(ptr(tg), ptr(ta), ptr(tb), ptr(g0), ptr(g1), B, C, H, W, *args, ptr(ws), ctypes.c_size_t(nbytes),
+                                       stream()))
+        close(g0, g0r, 1e-4)
+        close(g1, g1r, 1e-4)
+    assert L.unflow_correlation_bwd(ptr(tg), ptr(ta), ptr(tb), ptr(g0), ptr(g1), B, C, H, W, *args, ptr(ws),
+                                    ctypes.c_size_t(fp32_part - 1), stream()) == -9
+
+
 # ---------------------------------------------------------------- warps vs oracle
 def _flows(rs, B, H, W, kind):
     if kind == "normal":
