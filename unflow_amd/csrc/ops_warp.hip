@@ -909,6 +909,46 @@ __global__ void downsample_kernel(const float* __restrict__ img, float* __restri
   }
 }
 
+// C = 3, scale 2 / 4 (the loss pyramid's own calls): one thread per OUTPUT PIXEL, each input row of its box as 3 S contiguous
+// floats in dword-aligned 16 / 8-byte buffer loads (4 or 12 load instructions per pixel instead of 12 or 48), the same
+// summation order per channel (rows outer, columns inner, one division) — bit-identical to downsample_kernel.  < 2 GiB.
+template <int S>
+__global__ __launch_bounds__(256) void downsample3_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H, int W) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (int)((long)B * H * W * 12), 0x00020000);
+  const int oh = H / S, ow = W / S;
+  const long n = (long)B * oh * ow;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % ow), oy = (int)((e / ow) % oh);
+    const int b = (int)(e / ((long)ow * oh));
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int yy = 0; yy < S; yy++) {
+      const int off = (((b * H + oy * S + yy) * W) + ox * S) * 12;
+      float v[3 * S];
+      if constexpr (S == 2) {
+        const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        const u2 c = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 16, 0, 0);
+        v[0] = __uint_as_float(a[0]); v[1] = __uint_as_float(a[1]); v[2] = __uint_as_float(a[2]); v[3] = __uint_as_float(a[3]);
+        v[4] = __uint_as_float(c[0]); v[5] = __uint_as_float(c[1]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16 * k, 0, 0);
+          v[4 * k] = __uint_as_float(a[0]); v[4 * k + 1] = __uint_as_float(a[1]);
+          v[4 * k + 2] = __uint_as_float(a[2]); v[4 * k + 3] = __uint_as_float(a[3]);
+        }
+      }
+#pragma unroll
+      for (int xx = 0; xx < S; xx++) { s0 += v[3 * xx]; s1 += v[3 * xx + 1]; s2 += v[3 * xx + 2]; }
+    }
+    const float inv = (float)(S * S);
+    float* o = out + e * 3;
+    o[0] = s0 / inv; o[1] = s1 / inv; o[2] = s2 / inv;
+  }
+}
+
 // The image pyramid of the loss (unsupervised.py:99-100,145-146: downsample(im, 4), then four times downsample(., 2)) in ONE
 // launch: a workgroup owns a 64 x 64 tile of the full-resolution image = 16 x 16 / 8 x 8 / 4 x 4 / 2 x 2 / 1 pixels of the five
 // levels; every level is the box mean of the previous level's VALUES with downsample_kernel's own summation order (rows outer,
@@ -987,6 +1027,11 @@ UNFLOW_API int unflow_downsample_fwd(const float* images, float* out, int B, int
   if (scale <= 0 || H % scale != 0 || W % scale != 0) return UNFLOW_ERR_NOT_DIVISIBLE;
   const long n = (long)B * (H / scale) * (W / scale) * C;
   if (n == 0) return UNFLOW_OK;
+  if (C == 3 && (scale == 2 || scale == 4) && (long)B * H * W * 12 < (1l << 31) - 64) {
+    if (scale == 2) downsample3_kernel<2><<<stream_grid(n / 3), 256, 0, as_stream(stream)>>>(images, out, B, H, W);
+    else downsample3_kernel<4><<<stream_grid(n / 3), 256, 0, as_stream(stream)>>>(images, out, B, H, W);
+    return launch_status();
+  }
   downsample_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(images, out, B, H, W, C, scale);
   return launch_status();
 }
