@@ -536,7 +536,6 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.acc ? 1 : p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id,
               split);
   if (t < 0) return;
-  const int mtile_id = t;
   // Tap classes of this block.  Output-parity classes (data gradient of a stride-2 conv, conv_transpose forward) write
   // different pixels: one class per block (cls_id).  ACCUMULATING classes (p.acc: forward of a stride-2 conv, data gradient
   // of a conv_transpose — source stride 2) all add into the same output tile: on the four parity sub-lattices of the source
