@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 // the shared per-stage barrier couples the 12 waves.  No MFMAs for sub-tiles beyond the last M / N tile: neutral.)
 template <int BN, int WN>
 __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
-  constexpr int BM = 128, WM = 64, NPL = 3, NT = 6, KS = 16;
+  constexpr int BM = 128, WM = 64, NPL = 3, KS = 16;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
