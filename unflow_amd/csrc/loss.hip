@@ -193,12 +193,15 @@ __device__ __forceinline__ void load_tile(float* __restrict__ lds, const float* 
   }
 }
 
-__device__ __forceinline__ void ternary_fwd_body(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                 const float* __restrict__ mask, int n_mask,
-                                                 float* __restrict__ wgt_out, float* __restrict__ loss_acc, float scale,
-                                                 int D, int N, int H, int W, unsigned vb, unsigned vg) {
-  __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW];
-  __shared__ float red[4];
+// DT: max_distance known at compile time (1..3: the reference's values, unsupervised.py:88; the tap loops unroll and their LDS
+// offsets become immediates), 0: the run-time value D.  The LDS tiles belong to the caller (one set per kernel, not per DT).
+template <int DT>
+__device__ __forceinline__ void ternary_fwd_body_t(float* __restrict__ t1, float* __restrict__ t2, float* __restrict__ red,
+                                                   const float* __restrict__ g1, const float* __restrict__ g2,
+                                                   const float* __restrict__ mask, int n_mask,
+                                                   float* __restrict__ wgt_out, float* __restrict__ loss_acc, float scale,
+                                                   int D_rt, int N, int H, int W, unsigned vb, unsigned vg) {
+  const int D = DT ? DT : D_rt;
   const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
   const int ntiles = tiles_x * tiles_y * N;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -216,8 +219,11 @@ __device__ __forceinline__ void ternary_fwd_body(const float* __restrict__ g1, c
     {
     const float c1 = t1[(ty + D) * CT_LW + tx + D], c2 = t2[(ty + D) * CT_LW + tx + D];
     float dist = 0.f;
-    for (int dy = 0; dy <= 2 * D; dy++)
-      for (int dx = 0; dx <= 2 * D; dx++) {
+#pragma unroll
+    for (int dy = 0; dy <= 2 * (DT ? DT : CT_MAXD); dy++)
+#pragma unroll
+      for (int dx = 0; dx <= 2 * (DT ? DT : CT_MAXD); dx++) {
+        if (!DT && (dy > 2 * D || dx > 2 * D)) continue;
         const float d = census_t(t1[(ty + dy) * CT_LW + tx + dx] - c1) - census_t(t2[(ty + dy) * CT_LW + tx + dx] - c2);
         const float d2 = d * d;
         dist += d2 * fast_rcp(0.1f + d2);
@@ -237,6 +243,19 @@ __device__ __forceinline__ void ternary_fwd_body(const float* __restrict__ g1, c
   const float t = block_sum(local, red);
   if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * scale);
 }
+__device__ __forceinline__ void ternary_fwd_body(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                 const float* __restrict__ mask, int n_mask,
+                                                 float* __restrict__ wgt_out, float* __restrict__ loss_acc, float scale,
+                                                 int D, int N, int H, int W, unsigned vb, unsigned vg) {
+  __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW];
+  __shared__ float red[4];
+  switch (D) {
+    case 1: ternary_fwd_body_t<1>(t1, t2, red, g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, vb, vg); break;
+    case 2: ternary_fwd_body_t<2>(t1, t2, red, g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, vb, vg); break;
+    case 3: ternary_fwd_body_t<3>(t1, t2, red, g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, vb, vg); break;
+    default: ternary_fwd_body_t<0>(t1, t2, red, g1, g2, mask, n_mask, wgt_out, loss_acc, scale, D, N, H, W, vb, vg); break;
+  }
+}
 __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                           const float* __restrict__ mask, int n_mask,
                                                           float* __restrict__ wgt_out, float* __restrict__ loss_acc,
@@ -247,12 +266,14 @@ __global__ __launch_bounds__(256) void ternary_fwd_kernel(const float* __restric
 // Gather form: d/dG2(q) = sum_e f(q, q+e) * (Wt(q+e) + Wt(q)), see DESIGN.md (census backward).
 // With `im` non-null the pixel's d(loss)/d(gray2w) goes straight into the flow gradient (warp_gray_bwd_pixel) instead of
 // (or in addition to) the dg2 plane: one launch and one [N,H,W] round trip less per pyramid level.
-__device__ __forceinline__ void ternary_bwd_body(const float* __restrict__ g1, const float* __restrict__ g2,
-                                                 const float* __restrict__ wgt, float* __restrict__ dg2, int D, int N,
-                                                 int H, int W, const float* __restrict__ im, int ld,
-                                                 const float* __restrict__ flow, float fscale, float* __restrict__ dflow,
-                                                 int acc, int shift, unsigned tile) {
-  __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW], tw[CT_LH * CT_LW];
+template <int DT>
+__device__ __forceinline__ void ternary_bwd_body_t(float* __restrict__ t1, float* __restrict__ t2, float* __restrict__ tw,
+                                                   const float* __restrict__ g1, const float* __restrict__ g2,
+                                                   const float* __restrict__ wgt, float* __restrict__ dg2, int D_rt, int N,
+                                                   int H, int W, const float* __restrict__ im, int ld,
+                                                   const float* __restrict__ flow, float fscale, float* __restrict__ dflow,
+                                                   int acc, int shift, unsigned tile) {
+  const int D = DT ? DT : D_rt;
   const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
   const int n = (int)tile / (tiles_x * tiles_y), tr = (int)tile - n * tiles_x * tiles_y;
   const int x0 = (tr % tiles_x) * CT_W, y0 = (tr / tiles_x) * CT_H;
@@ -265,8 +286,11 @@ __device__ __forceinline__ void ternary_bwd_body(const float* __restrict__ g1, c
   if (x >= W || y >= H) return;
   const float q1 = t1[(ty + D) * CT_LW + tx + D], q2 = t2[(ty + D) * CT_LW + tx + D], wq = tw[(ty + D) * CT_LW + tx + D];
   float grad = 0.f;
-  for (int dy = 0; dy <= 2 * D; dy++)
-    for (int dx = 0; dx <= 2 * D; dx++) {
+#pragma unroll
+  for (int dy = 0; dy <= 2 * (DT ? DT : CT_MAXD); dy++)
+#pragma unroll
+    for (int dx = 0; dx <= 2 * (DT ? DT : CT_MAXD); dx++) {
+      if (!DT && (dy > 2 * D || dx > 2 * D)) continue;
       const int yy = y + dy - D, xx = x + dx - D;
       if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;   // no centre pixel there
       const float ws = tw[(ty + dy) * CT_LW + tx + dx] + wq;
@@ -282,6 +306,19 @@ __device__ __forceinline__ void ternary_bwd_body(const float* __restrict__ g1, c
   const unsigned i = (unsigned)(((long)n * H + y) * W + x);
   if (dg2) dg2[i] = grad;
   if (im) warp_gray_bwd_pixel(grad, im, ld, flow, fscale, dflow, acc, shift, N, H, W, i, x, y, n);
+}
+__device__ __forceinline__ void ternary_bwd_body(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                 const float* __restrict__ wgt, float* __restrict__ dg2, int D, int N,
+                                                 int H, int W, const float* __restrict__ im, int ld,
+                                                 const float* __restrict__ flow, float fscale, float* __restrict__ dflow,
+                                                 int acc, int shift, unsigned tile) {
+  __shared__ float t1[CT_LH * CT_LW], t2[CT_LH * CT_LW], tw[CT_LH * CT_LW];
+  switch (D) {
+    case 1: ternary_bwd_body_t<1>(t1, t2, tw, g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, tile); break;
+    case 2: ternary_bwd_body_t<2>(t1, t2, tw, g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, tile); break;
+    case 3: ternary_bwd_body_t<3>(t1, t2, tw, g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, tile); break;
+    default: ternary_bwd_body_t<0>(t1, t2, tw, g1, g2, wgt, dg2, D, N, H, W, im, ld, flow, fscale, dflow, acc, shift, tile); break;
+  }
 }
 __global__ __launch_bounds__(256) void ternary_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                           const float* __restrict__ wgt, float* __restrict__ dg2, int D,
