@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU work (compiles the whole library to assembly); deselect with -m 'not slow'")
 
 
 @pytest.fixture(scope="session")

@@ -196,9 +196,9 @@ def test_trainer_run_resume_and_save_arithmetic(tmp_path):
 
     class Fake(Trainer):
         def __init__(self, params):
-            self.params, self.rank, self.iteration = dict(params), 0, 0
+            self.params, self.rank, self.world, self.iteration = dict(params), 0, 1, 0
             self.steps, self.saved, self.offsets = [], [], []
-            self.engine = type('E', (), {'step_count': 0, 'check_device_faults': lambda self: 0})()
+            self.engine = type('E', (), {'step_count': 0, 'check_device_faults': lambda self, world_sync=False: 0})()
 
         def train_step(self, im1, im2, augment=None):
             self.steps.append((self.iteration, int(im1)))

@@ -12,7 +12,9 @@ lanes per row per cycle) in a few hundred to a few thousand stores per launch, t
 usage: isa_store_hazard.py file.s [...]         (exit status 1 if any site is found)
        isa_store_hazard.py --build              (compile every csrc/*.hip to assembly with the library's flags and scan)
 A site = a buffer store of > 64 data bits with an SGPR soffset whose data VGPRs are written by one of the next WINDOW
-instructions (s_nop N counts as N + 1)."""
+instructions (s_nop N counts as N + 1).
+Limitation: the scan follows the LISTING (straight-line code after the store, through labels); a store that is the last
+instruction before a taken branch is checked against the fall-through instructions, not against the branch target's."""
 import glob
 import os
 import re

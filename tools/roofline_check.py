@@ -10,8 +10,8 @@ import csv
 import sys
 from collections import defaultdict
 
-FAMILY = ('igemm_gather_kernel', 'igemm_wgrad', 'splitk_reduce_epilogue', 'sum_partials', 'head3_', 'skinny_conv',
-          'tiny_deconv')
+FAMILY = ('igemm_', 'conv_first7', 'splitk_reduce', 'sum_partials', 'head3_', 'skinny', 'tiny_deconv', 'pointwise32',
+          'flow_wgrad', 'colsum', 'deconv_sib', 'fillBuffer')
 
 
 def short(name):
@@ -37,7 +37,7 @@ def main():
             continue
         t = per_step[k] * avg.get(k, 0.0) / 1e3
         total += t
-        if 'igemm' in k:
+        if 'igemm' in k or 'conv_first7' in k:
             mfma += t
         print("%-62s %5d %10.1f %10.1f" % (k[:62], per_step[k], avg.get(k, 0.0) / 1e3, t))
     print("conv family: %.3f ms/step -> %.1f TFLOP/s for %.1f algorithmic GFLOP (compare with roofline.achieved of the "

@@ -29,7 +29,6 @@ import torch
 
 from .. import _lib
 from .._lib import check, ptr, stream, cf, cl
-from ..ops import workspace
 from . import layers as L
 
 FLOW_SCALE = 5.0                                   # flownet.py:11
@@ -933,7 +932,7 @@ class FlowNetEngine:
                 if need_fwarp:      # forward_warp(flow*scale) (losses.py:28-29), deterministic accumulation
                     check(lib.unflow_scale(ptr(flow), cf(fs), ptr(lv['fscaled']), cl(flow.numel()), st), "scale")
                     fwm = lv['fwmap']
-                    ws = workspace(lib.unflow_forward_warp_workspace_bytes(N, h, w, 1), self.dev, slot=2)
+                    ws = lv['fwws']      # this engine's own scratch (see _level_extra), never the shared grow-only one
                     check(lib.unflow_forward_warp_fwd(ptr(lv['fscaled']), ptr(fwm), N, h, w, 1, ptr(ws),
                                                       _lib.csz(ws.numel() * 4), st), "forward_warp")
                 a = acc() if (with_grad and wt('fb')) else 0
@@ -1013,6 +1012,12 @@ class FlowNetEngine:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
         lv.update(maskN=z(N, h, w), fwarped=z(N, h, w, 2), gwarped=z(N, h, w, 2), dimtmp=z(N, h, w, 2),
                   fscaled=z(N, h, w, 2), fwmap=z(N, h, w), imw=z(N, h, w, 3), gdiff=z(N, h, w, 6), dimw=z(N, h, w, 3))
+        # forward_warp's scratch is owned by the engine (sized here, before any capture): the module-global grow-only
+        # workspace of ops.py is shared by every engine of the process — a second, larger engine (Trainer.eval's 1 x 384 x
+        # 1280 one beside a small-crop training engine) would re-allocate it under this engine's captured graphs
+        lib = _lib.lib()
+        lib.unflow_forward_warp_workspace_bytes.restype = _lib.ctypes.c_size_t
+        lv['fwws'] = torch.empty(int(lib.unflow_forward_warp_workspace_bytes(N, h, w, 1)) // 4 + 64, dtype=torch.float32, device=self.dev)
 
     # ------------------------------------------------------------------ backward
     def backward_net(self, part=None):
@@ -1158,15 +1163,31 @@ class FlowNetEngine:
                                           cl(self.n_weights), cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1),
                                           cf(beta2), cf(eps), self.stream()), "adam")
 
-    def check_device_faults(self):
+    def check_device_faults(self, world_sync=False):
         """Sticky device-side fault counters of the library, read (and cleared) with a host sync: the bounded spins of the
         stream-K fix-up (csrc/conv_streamk.hip: a waiter that gave up has added a slab that was never written, so an
         output tile of that launch is WRONG).  Raises instead of returning a count: callers sit at points where the host
-        synchronises anyway (Trainer's display interval and checkpoint, the end of bench.py's timed region)."""
-        n = _lib.lib().unflow_debug_streamk_timeouts()
+        synchronises anyway (Trainer's display interval and checkpoint, the end of bench.py's timed region).  world_sync: in a
+        multi-rank run, agree on the outcome first (one small all-reduce) so that all ranks raise or none does."""
+        import contextlib
+        with (torch.cuda.device(self.dev) if self.dev.type == 'cuda' else contextlib.nullcontext()):
+            n = _lib.lib().unflow_debug_streamk_timeouts()      # the counter is a per-device symbol: read THIS engine's device
+        if world_sync:
+            # every rank raises together (a lone raise in front of a collective leaves the other ranks hanging in it): the
+            # MAX over ranks of (count, read failure)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                t = torch.tensor([max(n, 0), 1 if n < 0 else 0], dtype=torch.int64,
+                                 device=self.dev if dist.get_backend() == 'nccl' else 'cpu')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                n = -1 if int(t[1]) else int(t[0])
+        if n < 0:
+            raise RuntimeError("stream-K conv kernels: the device-side fault counter could not be read (hipMemcpyFromSymbol "
+                               "failed on %s, or on another rank) — the state of the run is unknown" % (self.dev,))
         if n != 0:
-            raise RuntimeError("stream-K conv kernels: %d fix-up wait(s) timed out since the last check — results of those "
-                               "launches are wrong; set UNFLOW_OPT_STREAMK=0 and report" % n)
+            raise RuntimeError("stream-K conv kernels: %d fix-up wait(s) timed out since the last check%s — results of those "
+                               "launches are wrong; set UNFLOW_OPT_STREAMK=0 and report"
+                               % (n, " (max over ranks)" if world_sync else ""))
         return 0
 
     # ------------------------------------------------------------------ composite

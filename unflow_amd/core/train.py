@@ -348,12 +348,19 @@ class Trainer:
             loss = self.train_step(im1, im2)
             if i == 1 or i % display == 0:
                 loss = float(loss)
-                self.engine.check_device_faults()       # the host has just synchronised on the loss: read the fault counters
+                self._check_faults()                    # the host has just synchronised on the loss: read the fault counters
                 log.append((i, loss))
                 print("-- train: i = {}, loss = {}".format(i, loss))
-        self.engine.check_device_faults()               # never checkpoint a run whose kernels reported a fault
+        self._check_faults()                            # never checkpoint a run whose kernels reported a fault
         self.save(ckpt_dir, max_iter)
         return log
+
+    def _check_faults(self):
+        """Device fault counters, agreed over the ranks (every rank reaches this at the same iterations): with more than one
+        rank the library's own communicator is drained first, then one MAX all-reduce — all ranks raise, or none."""
+        if self.world > 1 and self.runner.reducer is not None:
+            self.runner.reducer.quiesce()
+        self.engine.check_device_faults(world_sync=self.world > 1)
 
     def train_step(self, im1, im2, augment=None):
         """sess.run([train_op, loss_]) (train.py:247-251): returns the loss tensor (device, no sync).  `augment`: None = the

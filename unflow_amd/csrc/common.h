@@ -20,6 +20,27 @@ static inline int launch_status() {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives several GPUs must
+// set it on each of them before launching with more than 64 KB of dynamic LDS.  Grow-only book per call site (`set`: one
+// slot per device ordinal, zero-initialised static of the caller); the runtime call happens once per (kernel, device, size
+// increase), afterwards this is a hipGetDevice and a compare.  Returns the runtime's status: a kernel that has a fallback
+// takes it when the set fails, the others report the failure through launch_status().  (A benign race between two host
+// threads of one process: both set the same value.)
+constexpr int UNFLOW_MAX_DEVICES = 64;
+struct DynLdsBook {
+  int set[UNFLOW_MAX_DEVICES];
+};
+static inline hipError_t ensure_dyn_lds(const void* kernel, int bytes, DynLdsBook& book) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= UNFLOW_MAX_DEVICES) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (bytes <= book.set[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) book.set[dev] = bytes;
+  return e;
+}
+
 // Grid size for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8,
 // capped (cdna guide, guideline 11).
 static inline int stream_grid(long work_items, int block = 256) {

@@ -286,9 +286,8 @@ int conv_first7_fwd(const unflow_planes* x_pl, const unflow_planes* w_pl, const 
   p.tiles_y = (Ho + F_TH - 1) / F_TH; p.tiles_x = (Wo + F_TW - 1) / F_TW;
   p.ntiles = B * p.tiles_y * p.tiles_x;
   p.leaky = leaky;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first7_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
-  (void)attr;
+  static DynLdsBook attr_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&conv_first7_kernel), F_SMEM, attr_book);
   const int grid = p.ntiles < first7_cus() ? p.ntiles : first7_cus();
   conv_first7_kernel<<<grid, 512, F_SMEM, st>>>(p);
   return launch_status();

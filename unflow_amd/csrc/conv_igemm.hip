@@ -1785,9 +1785,8 @@ int launch_gather_cfg(const GatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
   const size_t smem = (MATH ? (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short) : (size_t)(BM + BN) * LDK * sizeof(float)) +
                       BM * sizeof(int);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
-  (void)attr;
+  static DynLdsBook attr_book{};   // once per instantiation
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH>), (int)smem, attr_book);
   dim3 grid(cdiv(M, BM), cdiv(p.N, BN), p.ncls * p.nsplit);
   igemm_gather_kernel<BM, BN, WM, WN, B_NK, MATH><<<grid, 256, smem, st>>>(p);
   return launch_status();
@@ -1828,9 +1827,8 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad_b3_cfg(const WgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const size_t smem = (size_t)3 * (BM + BN) * LDH * sizeof(unsigned short);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_b3_kernel<BM, BN, WM, WN>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
-  (void)attr;
+  static DynLdsBook attr_book{};   // once per instantiation
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_wgrad_b3_kernel<BM, BN, WM, WN>), (int)smem, attr_book);
   dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
   igemm_wgrad_b3_kernel<BM, BN, WM, WN><<<grid, 256, smem, st>>>(p);
   return launch_status();
@@ -1840,9 +1838,8 @@ template <int BM, int BN, int WM, int WN>
 int launch_wgrad_cfg(const WgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const size_t smem = (size_t)(BK * BM + BK * BN) * sizeof(float);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM, BN, WM, WN>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // once per instantiation
-  (void)attr;
+  static DynLdsBook attr_book{};   // once per instantiation
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM, BN, WM, WN>), (int)smem, attr_book);
   dim3 grid(cdiv(Mp, BM), cdiv(p.Cb, BN), p.nsplit);
   igemm_wgrad_kernel<BM, BN, WM, WN><<<grid, 256, smem, st>>>(p);
   return launch_status();

@@ -1722,9 +1722,8 @@ template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
   const int smem = pl_smem_gather(BM, BN, NPL);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  (void)attr;
+  static DynLdsBook attr_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_gather_kernel<BM, BN, WM, WN, NPL, F16>), smem, attr_book);
   PlGatherParams q = p;
   q.mt = cdiv(M, BM); q.nt = cdiv(p.N, BN);
   pl_gather_tiles2d<BM>(q);
@@ -1737,9 +1736,8 @@ int launch_pl_gather(const PlGatherParams& p, hipStream_t st) {
 int launch_pl_gather_pp(const PlGatherParams& p, hipStream_t st) {
   const int M = p.B * p.Hg * p.Wg;
   constexpr int smem = 6 * 3 * 128 * 32 * 2 + 2 * 128 * 4;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_gather_pp_kernel<3, false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  (void)attr;
+  static DynLdsBook attr_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_gather_pp_kernel<3, false>), smem, attr_book);
   PlGatherParams q = p;
   q.mt = cdiv(M, 128); q.nt = cdiv(p.N, 128);
   pl_gather_tiles2d<128>(q);
@@ -1804,12 +1802,8 @@ template <int BN, int WN, int NPL, bool F16>
 int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   const int hp = pl_halo_pixels(p);
   const int smem = pl_halo_main_bytes(BN, WN, NPL, hp) + 128 * 4 + 16;
-  static int smem_set = 0;      // grow-only (the halo size depends on the layer): benign race, idempotent
-  if (smem > smem_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, 64, WN, NPL, F16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    smem_set = smem;
-  }
+  static DynLdsBook book{};     // grow-only per device (the halo size depends on the layer)
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, 64, WN, NPL, F16>), smem, book);
   PlGatherParams q = p;
   q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
   const int grid = pl_grid(q);
@@ -1913,9 +1907,8 @@ template <int BM, int BN, int WM, int WN, int NPL, bool F16>
 int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = NPL * (BM + BN) * BK * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  (void)attr;
+  static DynLdsBook attr_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16>), smem, attr_book);
   PlWgradParams q = p;
   q.mt = cdiv(Mp, BM); q.nt = cdiv(p.Cb, BN);
   igemm_pl_wgrad_kernel<BM, BN, WM, WN, NPL, F16><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
@@ -1926,9 +1919,8 @@ template <int BN, int WN>
 int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = 2 * 3 * (128 + BN) * 16 * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  (void)attr;
+  static DynLdsBook attr_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN>), smem, attr_book);
   PlWgradParams q = p;
   q.mt = cdiv(Mp, 128); q.nt = cdiv(p.Cb, BN);
   igemm_pl_wgrad_dma_kernel<BN, WN><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
@@ -1939,9 +1931,8 @@ template <int BN>
 int launch_pl_wgrad_pp(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = 3 * 3 * (256 + BN) * 16 * 2;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_wgrad_pp_kernel<BN>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  (void)attr;
+  static DynLdsBook attr_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_pp_kernel<BN>), smem, attr_book);
   PlWgradParams q = p;
   q.mt = cdiv(Mp, 256); q.nt = cdiv(p.Cb, BN);
   igemm_pl_wgrad_pp_kernel<BN><<<q.mt * q.nt * p.nsplit, 512, smem, st>>>(q, (unflow::options().wgrad_pp & 1) ? 0 : 1);

@@ -458,12 +458,9 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
   if (!ws || ws_bytes < pl_halo_sk_ws_bytes()) return UNFLOW_ERR_WORKSPACE;
   const int hp = pl_halo_pixels(p);
   const int smem = pl_halo_sk_smem(p);
-  static int smem_set = 0;
-  if (smem > smem_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    smem_set = smem;
-  }
+  static DynLdsBook book_a{}, book_b{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false, false>), smem, book_a);
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_sk_kernel<3, false, true>), smem, book_b);
   PlGatherParams q = p;
   q.nsplit = 1; q.partial = nullptr;
   SkPlan sk{};

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void corr_fwd_rs_kernel(const CorrPlParams 
 // of 0.90) and the kernel is slower, 218 against 206 us; odd row groups run bottom-up so that vertical neighbours ask for their
 // shared rows at the same step: no fewer bytes.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int RG_R = 8, RG_GW = 9, RG_ROWS = RG_R + RG_GW - 1, RG_NS = 24;
+constexpr int RG_R = 8, RG_GW = 9, RG_NS = 24;       // 16 = RG_R + RG_GW - 1 f1 rows per chunk
 constexpr int RG_SLOT = 3 * 32 * 64;                    // bytes per slot
 constexpr int RG_SMEM = RG_NS * RG_SLOT;                // 147,456 B; the epilogue's band staging (8 x 24 x 81 floats) reuses it
 
@@ -578,6 +578,15 @@ __global__ __launch_bounds__(512, 1) void corr_fwd_ring_kernel(const CorrPlParam
   request_a(0);
   request(2, 0, 0);
   request(3, 0, 0);
+  // The fragment registers are loop-carried and the compiler knows nothing about loads issued by inline asm: whatever copy it
+  // needs for the loop phi (it did place `v_mov_b64 v[108:131] <- v[132:155]` at the END of the body, before any covering
+  // wait: ADVICE round 5) must come AFTER the data has landed.  VGPR reads are not interlocked with VMEM returns, so the
+  // values enter the loop — here and at the end of the body — only through a wait that is tied to them: vmcnt(6) leaves the
+  // two youngest row requests (steps 4 and 8: 3 + 3 DMA loads) in flight.  tools/isa_load_hazard.py scans the assembly for it.
+#define RG_LAND_FRAGMENTS()                                                                                                     \
+  asm volatile("s_waitcnt vmcnt(6)"                                                                                              \
+               : "+v"(afn[0][0]), "+v"(afn[0][1]), "+v"(afn[0][2]), "+v"(afn[1][0]), "+v"(afn[1][1]), "+v"(afn[1][2])::"memory")
+  RG_LAND_FRAGMENTS();
   int cb = 0;                                          // (16 c) mod 24
   for (int c = 0; c < nchunk; c++) {
     int cbn = cb + 16;
@@ -621,7 +630,9 @@ __global__ __launch_bounds__(512, 1) void corr_fwd_ring_kernel(const CorrPlParam
                                                               __builtin_bit_cast(bf16x8, bf[j & 1][pct[pr]][tb[tt]]), acc[j][pr], 0, 0, 0);
     }
     cb = cbn;
+    RG_LAND_FRAGMENTS();                               // (issued at step 0, nine steps of products ago: this does not stall)
   }
+#undef RG_LAND_FRAGMENTS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the out-of-range requests past the last chunk write zeros: let them land
   __syncthreads();                                     // the ring is dead: its LDS becomes the band staging
   // acc[j][pr][e] of lane (column l15, quarter q) is the product of f0 site s0 = 16 rt + 4 q + e and staged site s1 = 16 ct + l15
@@ -1587,20 +1598,19 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   const bool al16 = in0->ld % 8 == 0 && ((reinterpret_cast<uintptr_t>(in0->base) | reinterpret_cast<uintptr_t>(in1->base)) & 15) == 0;
   if (p.joff != 0 && g.s2 == 1 && g.r == 4 && p.vr == 24 && C % 32 == 0 && al16 && unflow::options().corr_rs >= 2) {
     // the +-4 cost volume: f1 rows streamed through an LDS ring, one 8-row workgroup per CU
-    static const hipError_t rg_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_ring_kernel),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, RG_SMEM);
-    (void)rg_attr;
-    corr_fwd_ring_kernel<<<B * p.nA * ((g.oh + RG_R - 1) / RG_R), 512, RG_SMEM, st>>>(p);
-    return launch_status();
+    static DynLdsBook rg_book{};
+    if (ensure_dyn_lds(reinterpret_cast<const void*>(&corr_fwd_ring_kernel), RG_SMEM, rg_book) == hipSuccess) {
+      corr_fwd_ring_kernel<<<B * p.nA * ((g.oh + RG_R - 1) / RG_R), 512, RG_SMEM, st>>>(p);
+      return launch_status();
+    }
+    (void)hipGetLastError();       // 147 KB of LDS refused on this device: the row-shared kernel below
   }
   if (p.joff != 0 && g.s2 == 1 && g.r >= 1 && g.r <= 4 && p.vr == 32 - 2 * g.r && C % 32 == 0 && al16 && unflow::options().corr_rs) {
     // rows shared by a workgroup (4 output rows, double-buffered chunks of 32 channels): a third of the narrow-band kernel's f1 traffic
-    static const hipError_t rs_attr[4] = {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM),
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rs_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_SMEM)};
-    (void)rs_attr;
+    static DynLdsBook rs_book[4]{};
+    const void* rs_fn[4] = {reinterpret_cast<const void*>(&corr_fwd_rs_kernel<3>), reinterpret_cast<const void*>(&corr_fwd_rs_kernel<5>),
+                            reinterpret_cast<const void*>(&corr_fwd_rs_kernel<7>), reinterpret_cast<const void*>(&corr_fwd_rs_kernel<9>)};
+    (void)ensure_dyn_lds(rs_fn[g.r - 1], RS_SMEM, rs_book[g.r - 1]);
     const int rs_grid = B * p.nA * ((g.oh + RS_R - 1) / RS_R);
     switch (g.gw) {
       case 3: corr_fwd_rs_kernel<3><<<rs_grid, 256, RS_SMEM, st>>>(p); break;
@@ -1615,12 +1625,8 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
     // instruction moves 8 whole cache lines)
     const int nw = C / 64;
     const int nb_smem = nw * (3 * 32 * 64 * 2 + g.gw * p.vr * g.gw * 4);
-    static int nb_set = 0;
-    if (nb_smem > nb_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_nb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                nb_smem);
-      nb_set = nb_smem;
-    }
+    static DynLdsBook nb_book{};
+    (void)ensure_dyn_lds(reinterpret_cast<const void*>(&corr_fwd_nb_kernel), nb_smem, nb_book);
     corr_fwd_nb_kernel<<<B * p.nA * g.s2 * g.oh, 64 * nw, nb_smem, st>>>(p);
     return launch_status();
   }
@@ -1628,11 +1634,9 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
   if (p.joff == 0 && (C == 128 || C == 256) && al16 && g.r <= 15 && out_bytes <= 0x3fffffffu && unflow::options().corr_rw) {
     const int npr = ((g.oh + g.s2 - 1) / g.s2 + RW_ROWS - 1) / RW_ROWS;      // groups of RW_ROWS rows per row class
     const int smem = 2 * (C / 64) * (3 * 32 * 64 * 2) + 8 * 4096;             // two tiles + the waves' accumulator slots
-    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rw_kernel<1>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 12288 + 8 * 4096);
-    static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_rw_kernel<2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 12288 + 8 * 4096);
-    (void)a1; (void)a2;
+    static DynLdsBook rw_book[2]{};
+    (void)ensure_dyn_lds(C == 128 ? reinterpret_cast<const void*>(&corr_fwd_rw_kernel<1>) : reinterpret_cast<const void*>(&corr_fwd_rw_kernel<2>),
+                         smem, rw_book[C == 128 ? 0 : 1]);
     const int blocks = B * g.s2 * p.nA * g.s2 * npr;
     if (C == 128) corr_fwd_rw_kernel<1><<<blocks, 512, smem, st>>>(p);
     else corr_fwd_rw_kernel<2><<<blocks, 512, smem, st>>>(p);
@@ -1642,19 +1646,14 @@ int corr_pl_fwd(const unflow_planes* in0, const unflow_planes* in1, int shift, f
     const int nw = C / 64;
     const int npr = ((g.oh + g.s2 - 1) / g.s2 + 1) / 2;       // row pairs (oy, oy + s2) per row class
     constexpr int per_wave = 3 * 32 * 64 * 2 + 2 * 32 * 32 * 4;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_wb_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * per_wave);
-    (void)attr;
+    static DynLdsBook attr_book{};
+    (void)ensure_dyn_lds(reinterpret_cast<const void*>(&corr_fwd_wb_kernel), 4 * per_wave, attr_book);
     corr_fwd_wb_kernel<<<B * g.s2 * p.nA * g.s2 * npr, 64 * nw, nw * per_wave, st>>>(p);
     return launch_status();
   }
   const int smem = 3 * 32 * (C + 8) * 2;
-  static int smem_set = 0;   // grow-only: benign race, idempotent
-  if (smem > smem_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              smem);
-    smem_set = smem;
-  }
+  static DynLdsBook pl_book{};
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&corr_fwd_pl_kernel), smem, pl_book);
   const int blocks = B * p.nA * g.s2 * g.oh;
   corr_fwd_pl_kernel<<<blocks, 256, smem, st>>>(p);
   return launch_status();
@@ -1682,12 +1681,9 @@ int corr_pl_bwd(const float* dout, int ld_dout, const unflow_planes* in0, const 
   p.dout_total = dbytes;
   const bool share = (C / 64) % 4 == 0 && dbytes < ((size_t)1 << 30) && unflow::options().corr_bwd_share;
   const int smem = 4 * 3 * 32 * 64 * 2 + (share ? 32 * BAND_PITCH * 4 : 0);
-  static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel<false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 3 * 32 * 64 * 2);
-  static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_pl_kernel<true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      4 * 3 * 32 * 64 * 2 + 32 * BAND_PITCH * 4);
-  (void)attr0; (void)attr1;
+  static DynLdsBook bwd_book[2]{};
+  (void)ensure_dyn_lds(share ? reinterpret_cast<const void*>(&corr_bwd_pl_kernel<true>) : reinterpret_cast<const void*>(&corr_bwd_pl_kernel<false>),
+                       smem, bwd_book[share ? 1 : 0]);
   const long jobs = (long)(C / 64) * B * p.nA * g.s2 * H;
   dim3 grid((unsigned)((jobs + 3) / 4), fuse ? 1 : 2);
   if (share) corr_bwd_pl_kernel<true><<<grid, 256, smem, st>>>(p);

@@ -21,13 +21,18 @@ OP_NAMES = ['backward_warp', 'downsample', 'correlation', 'forward_warp']  # ops
 _CORR_DEFAULTS = dict(kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2)  # correlation_op.cc:136-140
 
 _ws = {}
+_ws_retired = []      # outgrown buffers stay allocated: a captured hipGraph may still hold their address
 
 
 def workspace(nbytes, device, slot=0):
-    """Grow-only per-device scratch buffer (the library never allocates)."""
+    """Grow-only per-device scratch buffer (the library never allocates).  A buffer that is outgrown is RETIRED, not freed:
+    launches captured into a hipGraph keep replaying with the address they were captured with (a second, larger engine in
+    the same process — Trainer.eval's beside a small-crop training engine — must not pull the scratch from under them)."""
     key = (device.index, slot)
     t = _ws.get(key)
     if t is None or t.numel() * 4 < nbytes:
+        if t is not None:
+            _ws_retired.append(t)
         t = torch.empty((int(nbytes) + 3) // 4 + 64, dtype=torch.float32, device=device)
         _ws[key] = t
     return t
