@@ -37,8 +37,6 @@ BF16X3_TERMS = 6                    # product terms of the fp32-equivalent 3-way
 CONV_MATH_TEXT = {
     "bf16x3": "conv fwd/dgrad/wgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on the bf16 MFMA, "
               "operands pre-split into planes by their producers (csrc/conv_planes.hip) — same error class as the fp32 MFMA",
-    "bf16x3_inline": "conv fwd/dgrad/wgrad: fp32-equivalent 3-way bf16 split (6 product terms, fp32 accumulate) on the bf16 "
-                     "MFMA, split while staging fp32 operands (csrc/conv_igemm.hip)",
     "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere",
     "f16": "fp16 activations and weights into v_mfma_f32_32x32x16_f16, fp32 accumulate (NOT fp32-equivalent: BASELINE "
            "configs[4]; tolerance vs the fp32 oracle stated in tests/test_f16_gpu.py)",
@@ -281,7 +279,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = measure_roofline(eng, args)
-    if rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C' and eng.math in ("bf16x3", "bf16x3_inline"):
+    if rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C' and eng.math == "bf16x3":
         out["value_fp32_mfma_only"] = measure_alt_fp32(args)      # same step with every conv kernel on the fp32 MFMA
     if rank == 0 and world == 1 and not args.no_secondary and (args.flownet, args.dtype, H, W) == ('C', 'f32', 384, 512):
         out["secondary"] = measure_secondary(args)
@@ -363,8 +361,8 @@ def measure_roofline(eng, args):
     # bf16 peak / 6 product terms; UNFLOW_WGRAD_MATH=fp32 / UNFLOW_CONV_MATH=fp32 put the latter / both on
     # v_mfma_f32_32x32x2_f32.
     f16 = eng.math == "f16"
-    bf16x3 = eng.math in ("bf16x3", "bf16x3_inline")
-    wg_b3 = bf16x3 and (eng.math == "bf16x3" or os.environ.get("UNFLOW_WGRAD_MATH", "bf16x3") != "fp32")
+    bf16x3 = eng.math == "bf16x3"
+    wg_b3 = bf16x3
     g_peak = BF16_MFMA_PEAK_TFLOPS if f16 else BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if bf16x3 else FP32_MFMA_PEAK_TFLOPS
     w_peak = BF16_MFMA_PEAK_TFLOPS if f16 else BF16_MFMA_PEAK_TFLOPS / BF16X3_TERMS if wg_b3 else FP32_MFMA_PEAK_TFLOPS
     peak = 1.0 / ((2.0 / 3.0) / g_peak + (1.0 / 3.0) / w_peak)
@@ -507,6 +505,7 @@ def measure_secondary(args):
              "loss rel <= 2e-4, final-flow EPE <= 1e-3 px vs the fp64 oracle (tests/test_parity_fullsize_gpu.py::"
              "test_flownetc_b4_384x512_kitti_loss_variant_vs_fp64_oracle)")]
     out = []
+    out.append(measure_ops())
     for name, extra, tol in cfgs:
         try:
             r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
@@ -523,6 +522,23 @@ def measure_secondary(args):
         except Exception as ex:
             out.append({"config": name, "value": None, "error": repr(ex)[:300]})
     return out
+
+
+def measure_ops():
+    """The HBM-family roofline in the driver's own line: `python bench_ops.py --driver` (a sub-process; <= 3 s of GPU time) — the
+    warps, downsample and Adam at 16 x 768 x 1024 / 39.2 M parameters, both correlation points (FlowNetC's 441 channels at the
+    step's shape; the north star's +-4 / 81 channels at 16 x 96 x 128 x 256), each with SURVEY 8(d)'s fp32 algorithmic bytes, the
+    median of 20 HIP-event timings and the fraction of 8 TB/s (correlation rows also TFLOP/s; their plane-format bytes separately)."""
+    import subprocess
+    name = "op-level rooflines (bench_ops.py --driver): algorithmic bytes per SURVEY 8(d) / median time, fraction of the 8 TB/s HBM peak"
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_ops.py"), "--driver"], capture_output=True, text=True, timeout=600)
+        rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"op"')]
+        if not rows:
+            raise RuntimeError("no rows: " + r.stderr[-300:])
+        return {"config": name, "ops": rows}
+    except Exception as ex:
+        return {"config": name, "ops": None, "error": repr(ex)[:300]}
 
 
 def measure_alt_fp32(args):

@@ -33,7 +33,11 @@ def timeit(fn, reps=20):
     return ts[len(ts) // 2] * 1e3   # us
 
 
-ONLY = sys.argv[1] if len(sys.argv) > 1 else ""      # print only the rows whose name contains this (every row is still measured)
+# `python bench_ops.py --driver`: the short subset bench.py embeds in the driver's line (secondary["ops"]: the warps, downsample,
+# Adam, both correlation points; <= 3 s of GPU time); otherwise an optional substring filter on the row names
+DRIVER = "--driver" in sys.argv[1:]
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+ONLY = _args[0] if _args else ""      # print only the rows whose name contains this (every row is still measured)
 
 
 def report(name, nbytes, us, extra=None):
@@ -44,7 +48,7 @@ def report(name, nbytes, us, extra=None):
            "frac_of_8TBs": round(gbs / HBM_PEAK, 3)}
     if extra:
         out.update(extra)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -63,8 +67,9 @@ def main():
     # image_warp forward: (2C+2)*4 B/px  (read image once, flow, write warped)
     report("image_warp_fwd C=3 %dx%dx%d" % (N, H, W), npx * 32,
            timeit(lambda: check(lib.unflow_image_warp_fwd(ptr(im), 3, ptr(flow), cf(1.0), ptr(out3), ptr(None), 0, N, H, W, 3, st))))
-    report("image_warp_fwd C=3, i.i.d. N(0,4^2) flow (gather worst case)", npx * 32,
-           timeit(lambda: check(lib.unflow_image_warp_fwd(ptr(im), 3, ptr(flow_iid), cf(1.0), ptr(out3), ptr(None), 0, N, H, W, 3, st))))
+    if not DRIVER:
+        report("image_warp_fwd C=3, i.i.d. N(0,4^2) flow (gather worst case)", npx * 32,
+               timeit(lambda: check(lib.unflow_image_warp_fwd(ptr(im), 3, ptr(flow_iid), cf(1.0), ptr(out3), ptr(None), 0, N, H, W, 3, st))))
     report("backward_warp_fwd C=3", npx * 32,
            timeit(lambda: check(lib.unflow_backward_warp_fwd(ptr(im), ptr(flow), ptr(out3), N, H, W, 3, st))))
     # the same op on a locally constant field (a translation): the rate of the gather itself, without the extra cache lines a
@@ -87,23 +92,26 @@ def main():
     dist = torch.empty_like(gray1)
     acc = torch.zeros(1, device=dev)
     dgray = torch.empty_like(gray1)
-    for D in (1, 3):
+    for D in (() if DRIVER else (1, 3)):
         report("ternary_fwd D=%d (census %dx%d)" % (D, 2 * D + 1, 2 * D + 1), npx * 12,
                timeit(lambda: check(lib.unflow_ternary_fwd(ptr(gray1), ptr(gray2), ptr(mask), 1, ptr(dist), ptr(acc), cf(1.0), cf(npx), D, N, H, W, st))))
         report("ternary_bwd D=%d" % D, npx * 16,
                timeit(lambda: check(lib.unflow_ternary_bwd(ptr(gray1), ptr(gray2), ptr(mask), 1, ptr(dist), ptr(dgray), cf(1.0), cf(npx), D, N, H, W, st))))
-    report("second_order fwd+bwd", npx * 16,
-           timeit(lambda: check(lib.unflow_second_order_fwd_bwd(ptr(flow), cf(1.0), ptr(acc), ptr(dfl), 0, cf(1.0), cf(npx), N, H, W, st))))
+    if not DRIVER:
+        report("second_order fwd+bwd", npx * 16,
+               timeit(lambda: check(lib.unflow_second_order_fwd_bwd(ptr(flow), cf(1.0), ptr(acc), ptr(dfl), 0, cf(1.0), cf(npx), N, H, W, st))))
     for s in (2, 4):
         o = torch.empty(N, H // s, W // s, 3, device=dev)
         report("downsample scale=%d C=3" % s, int(npx * 12 * (1 + 1.0 / (s * s))),
                timeit(lambda: check(lib.unflow_downsample_fwd(ptr(im), ptr(o), N, H, W, 3, s, st))))
     # forward_warp (ops/forward_warp_op.cu.cc:16-125): 12 B/px forward (flow in, splat sum out), 20 B/px backward; the work is
     # the <= 81 taps per source pixel, not the bytes — the HBM fraction is reported all the same (DESIGN.md has the tap-rate bound)
-    fw_out = torch.empty(N, H, W, 1, device=dev)
-    fw_ws = torch.empty(lib.unflow_forward_warp_workspace_bytes(N, H, W, 1) // 4 + 64, dtype=torch.float32, device=dev)   # 64-bit sums + the far-source bins
-    flow_50 = (torch.rand(N, H, W, 2, generator=g) * 100 - 50).to(dev)
-    for nm, fl in (("smooth field, sigma 4 px", flow), ("i.i.d. N(0,4^2)", flow_iid), ("i.i.d. U(-50,50) px", flow_50)):
+    fw_out = fw_ws = flow_50 = None
+    if not DRIVER:
+        fw_out = torch.empty(N, H, W, 1, device=dev)
+        fw_ws = torch.empty(lib.unflow_forward_warp_workspace_bytes(N, H, W, 1) // 4 + 64, dtype=torch.float32, device=dev)   # 64-bit sums + the far-source bins
+        flow_50 = (torch.rand(N, H, W, 2, generator=g) * 100 - 50).to(dev)
+    for nm, fl in (() if DRIVER else (("smooth field, sigma 4 px", flow), ("i.i.d. N(0,4^2)", flow_iid), ("i.i.d. U(-50,50) px", flow_50))):
         for det in (1, 0):
             report("forward_warp_fwd %s, %s" % ("deterministic (64-bit fixed-point sums)" if det else "float atomics (reference contract)", nm),
                    npx * 12, timeit(lambda: check(lib.unflow_forward_warp_fwd(ptr(fl), ptr(fw_out), N, H, W, det, ptr(fw_ws),
@@ -143,20 +151,29 @@ def main():
     co2 = torch.empty(N2, h2, w2, 84, device=dev)
     nb = N2 * h2 * w2 * (2 * 256 + 81) * 4
     gfl = 2 * 81 * 256 * N2 * h2 * w2 / 1e9
-    us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f2), ptr(f2), 256, N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
-    report("correlation_nhwc_fwd 81ch (md=4, stride_2=1) N=16 96x128, fp32 entry", nb, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
-    # planes entry: the features are read as 3 bf16 planes (6 B/value instead of 4)
+    if not DRIVER:
+        us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd(ptr(f2), ptr(f2), 256, N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+        report("correlation_nhwc_fwd 81ch (md=4, stride_2=1) N=16 96x128, fp32 entry", nb, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
+    # planes entry: the ALGORITHMIC bytes are SURVEY 8(d)'s fp32 figure, (2 * 256 + 81) * 4 B per pixel, whatever format the kernel
+    # reads; the bytes of the format it does read (3 bf16 planes: 6 B per feature value) are reported beside it
     nbp = N2 * h2 * w2 * (2 * 256 * 6 + 81 * 4)
     us = timeit(lambda: check(lib.unflow_correlation_nhwc_fwd_pl(ptr(f2), ptr(f2), 256, planes_of(F2.pl), planes_of(F2.pl), N2 // 2, ptr(co2), 84, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
-    report("correlation_nhwc_fwd_pl 81ch (md=4, stride_2=1) N=16 96x128", nbp, us, {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1)})
+    report("correlation_nhwc_fwd_pl 81ch (md=4, stride_2=1) N=16 96x128", nb, us,
+           {"GFLOP_algorithmic": round(gfl, 2), "TFLOP/s": round(gfl * 1e3 / us, 1), "plane_format_MB": round(nbp / 1e6, 1),
+            "frac_of_8TBs_on_plane_bytes": round(nbp / us / 1e3 / HBM_PEAK, 3)})
     gco2 = torch.randn(N2, h2, w2, 84, generator=g).to(dev)
     gf2 = torch.empty_like(f2)
-    nbb = N2 * h2 * w2 * (81 + 2 * 256 + 256) * 4
-    us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco2), 84, ptr(f2), ptr(f2), 256, N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
-    report("correlation_nhwc_bwd 81ch N=16 96x128 (fused g0+g1), fp32 entry", nbb, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
+    nbb = N2 * h2 * w2 * (81 + 2 * 256 + 256) * 4      # dOut + both features read, the (fused, shared-tensor) gradient written once
+    if not DRIVER:
+        us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd(ptr(gco2), 84, ptr(f2), ptr(f2), 256, N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
+        report("correlation_nhwc_bwd 81ch N=16 96x128 (fused g0+g1), fp32 entry", nbb, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
     nbbp = N2 * h2 * w2 * (81 * 4 + 2 * 256 * 6 + 256 * 4)
     us = timeit(lambda: check(lib.unflow_correlation_nhwc_bwd_pl(ptr(gco2), 84, ptr(f2), ptr(f2), 256, planes_of(F2.pl), planes_of(F2.pl), N2 // 2, ptr(gf2), ptr(None), 256, 1, N2, 256, h2, w2, 1, 4, 4, 1, 1, st)))
-    report("correlation_nhwc_bwd_pl 81ch N=16 96x128 (fused g0+g1)", nbbp, us, {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1)})
+    report("correlation_nhwc_bwd_pl 81ch N=16 96x128 (fused g0+g1)", nbb, us,
+           {"GFLOP_algorithmic": round(2 * gfl, 2), "TFLOP/s": round(2 * gfl * 1e3 / us, 1), "plane_format_MB": round(nbbp / 1e6, 1),
+            "frac_of_8TBs_on_plane_bytes": round(nbbp / us / 1e3 / HBM_PEAK, 3)})
+    if DRIVER:
+        return
     # the reference op's own boundary: two NCHW fp32 tensors in, NCHW out (ops/correlation_op.cc) — transposes to NHWC, operand
     # planes built in the workspace, the planes kernels, transpose back.  With only the fp32 part of the workspace: the fp32 kernels.
     del F2, f2, co2, gco2, gf2

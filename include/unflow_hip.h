@@ -147,6 +147,10 @@ int unflow_forward_warp_ranges(const float* flows, int* ranges, int B, int H, in
 /* ops/downsample_op.cu.cc:15-49 (box mean); H,W must be divisible by scale (downsample_op.cc:37-40). */
 int unflow_downsample_fwd(const float* images, float* out, int B, int H, int W, int C, int scale,
                           unflow_stream_t stream);
+/* tf.image.resize_area(images, [out_h, out_w]) (core/util.py:12-14 and the odd-size branch of util.downsample, :26): area-weighted
+ * mean of the source rectangle of every output pixel, NHWC. */
+int unflow_resize_area(const float* images, float* out, int B, int H, int W, int C, int out_h, int out_w,
+                       unflow_stream_t stream);
 /* The loss pyramid's image chain downsample(., 4), downsample(., 2) x 4 (unsupervised.py:99-100,145-146) on 3-channel images in
  * one launch; levels[k] = [N, H / (4 << k), W / (4 << k), 3], k = 0..4, each bit-identical to the chained unflow_downsample_fwd
  * calls.  H, W multiples of 64 (UNFLOW_ERR_NOT_DIVISIBLE otherwise). */
@@ -296,6 +300,13 @@ int unflow_loss_pyramid_default(const unflow_pyr_level* levels, int n_levels, in
 int unflow_photometric_fwd_bwd(const float* im, int ld_im, const float* flow, float flow_scale, const float* mask,
                                int n_mask, float* loss_acc, float* d_flow, int accumulate, float weight, float normalizer,
                                int pair_shift, int N, int H, int W, unflow_stream_t stream);
+
+/* charbonnier_loss (losses.py:298-322), the stand-alone form: loss_acc[0] += weight * sum(min(mask * ((x*beta)^2 +
+ * epsilon^2)^alpha, truncate)) / (npix*C) over x [npix, C]; mask [npix, mask_channels], mask_channels 1 or C, or NULL;
+ * truncate < 0: none.  length_sq (losses.py:12-13): out[i] = sum_c x[i,c]^2. */
+int unflow_charbonnier_loss(const float* x, const float* mask, int mask_channels, float truncate, float alpha, float beta,
+                            float epsilon, float* loss_acc, float weight, long npix, int C, unflow_stream_t stream);
+int unflow_length_sq(const float* x, float* out, long npix, int C, unflow_stream_t stream);
 
 /* smoothness_loss (losses.py:206-255): first-order forward differences of flow*flow_scale, Charbonnier. */
 int unflow_smooth_1st_fwd_bwd(const float* flow, float flow_scale, float* loss_acc, float* d_flow, int accumulate,

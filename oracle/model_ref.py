@@ -427,12 +427,14 @@ def create_outgoing_mask(flow):
     return inside.to(flow.dtype).unsqueeze(3)
 
 
-def charbonnier_loss(x, mask=None, alpha=0.45, beta=1.0, epsilon=0.001):
+def charbonnier_loss(x, mask=None, alpha=0.45, beta=1.0, epsilon=0.001, truncate=None):
     """losses.py:298-322; normaliser = number of elements of x (not the mask sum)."""
     norm = float(x.numel())
     err = torch.pow((x * beta) ** 2 + epsilon ** 2, alpha)
     if mask is not None:
         err = mask * err
+    if truncate is not None:
+        err = torch.clamp(err, max=truncate)
     return err.sum() / norm
 
 

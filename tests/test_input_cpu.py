@@ -1,6 +1,6 @@
 """CPU tests of the (f2) groundwork: .npz parameter files keyed by the reference's variable names, .flo and KITTI flow-PNG
 readers (fixtures under tests/golden, written by tests/golden/make_io_fixtures.py), resize_output_flow, outlier metrics,
-the product learning-rate schedule and resize_area."""
+the product learning-rate schedule."""
 import os
 
 import numpy as np
@@ -142,16 +142,6 @@ def test_product_learning_rate_schedule():
     assert [learning_rate_at(m, i) for i in (0, 10, 11, 30, 31, 60)] == [1e-3, 1e-3, 1e-4, 1e-4, 1e-5, 1e-5]
     assert learning_rate_at(m, 61) == 1e-3                   # past the list: the reference's loop leaves index 0
     assert learning_rate_at(dict(learning_rate=3e-5), 12345) == 3e-5
-
-
-def test_resize_area_integer_and_fractional():
-    from unflow_amd.core.util import resize_area
-    x = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6, 1)
-    y = resize_area(x, torch.empty(1, 2, 3, 1))
-    assert torch.allclose(y, x.reshape(2, 2, 2, 3, 2, 1).mean(dim=(2, 4)))
-    # 5 -> 2 along one axis: windows [0, 2.5) and [2.5, 5) with the middle pixel split in half
-    z = resize_area(torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]).view(1, 1, 5, 1), torch.empty(1, 1, 2, 1))
-    assert torch.allclose(z.flatten(), torch.tensor([(1 + 2 + 1.5) / 2.5, (1.5 + 4 + 5) / 2.5]))
 
 
 def test_read_png_image_grey_alpha_and_16_bit(tmp_path):

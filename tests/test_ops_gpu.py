@@ -343,3 +343,37 @@ def test_correlation_backward_both_math_modes(dev):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", "correlation"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def _area_weights(n_in, n_out):
+    """[n_out, n_in] weights of tf.image.resize_area along one axis (TF's ResizeAreaOp): output i averages the source interval
+    [i*s, (i+1)*s), s = n_in / n_out, every source pixel weighted by the covered fraction — the independent restatement."""
+    import math
+    s = n_in / n_out
+    w = torch.zeros(n_out, n_in, dtype=torch.float64)
+    for i in range(n_out):
+        lo, hi = i * s, (i + 1) * s
+        for j in range(int(math.floor(lo)), min(n_in, int(math.ceil(hi)))):
+            w[i, j] = (min(hi, j + 1) - max(lo, j)) / s
+    return w
+
+
+def test_resize_area_integer_fractional_and_odd_sizes(dev):
+    """core/util.py:12-14,26 (tf.image.resize_area): integer ratios are box means, 5 -> 2 splits the middle pixel in half, and
+    the odd sizes the reference's util.downsample sends here (int(H / num)) match the separable area weights in fp64."""
+    from unflow_amd.core.util import resize_area, downsample
+    x = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6, 1)
+    y = resize_area(x.to(dev), torch.empty(1, 2, 3, 1)).cpu()
+    assert torch.allclose(y, x.reshape(2, 2, 2, 3, 2, 1).mean(dim=(2, 4)))
+    z = resize_area(torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]).view(1, 1, 5, 1).to(dev), torch.empty(1, 1, 2, 1)).cpu()
+    assert torch.allclose(z.flatten(), torch.tensor([(1 + 2 + 1.5) / 2.5, (1.5 + 4 + 5) / 2.5]))
+    g = torch.Generator().manual_seed(3)
+    for (H, W, num) in ((375, 1241, 2), (93, 155, 4), (47, 31, 2)):
+        t = torch.rand(2, H, W, 3, generator=g)
+        got = downsample(t.to(dev), num).cpu().double()           # odd size -> the resize_area branch
+        oh, ow = int(H / num), int(W / num)
+        ref = torch.einsum('yh,bhwc,xw->byxc', _area_weights(H, oh), t.double(), _area_weights(W, ow))
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 2e-6
+    with pytest.raises(TypeError):
+        resize_area(x, torch.empty(1, 2, 3, 1))                    # host tensors: no CPU fallback

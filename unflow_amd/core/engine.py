@@ -55,12 +55,14 @@ def conv_math_mode():
     """How the conv / conv_transpose layers multiply (UNFLOW_CONV_MATH):
        'bf16x3'  (default) operands pre-split into three bf16 planes by their producers, six bf16 MFMA terms, fp32
                  accumulate — fp32-class accuracy (csrc/conv_planes.hip);
-       'bf16x3_inline'     the same products with the split done while staging fp32 operands (csrc/conv_igemm.hip);
        'fp32'    v_mfma_f32_32x32x2_f32 everywhere (csrc/conv_igemm.hip);
-       'f16'     fp16 activations and weights in, fp32 accumulate (BASELINE configs[4]); NOT fp32-equivalent."""
+       'f16'     fp16 activations and weights in, fp32 accumulate (BASELINE configs[4]); NOT fp32-equivalent.
+    (Round 6 removed the fourth mode, 'bf16x3_inline' — the engine without planes on the in-staging split of
+    csrc/conv_igemm.hip: no user.  Those kernels remain what the plain fp32-tensor entry points of the C ABI run,
+    unflow_conv2d_fwd & co., which have no planes to take.)"""
     m = os.environ.get('UNFLOW_CONV_MATH', 'bf16x3')
-    if m not in ('bf16x3', 'bf16x3_inline', 'fp32', 'f16'):
-        raise ValueError("UNFLOW_CONV_MATH must be bf16x3, bf16x3_inline, fp32 or f16")
+    if m not in ('bf16x3', 'fp32', 'f16'):
+        raise ValueError("UNFLOW_CONV_MATH must be bf16x3, fp32 or f16")
     return m
 
 

@@ -1,29 +1,21 @@
 """Mirror of src/e2eflow/core/util.py:12-26."""
-import math
-
 import torch
 
 from ..ops import downsample as downsample_ops
 
 
-def _area_weights(n_in, n_out, device):
-    """[n_out, n_in] weights of tf.image.resize_area along one axis: output i averages the source interval
-    [i*s, (i+1)*s), s = n_in / n_out, every source pixel weighted by the covered fraction (TF's ResizeAreaOp)."""
-    s = n_in / n_out
-    w = torch.zeros(n_out, n_in, dtype=torch.float64)
-    for i in range(n_out):
-        lo, hi = i * s, (i + 1) * s
-        for j in range(int(math.floor(lo)), min(n_in, int(math.ceil(hi)))):
-            w[i, j] = (min(hi, j + 1) - max(lo, j)) / s
-    return w.to(device=device, dtype=torch.float32)
-
-
 def resize_area(tensor, like):
-    """tf.image.resize_area(tensor, like.shape[1:3]) (core/util.py:12-14; stop_gradient there — no gradient here either)."""
+    """tf.image.resize_area(tensor, like.shape[1:3]) (core/util.py:12-14; stop_gradient there — no gradient here either):
+    one HIP kernel (csrc/ops_warp.hip resize_area_kernel), GPU tensors only like every op of the package."""
+    from .. import _lib
+    from .._lib import check, ptr, stream
+    from ..ops import _dev
     _, h, w, _ = like.shape
-    B, H, W, C = tensor.shape
-    wy, wx = _area_weights(H, h, tensor.device), _area_weights(W, w, tensor.device)
-    return torch.einsum('yh,bhwc,xw->byxc', wy, tensor.detach(), wx)
+    t = _dev(tensor.detach(), 'tensor')
+    B, H, W, C = t.shape
+    out = torch.empty(B, int(h), int(w), C, dtype=torch.float32, device=t.device)
+    check(_lib.lib().unflow_resize_area(ptr(t), ptr(out), B, H, W, C, int(h), int(w), stream(t.device)), "resize_area")
+    return out
 
 
 def downsample(tensor, num):

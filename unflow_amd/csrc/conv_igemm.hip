@@ -1,7 +1,8 @@
 // conv / conv_transpose stacks of FlowNetC/S (src/e2eflow/core/flownet.py:89-237) as implicit GEMMs for gfx950,
 // channels-last — the kernels that take fp32 tensors as operands.  The default path of the training step is
-// csrc/conv_planes.hip (pre-split 16-bit operand planes); this file is what runs with UNFLOW_CONV_MATH=fp32 /
-// bf16x3_inline, for operands without planes (the old C-ABI entry points, unaligned channel counts), and it holds the
+// csrc/conv_planes.hip (pre-split 16-bit operand planes); this file is what runs with UNFLOW_CONV_MATH=fp32 and for
+// operands without planes (the plain fp32-tensor entry points of the C ABI — the seam a TF op shell binds, INTEGRATION.md
+// 2b — and unaligned channel counts), and it holds the
 // kernels of the layers that are no GEMM at all: the Cout = 2 flow heads (head3_*), the 2 -> 2 flow upsamplers
 // (tiny_deconv_*), conv_redir's data gradient (pointwise32) and the batched bias-gradient column sums.
 //

@@ -655,6 +655,51 @@ UNFLOW_API int unflow_photometric_fwd_bwd(const float* im, int ld_im, const floa
   return launch_status();
 }
 
+// ------------------------------------------------------------------ generic Charbonnier (losses.py:298-322) and length_sq (:12-13)
+// charbonnier_loss(x, mask, truncate, alpha, beta, epsilon) = sum(min(mask * ((x*beta)^2 + eps^2)^alpha, truncate)) / (npix * C):
+// the stand-alone form of the penalty every fused term above applies (there with the reference's defaults folded in).
+// mask: [npix, mask_channels] with mask_channels 1 or C (or NULL); truncate < 0: none.  loss_acc[0] += weight * that.
+__global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restrict__ x, int C, const float* __restrict__ mask, int mc,
+                                                          float truncate, float alpha, float beta, float eps2, float scale,
+                                                          float* __restrict__ loss_acc, long n) {
+  __shared__ float red[4];
+  float local = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i] * beta;
+    float e = fast_pow(v * v + eps2, alpha);
+    if (mask) e *= mc == 1 ? mask[i / C] : mask[i];
+    if (truncate >= 0.f) e = fminf(e, truncate);
+    local += e;
+  }
+  const float t = block_sum(local, red);
+  if (threadIdx.x == 0) atomicAdd(loss_acc, t * scale);
+}
+
+UNFLOW_API int unflow_charbonnier_loss(const float* x, const float* mask, int mask_channels, float truncate, float alpha, float beta,
+                                       float epsilon, float* loss_acc, float weight, long npix, int C, unflow_stream_t stream) {
+  if (!x || !loss_acc) return UNFLOW_ERR_NULL;
+  if (npix <= 0 || C <= 0 || (mask && mask_channels != 1 && mask_channels != C)) return UNFLOW_ERR_SHAPE;
+  const long n = npix * C;
+  charbonnier_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(x, C, mask, mask_channels, truncate, alpha, beta,
+                                                                    epsilon * epsilon, weight / (float)n, loss_acc, n);
+  return launch_status();
+}
+
+__global__ void length_sq_kernel(const float* __restrict__ x, int C, float* __restrict__ out, long npix) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; c++) { const float v = x[i * C + c]; s += v * v; }
+    out[i] = s;
+  }
+}
+
+UNFLOW_API int unflow_length_sq(const float* x, float* out, long npix, int C, unflow_stream_t stream) {
+  if (!x || !out) return UNFLOW_ERR_NULL;
+  if (npix <= 0 || C <= 0) return UNFLOW_ERR_SHAPE;
+  length_sq_kernel<<<stream_grid(npix), 256, 0, as_stream(stream)>>>(x, C, out, npix);
+  return launch_status();
+}
+
 // ------------------------------------------------------------------ first-order smoothness (losses.py:206-255)
 // delta_x(p) = f(p) - f(p+(0,1)) (masked on the last column), delta_y(p) = f(p) - f(p+(1,0)) (last row);
 // Charbonnier on each, normaliser N_dir*H*W*2 per flow channel.
