@@ -545,15 +545,15 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     occ_thresh_bw = 0.01 * mag_sq_bw + 0.5
     fb_occ_fw = (length_sq(flow_diff_fw) > occ_thresh_fw).to(im1.dtype)
     fb_occ_bw = (length_sq(flow_diff_bw) > occ_thresh_bw).to(im1.dtype)
+    if mask_occlusion == 'disocc' or 'sym' in need:      # losses.py:28-29 (TF prunes it when nothing consumes it)
+        disocc_fw = (forward_warp(flow_fw) < DISOCC_THRESH).to(im1.dtype)
+        disocc_bw = (forward_warp(flow_bw) < DISOCC_THRESH).to(im1.dtype)
     if mask_occlusion == 'fb':
         mask_fw = mask_fw * (1 - fb_occ_fw)
         mask_bw = mask_bw * (1 - fb_occ_bw)
-    elif mask_occlusion == 'disocc' or 'sym' in need:
-        disocc_fw = (forward_warp(flow_fw) < DISOCC_THRESH).to(im1.dtype)
-        disocc_bw = (forward_warp(flow_bw) < DISOCC_THRESH).to(im1.dtype)
-        if mask_occlusion == 'disocc':
-            mask_fw = mask_fw * (1 - disocc_bw)
-            mask_bw = mask_bw * (1 - disocc_fw)
+    elif mask_occlusion == 'disocc':
+        mask_fw = mask_fw * (1 - disocc_bw)
+        mask_bw = mask_bw * (1 - disocc_fw)
     occ_fw = 1 - mask_fw
     occ_bw = 1 - mask_bw
     if 'sym' in need:

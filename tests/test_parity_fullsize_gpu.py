@@ -122,8 +122,49 @@ def test_flownetc_b4_384x512_kitti_loss_variant_vs_fp64_oracle(dev):
           "%d of %d leaky units flipped" % (loss, loss_ref, abs(loss - loss_ref) / abs(loss_ref), worst, al.flips, al.units))
 
 
+def test_flownet_css_768x1024_b2_end_to_end_vs_fp64_fixture(dev):
+    """BASELINE configs[3] at its BENCHMARKED batch (B = 2, bench.py measure_secondary): C -> S -> S at 768x1024 end to end against
+    the fp64 oracle's outputs, committed as tests/golden/css_768x1024_b2_fp64.npz by tests/golden/make_css_fp64_fixture.py (an
+    fp64 pass over three networks at this size is minutes of host time: run once, cached; the weights and images are
+    regenerated here from their seeds).  The bound is the north star's own, with the noise floor of ANY fp32 evaluation of this
+    graph beside it: |HIP - fp64| <= max(1e-3 px, 4 x |oracle32 - fp64|), the latter measured by the same script (4e-5 px)."""
+    import os
+    import numpy as np
+    from unflow_amd.core.engine import FlowNetEngine
+    sys_path_golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location('make_css_fp64_fixture', os.path.join(sys_path_golden, 'make_css_fp64_fixture.py'))
+    mk = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mk)
+    fx = np.load(os.path.join(sys_path_golden, 'css_768x1024_b2_fp64.npz'))
+    B, H, W = mk.B, mk.H, mk.W
+    assert list(fx['meta']) == [B, H, W, mk.WSEED, mk.ISEED, mk.STEP] and float(fx['head_scale']) == mk.HEAD_SCALE
+    params = dict(flownet=mk.SPEC, pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0)
+    eng = FlowNetEngine(B, H, W, params=params, device=dev, seed=None)
+    eng.load_tf_params(mk.css_params())
+    im1, im2 = images(B, H, W, mk.ISEED)
+    loss = graph_step(eng, im1.to(dev), im2.to(dev))          # the bench's launch path: captured hipGraphs
+    fw, bw = eng.final_flows()
+    st = mk.STEP
+
+    def epe(a, ref):
+        d = a[:, ::st, ::st].cpu().double() - torch.from_numpy(ref).double()
+        return (d * d).sum(-1).sqrt().mean().item()
+    e_loss = abs(loss - float(fx['loss64'])) / abs(float(fx['loss64']))
+    e_fw, e_bw = epe(fw, fx['fw64']), epe(bw, fx['bw64'])
+    floor = max(float(fx['epe32_lat_fw']), float(fx['epe32_lat_bw']))
+    print("CSS 768x1024 B=2 end to end vs the fp64 oracle (lattice [::%d, ::%d]): loss rel %.2e (fp32 oracle: %.2e), EPE fw %.2e bw %.2e px "
+          "(fp32 oracle against fp64: %.2e / %.2e px), max |flow| %.0f px"
+          % (st, st, e_loss, abs(float(fx['loss32']) - float(fx['loss64'])) / float(fx['loss64']), e_fw, e_bw,
+             float(fx['epe32_lat_fw']), float(fx['epe32_lat_bw']), float(fx['fmax'])))
+    assert e_loss <= 1e-4, e_loss
+    assert e_fw <= max(1e-3, 4 * floor) and e_bw <= max(1e-3, 4 * floor), (e_fw, e_bw, floor)
+    assert e_fw < 1e-3 and e_bw < 1e-3, (e_fw, e_bw)      # the north star's plain bound holds at these flow magnitudes
+
+
 def test_flownet_css_768x1024_vs_oracle(dev):
-    """BASELINE configs[3]: C -> S -> S at 768x1024 (B = 1 keeps the CPU oracle within minutes)."""
+    """BASELINE configs[3]: C -> S -> S at 768x1024; every gradient of the trained network (B = 1 keeps the CPU oracle's fp64
+    backward pass within minutes; the benchmarked batch B = 2 is covered end to end by the fixture test above)."""
     from unflow_amd.core.engine import FlowNetEngine, flow_error_avg, FLOW_SCALE
     from oracle import model_ref as M
     B, H, W = 1, 768, 1024
@@ -146,8 +187,7 @@ def test_flownet_css_768x1024_vs_oracle(dev):
     got = eng.export_tf_grads()
     reg = 0.0004 * 0.5 * sum((v.double() ** 2).sum().item() for k, v in tf_params.items() if k.endswith('/weights'))
 
-    # (1) end to end, fp32 oracle (an fp64 pass over three networks at this size takes many minutes on the host): the two
-    # frozen stages amplify fp32 summation-order noise through the next stage's warp, hence the wider bounds
+    # (1) end to end, fp32 oracle: at these flow magnitudes (tens of pixels) the plain 1e-3 px bound
     loss32, ffw, fbw, _ = oracle_step(tf_params, im1, im2, params, dtype=torch.float32, backward=False)
     e_loss = abs(loss - loss32) / abs(loss32)
     e_fw = flow_error_avg(fw, ffw.to(dev)).item()
@@ -155,8 +195,7 @@ def test_flownet_css_768x1024_vs_oracle(dev):
     fmax = max(ffw.abs().max().item(), fbw.abs().max().item())
     print("CSS 768x1024 end-to-end vs fp32 oracle: loss rel %.2e, EPE fw %.2e bw %.2e px (max |flow| %.0f px)"
           % (e_loss, e_fw, e_bw, fmax))
-    # random-weight stacks produce flows of hundreds of pixels: 1e-3 px + 1e-5 of the flow magnitude
-    assert e_loss <= 2e-4 and e_fw < 1e-3 + 1e-5 * fmax and e_bw < 1e-3 + 1e-5 * fmax
+    assert e_loss <= 2e-4 and e_fw < 1e-3 and e_bw < 1e-3
 
     # (2) the trained network alone, fp64, fed the ENGINE's stage-2 flows: loss, flows and every gradient, tight bounds
     scope = 'stack_2_flownet/'
