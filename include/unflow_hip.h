@@ -432,6 +432,17 @@ size_t unflow_weight_planes_elems(int taps, int R, int Cc, int transposed);
 int unflow_weight_planes_batched(int n, const float* const* w, const int* taps, const int* R, const int* Cc,
                                  void* const* direct, void* const* transposed, int n_planes, unflow_stream_t stream);
 
+/* The optimizer update of train.py:151-152 (unflow_adam_step's arithmetic, bit-identical parameters) and the re-split of the
+ * updated weights into their planes in ONE pass over a table of tensors W[taps][R][Cc] that live inside the flat buffers P / G /
+ * M / V (identical layouts; w[i] points into P): 64 x 64 tiles, the new values go from the tile to both plane copies without a
+ * second read.  direct[i] / transposed[i] may be NULL (a tensor without planes — the Cout = 2 layers, or the bias block as one
+ * pseudo-tensor with taps = R = 1); regularized[i] != 0 adds l2_scale * p to the gradient (and, with loss_acc, l2_scale * 0.5 * p^2
+ * of the PRE-update values to loss_acc[0], like unflow_adam_step_regloss).  n_planes 0: no tensor of the table has planes. */
+int unflow_adam_planes_batched(int n, float* const* w, const int* taps, const int* R, const int* Cc, void* const* direct,
+                               void* const* transposed, const int* regularized, int n_planes, float* P, const float* G, float* M,
+                               float* V, float grad_scale, float l2_scale, float lr_t, float beta1, float beta2, float eps,
+                               float* loss_acc, unflow_stream_t stream);
+
 size_t unflow_conv_pl_workspace_bytes(int B, int H, int W, int Cin, int Cout, int k, int stride, int n_planes);
 
 /* Every Cout = 2 filter gradient of a refinement decoder (flownet.py:89-131: flowN = conv k3 -> 2, flowN_upM =

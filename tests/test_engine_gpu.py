@@ -144,6 +144,38 @@ def test_adam_step_vs_oracle(dev):
         assert (got[k] - P[k]).abs().max().item() < 2e-7, k     # <= 0.2 % of one Adam step (lr = 1e-4)
 
 
+def test_fused_adam_planes_bit_identical_to_the_two_launches(dev):
+    """unflow_adam_planes_batched (L2 + Adam + the weight planes in one pass; UNFLOW_FUSED_ADAM=1, off by default: not faster) against
+    adam_kernel + weight_planes_kernel: parameters, both moments and both plane copies of every layer bit for bit, whole vector and
+    bucketed ranges; the L2 loss term within float-atomic order."""
+    from unflow_amd.core.engine import FlowNetCEngine
+    B, H, W = 1, 64, 64
+    a = FlowNetCEngine(B, H, W, device=dev, seed=3)
+    b = FlowNetCEngine(B, H, W, device=dev, seed=3)
+    g = torch.Generator().manual_seed(9)
+    grad = (torch.randn(a.n_params, generator=g) * 1e-3).to(dev)
+    for e in (a, b):
+        e.G.copy_(grad)
+        e.defer_l2 = True
+        e.loss_acc.zero_()
+    ranges = [r for part in a.part_buckets() for r in part]
+    for step in range(2):
+        lr_t = a.adam_begin(1e-4)
+        for lo, hi in ranges:
+            a.adam_range(lo, hi, lr_t, 0.5)
+        a.refresh_weight_planes(force=True)
+        lr_t = b.adam_begin(1e-4)
+        if step == 0:
+            b.adam_ranges_fused(ranges, lr_t, 0.5)                  # every bucket in one table
+        else:
+            for r in ranges:
+                b.adam_ranges_fused([r], lr_t, 0.5)                 # bucket by bucket
+    torch.cuda.synchronize()
+    for name in ('P', 'M', 'V', 'WP'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert abs(a.loss_acc.item() - b.loss_acc.item()) <= 1e-5 * abs(a.loss_acc.item())
+
+
 FULL_PARAMS = [
     # KITTI-style: forward-backward consistency + occlusion masking (config.ini [train_kitti]: fb 0.2, occ 12.4)
     dict(flownet='C', pyramid_loss=True, border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0, fb_weight=0.2,

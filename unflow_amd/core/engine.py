@@ -542,12 +542,20 @@ class FlowNetEngine:
         self.wgrad_inline_tiny = False
         self.batch_flow_wgrad = True      # all Cout = 2 filter gradients of a decoder in one batched launch pair
         self.n_planes = {'bf16x3': 3, 'f16': 1}.get(self.math, 0)
+        # UNFLOW_FUSED_ADAM=1: L2 + Adam and the re-split of the updated weights in one pass (csrc/conv_planes.hip
+        # adam_planes_kernel; round 6).  Built, bit-identical, and NOT faster: 267.7 / 269.5 us against
+        # 264.5 / 269.2 us for adam_kernel + weight_planes_kernel at FlowNetC's 39.2 M parameters (tools/debug/adam_fused_time.py;
+        # the step 671.5 / 673.5 against 672.6 / 672.0 pairs/s): the 157 MB of P the second launch re-reads come from the
+        # Infinity Cache, and the fused kernel's 64 x 64 tiles stream the four flat buffers in 256-byte row pieces (5.8 TB/s)
+        # where the flat kernel runs at 6.5.  Default off.
+        self.fused_adam = os.environ.get('UNFLOW_FUSED_ADAM', '0') == '1'
         # fp16 mode: the fp16 planes of GRADIENT tensors hold 2^12 x the gradient (producers scale, consumers divide their
         # fp32 sums): activation gradients of the deep layers are 1e-7 .. 1e-4, below fp16's normal range (6e-5); bf16 x 3
         # planes have fp32's exponent range and are never scaled
         self.grad_plane_scale = 4096.0 if self.math == 'f16' else 0.0
         if layout_only:
             self.n_planes = 0
+        self.fused_adam = self.fused_adam and self.n_planes > 0
         import contextlib
         with (torch.cuda.device(self.dev) if self.dev.type == 'cuda' else contextlib.nullcontext()):
             self.stages = [_Stage(self, k, i, self.full_res and i == len(spec) - 1) for i, k in enumerate(spec)]
@@ -615,6 +623,7 @@ class FlowNetEngine:
             self._wp_users = users
             self._wp_table = self._wp_table_of(users)
             self._wp_range_tables = {}
+        self._adam_tables = {}
 
     @staticmethod
     def _wp_table_of(users):
@@ -1148,6 +1157,54 @@ class FlowNetEngine:
                                               cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1), cf(beta2), cf(eps),
                                               self.stream()), "adam")
 
+    def _adam_table(self, ranges):
+        """ctypes table of unflow_adam_planes_batched for the flat ranges [(lo, hi), ...]: every weight tensor that lies in a
+        range (with its plane copies, or without for the layers that have none) + the bias part of each range as one
+        unregularised pseudo-tensor.  Ranges are unions of whole tensors by construction (part_buckets)."""
+        import ctypes
+        key = tuple(ranges)
+        tab = self._adam_tables.get(key)
+        if tab is not None:
+            return tab
+        base = self.P.data_ptr()
+        rows = []
+        for l in self.layers:
+            off = (l.w.data_ptr() - base) // 4
+            n = l.w.numel()
+            hit = [r for r in ranges if r[0] <= off < r[1]]
+            if not hit:
+                continue
+            assert off + n <= hit[0][1], "flat range cuts through %s" % l.name
+            if l.uses_planes() and self.n_planes:
+                taps, R, Cc = l.wplane_view()
+                rows.append((l.w.data_ptr(), taps, R, Cc, l.wpl_d.data_ptr(), l.wpl_t.data_ptr(), 1))
+            else:
+                sh = l.wshape()
+                rows.append((l.w.data_ptr(), sh[0] * sh[1], sh[2], sh[3], 0, 0, 1))
+        for lo, hi in ranges:
+            blo = max(lo, self.n_weights)
+            if hi > blo:
+                rows.append((base + 4 * blo, 1, 1, hi - blo, 0, 0, 0))
+        n = len(rows)
+        col = lambda i, ct: (ct * n)(*[r[i] for r in rows])                 # noqa: E731
+        tab = (n, col(0, ctypes.c_void_p), col(1, ctypes.c_int), col(2, ctypes.c_int), col(3, ctypes.c_int), col(4, ctypes.c_void_p),
+               col(5, ctypes.c_void_p), col(6, ctypes.c_int))
+        self._adam_tables[key] = tab
+        return tab
+
+    def adam_ranges_fused(self, ranges, lr_t, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """The fused L2 + Adam update of the flat ranges AND the re-split of their weights into the operand planes, one launch
+        (per 64 tensors) on the current stream; afterwards the planes of these ranges are current."""
+        ranges = [(lo, hi) for lo, hi in ranges if hi > lo]
+        if not ranges:
+            return
+        n, w, taps, R, Cc, d, t, reg = self._adam_table(ranges)
+        if n == 0:
+            return
+        check(_lib.lib().unflow_adam_planes_batched(n, w, taps, R, Cc, d, t, reg, self.n_planes, ptr(self.P), ptr(self.G), ptr(self.M),
+                                                    ptr(self.V), cf(grad_scale), cf(L2_SCALE), cf(lr_t), cf(beta1), cf(beta2), cf(eps),
+                                                    ptr(self.loss_acc if self.defer_l2 else None), self.stream()), "adam_planes")
+
     def adam_step(self, lr, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
         """tf.train.AdamOptimizer(beta1=0.9, beta2=0.999) update (train.py:151-152), TF formulation, with the
         slim.l2_regularizer(0.0004) gradient added for the weight tensors (biases are not regularised)."""
@@ -1155,6 +1212,10 @@ class FlowNetEngine:
         t = self.step_count
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
         self._wplanes_version = None       # the parameters change behind torch's back: their operand planes are stale
+        if self.fused_adam and self.dev.type == 'cuda':
+            self.adam_ranges_fused([(0, self.n_params)], lr_t, grad_scale, beta1, beta2, eps)
+            self._wplanes_version = self.P._version        # ... and were re-split by the same launch
+            return
         if self.defer_l2:   # the loss of THIS step gets its regularisation term from the pre-update parameters here
             check(_lib.lib().unflow_adam_step_regloss(ptr(self.P), ptr(self.G), ptr(self.M), ptr(self.V),
                                                       cl(self.n_params), cl(self.n_weights), cf(grad_scale), cf(L2_SCALE),

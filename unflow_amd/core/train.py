@@ -86,7 +86,9 @@ class StepRunner:
         """One eager pass (grows the workspaces), then one hipGraph per backward part."""
         e = self.eng
         e.refresh_weight_planes(force=True)
-        e.planes_external = self.reducer is not None     # from here on: re-split per bucket, after its update (_update)
+        # from here on the captured forward does not re-split the weights: the optimizer update does (fused kernel), or — two
+        # launches — the runner right after each bucket's update (_update)
+        e.planes_external = self.reducer is not None or (e.fused_adam and e.n_planes > 0)
         for k in range(self.nparts):
             self._part(k)
         torch.cuda.synchronize(e.dev)
@@ -122,6 +124,9 @@ class StepRunner:
         scale = 1.0 / self.world
 
         def update(ranges):
+            if e.fused_adam:
+                e.adam_ranges_fused(ranges, lr_t, scale)       # L2 + Adam + the planes of these ranges, one launch
+                return
             for lo, hi in ranges:
                 e.adam_range(lo, hi, lr_t, scale)
             if e.planes_external:
@@ -143,6 +148,8 @@ class StepRunner:
                 self.reducer.reduce_then(ranges, lambda r=upd: update(r))
         if self.reducer is not None:
             self.reducer.finish()
+        elif e.fused_adam:
+            e.adam_ranges_fused([(0, e.n_params)], lr_t, scale)
         else:
             e.adam_range(0, e.n_params, lr_t, scale)
         if e.planes_external:

@@ -1161,25 +1161,29 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 
 // dx[b, yy, x0+o, ci] (+)= sum_{ky,kx,co} dz[b, yy+1-ky, x0+o+1-kx, co] * w[ky,kx,ci,co]; wave = (row, strip, quad group);
 // the dz window of the strip is wave-uniform (scalar loads), lanes differ only in the channel quad.
+// A wave walks `ns` consecutive strips of its row with the quad's 72 filter values resident (round 6: one strip per wave
+// re-loaded them — 18 16-byte loads per lane — for every 8 pixels = 8 16-byte stores).
 template <int S>
-__global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdParams p) {
+__global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdParams p, int ns) {
   const int lane = threadIdx.x & 63;
-  const int strips = p.W / S;
+  const int strips = p.W / S, sblocks = strips / ns;
   const int Cq = p.Cin >> 2, groups = (Cq + 63) / 64;
-  const long njobs = (long)p.B * p.H * strips * groups;
+  const long njobs = (long)p.B * p.H * sblocks * groups;
   const long job = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6));
   if (job >= njobs) return;
   const int g = (int)(job % groups);
   const long j2 = job / groups;
-  const int xs = (int)(j2 % strips);
-  const long row = j2 / strips;
+  const int xsb = (int)(j2 % sblocks);
+  const long row = j2 / sblocks;
   const int yy = (int)(row % p.H);
   const long b = row / p.H;
-  const int x0 = xs * S;
   const int c4 = g * 64 + lane;
   const bool active = c4 < Cq;
   float wr[9][8];
   load_head_weights(p.w, p.Cin, c4, active, wr);
+#pragma unroll 1
+  for (int si = 0; si < ns; si++) {
+  const int x0 = (xsb * ns + si) * S;
   // dz window: rows yy-1..yy+1, columns x0-1..x0+S, 2 channels; zero outside the image
   float dzv[3];
 #pragma unroll
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
       dzw[r][i][0] = lane_bcast(dzv[r], 2 * i);
       dzw[r][i][1] = lane_bcast(dzv[r], 2 * i + 1);
     }
-  if (!active) return;
+  if (!active) continue;
 #pragma unroll
   for (int o = 0; o < S; o++) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1225,6 +1229,7 @@ __global__ __launch_bounds__(256) void head3_dgrad_strip_kernel(const SkinnyBwdP
     }
     *reinterpret_cast<float4*>(d) = v;
     store_planes4(p.po, (size_t)pxl, c4 * 4, v);
+  }
   }
 }
 
@@ -2010,9 +2015,12 @@ int unflow_conv2d_bwd_data_po(const float* dz, int lddz, const float* w, float* 
     SkinnyBwdParams p{dz, lddz, w, dx, lddx, act_src, ld_act, act_lo, act_hi, accumulate, B, H, W, Cin, k, pt, pl, po};
     const int S = (lddx % 4 == 0 && (!act_src || ld_act % 4 == 0)) ? head_strip(B, H, W, k, Cout) : 0;
     if (S) {
-      const long jobs = (long)B * H * (W / S) * cdiv(Cin / 4, 64);
-      if (S == 8) head3_dgrad_strip_kernel<8><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
-      else head3_dgrad_strip_kernel<4><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p);
+      // (round 6 measured and dropped: a wave walking 2 or 4 strips with its filter values resident — flow2's data gradient 37.8 ->
+      // 44.8 us, flow3's 24.6 -> 26.7: fewer, longer waves hide less of the store latency than the filter re-loads cost)
+      const int strips = W / S, ns = 1;
+      const long jobs = (long)B * H * (strips / ns) * cdiv(Cin / 4, 64);
+      if (S == 8) head3_dgrad_strip_kernel<8><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p, ns);
+      else head3_dgrad_strip_kernel<4><<<(int)((jobs + 3) / 4), 256, 0, st>>>(p, ns);
       return launch_status();
     }
     const long total = (long)B * H * W * (Cin / 4);

@@ -1626,6 +1626,117 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const WPlaneBatch b)
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused L2 + Adam + weight planes
+// Round 6: the optimizer update and the re-split of the updated weights in ONE pass.  adam_kernel
+// (train_misc.hip) streams P, G, M, V in and P, M, V out; weight_planes_kernel then reads the 157 MB of P it just wrote to
+// write 471 MB of planes.  Here a block owns a 64 x 64 tile of one tap of one tensor (weight_planes_kernel's own mapping),
+// updates it — the same expressions in the same order as adam_kernel: bit-identical parameters — keeps the new values in
+// its LDS tile and writes both plane copies from there: the second read of P and a launch are gone.  The table also takes
+// tensors WITHOUT planes (direct == transposed == NULL: the Cout = 2 layers) and the bias block (reg == 0: one pseudo-tensor of
+// taps = R = 1), so one launch covers a whole flat range of the parameter vector.
+struct AdamPlaneArgs {
+  float* P; const float* G; float* M; float* V;      // the four flat buffers (identical layout: a tensor's offset is w - P)
+  float gscale, l2, lr_t, b1, b2, eps;
+  float* loss_acc;                                   // non-NULL: += l2 * 0.5 * sum(p^2) over the regularised tensors (pre-update)
+};
+
+__global__ __launch_bounds__(256) void adam_planes_kernel(const WPlaneBatch b, const AdamPlaneArgs a, const unsigned long long reg_mask) {
+  __shared__ float tile[64][65];
+  __shared__ float red[4];
+  int di = 0;
+  while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].block0) di++;
+  const WPlaneDesc d = b.d[di];
+  const bool reg = (reg_mask >> di) & 1ull;
+  int lb = blockIdx.x - d.block0;
+  const int tc = lb % d.tiles_c; lb /= d.tiles_c;
+  const int tr = lb % d.tiles_r; lb /= d.tiles_r;
+  const int tap = lb;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int Cc8 = (d.Cc + 7) & ~7, R8 = (d.R + 7) & ~7;
+  const size_t base = (size_t)(d.w - a.P) + (size_t)tap * d.R * d.Cc;
+  float sq = 0.f;
+  const bool vec = (d.Cc & 3) == 0 && (base & 3) == 0;       // rows of whole, 16-byte aligned quads (every tensor of the engine)
+  if (vec) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int r = e >> 4, c = (e & 15) * 4;
+      float pv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < d.R && c0 + c < d.Cc) {
+        const size_t i = base + (size_t)(r0 + r) * d.Cc + c0 + c;
+        const f32x4_nt pq = *reinterpret_cast<const f32x4_nt*>(a.P + i);
+        const f32x4_nt gq = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(a.G + i));
+        f32x4_nt mq = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(a.M + i));
+        f32x4_nt vq = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(a.V + i));
+        f32x4_nt po;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float gr = gq[j] * a.gscale;
+          if (reg) {
+            gr += a.l2 * pq[j];
+            sq += pq[j] * pq[j];
+          }
+          mq[j] = a.b1 * mq[j] + (1.f - a.b1) * gr;
+          vq[j] = a.b2 * vq[j] + (1.f - a.b2) * (gr * gr);
+          po[j] = pq[j] - a.lr_t * mq[j] / (sqrtf(vq[j]) + a.eps);
+          pv[j] = po[j];
+        }
+        *reinterpret_cast<f32x4_nt*>(a.P + i) = po;
+        __builtin_nontemporal_store(mq, reinterpret_cast<f32x4_nt*>(a.M + i));
+        __builtin_nontemporal_store(vq, reinterpret_cast<f32x4_nt*>(a.V + i));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) tile[r][c + j] = pv[j];
+    }
+  } else {
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      float pn = 0.f;
+      if (r0 + r < d.R && c0 + c < d.Cc) {
+        const size_t i = base + (size_t)(r0 + r) * d.Cc + c0 + c;
+        const float pq = a.P[i];
+        float gr = a.G[i] * a.gscale;
+        if (reg) {
+          gr += a.l2 * pq;
+          sq += pq * pq;
+        }
+        const float mn = a.b1 * a.M[i] + (1.f - a.b1) * gr;
+        const float vn = a.b2 * a.V[i] + (1.f - a.b2) * (gr * gr);
+        a.M[i] = mn;
+        a.V[i] = vn;
+        pn = pq - a.lr_t * mn / (sqrtf(vn) + a.eps);
+        a.P[i] = pn;
+      }
+      tile[r][c] = pn;
+    }
+  }
+  __syncthreads();
+  if (d.direct) {
+    const long ps = (long)d.taps * d.R * Cc8;
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int r = e >> 3, c8 = (e & 7) * 8;
+      if (r0 + r >= d.R || c0 + c8 >= Cc8) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = tile[r][c8 + i];
+      put_planes8(d.direct, ps, b.n_planes, ((size_t)tap * d.R + r0 + r) * Cc8 + c0 + c8, v);
+    }
+  }
+  if (d.transposed) {
+    const long ps = (long)d.taps * d.Cc * R8;
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int r8 = (e & 7) * 8, c = e >> 3;
+      if (c0 + c >= d.Cc || r0 + r8 >= R8) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = tile[r8 + i][c];
+      put_planes8(d.transposed, ps, b.n_planes, ((size_t)tap * d.Cc + c0 + c) * R8 + r0 + r8, v);
+    }
+  }
+  if (a.loss_acc && reg) {          // (block-uniform condition: block_sum's barriers are safe)
+    const float t = block_sum(sq, red);
+    if (threadIdx.x == 0) atomicAdd(a.loss_acc, t * 0.5f * a.l2);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct PlPlan {
   int cfg;  // 0: 128x128, 1: 128x64, 2: 64x64
@@ -2084,6 +2195,39 @@ UNFLOW_API int unflow_weight_planes_batched(int n, const float* const* w, const 
       blocks += d.taps * d.tiles_r * d.tiles_c;
     }
     if (blocks > 0) weight_planes_kernel<<<blocks, 256, 0, st>>>(b);
+  }
+  return launch_status();
+}
+
+UNFLOW_API int unflow_adam_planes_batched(int n, float* const* w, const int* taps, const int* R, const int* Cc, void* const* direct,
+                                          void* const* transposed, const int* regularized, int n_planes, float* P, const float* G,
+                                          float* M, float* V, float grad_scale, float l2_scale, float lr_t, float beta1, float beta2,
+                                          float eps, float* loss_acc, unflow_stream_t stream) {
+  if (!w || !taps || !R || !Cc || !direct || !transposed || !regularized || !P || !G || !M || !V) return UNFLOW_ERR_NULL;
+  if (n_planes != 0 && n_planes != 1 && n_planes != 3) return UNFLOW_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  AdamPlaneArgs a{P, G, M, V, grad_scale, l2_scale, lr_t, beta1, beta2, eps, loss_acc};
+  for (int i0 = 0; i0 < n; i0 += MAX_WDESC) {
+    WPlaneBatch b{};
+    b.n = min(n - i0, MAX_WDESC);
+    b.n_planes = n_planes ? n_planes : 3;
+    unsigned long long reg_mask = 0;
+    int blocks = 0;
+    for (int i = 0; i < b.n; i++) {
+      WPlaneDesc& d = b.d[i];
+      if (!w[i0 + i] || taps[i0 + i] <= 0 || R[i0 + i] <= 0 || Cc[i0 + i] <= 0 || w[i0 + i] < P) return UNFLOW_ERR_SHAPE;
+      if (!n_planes && (direct[i0 + i] || transposed[i0 + i])) return UNFLOW_ERR_UNSUPPORTED;
+      d.w = w[i0 + i];
+      d.direct = reinterpret_cast<unsigned short*>(direct[i0 + i]);
+      d.transposed = reinterpret_cast<unsigned short*>(transposed[i0 + i]);
+      d.taps = taps[i0 + i]; d.R = R[i0 + i]; d.Cc = Cc[i0 + i];
+      d.tiles_r = cdiv(d.R, 64);
+      d.tiles_c = cdiv(d.Cc, 64);
+      d.block0 = blocks;
+      blocks += d.taps * d.tiles_r * d.tiles_c;
+      if (regularized[i0 + i]) reg_mask |= 1ull << i;
+    }
+    if (blocks > 0) adam_planes_kernel<<<blocks, 256, 0, st>>>(b, a, reg_mask);
   }
   return launch_status();
 }

@@ -20,13 +20,26 @@
 // workgroup becomes resident without any other one having to finish.  Every spin is bounded (g_sk_timeouts).
 // Hand-off (cdna_hip_programming.md §5 / Guideline 16, write-through form): 16-byte sc1 stores -> s_waitcnt vmcnt(0) in
 // every wave -> workgroup barrier -> relaxed agent-scope flag store; the reader polls relaxed, passes a barrier, and reads
-// the slab with sc1 loads (served by L2 / fabric, never a stale L1 line).  Flags are zeroed by a memset node ahead of the launch.
+// the slab with sc1 loads (served by L2 / fabric, never a stale L1 line).  The flags clean themselves (g_sk_flags below).
+#include <mutex>
+
 #include "planes_shared.h"
 
 namespace {
 using namespace igemm;
 
 __device__ int g_sk_timeouts;      // spins that gave up (a result is then wrong; the tests assert 0)
+
+// Arrival flags.  Round 6: they live in the library's own device memory instead of the caller's workspace and CLEAN THEMSELVES —
+// every raised flag has exactly one waiter (the workgroup that started the item), which resets it once it has passed — so a
+// launch finds them zero (module load zero-initialises them) and the memset node in front of every stream-K launch (5 per
+// training step, 5-6 us each on the critical path) is gone.  One row of flags per WORKSPACE: launches that share a workspace
+// share its slabs and are serialised by their caller anyway, so keying the flags by the workspace pointer adds no constraint
+// (host table sk_flag_slot; more than SK_FLAG_SLOTS distinct workspaces or G > SK_MAX_G: the old way, flags behind the slabs
+// + memset).  A spin that timed out leaves its flag raised: unflow_debug_streamk_timeouts() — which every caller of this path
+// polls, and whose non-zero result is fatal — clears the flags along with the counter.
+constexpr int SK_FLAG_SLOTS = 64, SK_MAX_G = 512;
+__device__ int g_sk_flags[SK_FLAG_SLOTS][SK_MAX_G];
 
 struct SkPlan {
   int G;                   // persistent workgroups
@@ -37,7 +50,8 @@ struct SkPlan {
   int nchunk;              // 32-channel chunks per item
   int ntaps[4];            // K tiles per chunk, by class
   unsigned wfull, wall;    // K tiles of a full group / of the launch
-  int* flags;              // [G] arrival flags of the slabs
+  int* flags;              // [G] arrival flags of the slabs (workspace form), or nullptr: row `slot` of g_sk_flags
+  int slot;
   float* slabs;            // [G][2 instances][4 waves][16 float4 rows][64 lanes] float4
 };
 
@@ -116,6 +130,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
   const int wg = xcd_remap(blockIdx.x, gridDim.x, p.xcd);          // logical id: an XCD runs a contiguous run of the item list
   const unsigned pos_begin = sk_pos(sk, wg), pos_end = sk_pos(sk, wg + 1);
   if (pos_begin >= pos_end) return;
+  int* const flags = sk.flags ? sk.flags : g_sk_flags[sk.slot];
 
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(sk.flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_store(flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
     if (k1 < nk) {
@@ -372,10 +387,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_halo_sk_kernel(const PlGather
         if (sk_pos(sk, w2 + 1) <= pa) continue;                  // an empty range: holds nothing
         if (threadIdx.x == 0) {
           int spins = 0;
-          while (__hip_atomic_load(sk.flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          while (__hip_atomic_load(flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > SK_SPIN_LIMIT) { atomicAdd(&g_sk_timeouts, 1); break; }
           }
+          // the one waiter of this flag has passed: lower it for the next launch on this workspace (nobody raises it again in
+          // this one: a workgroup writes at most one slab per launch)
+          if (spins <= SK_SPIN_LIMIT) __hip_atomic_store(flags + w2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const int soff = w2 * SK_SLAB_BYTES;
@@ -454,6 +472,20 @@ bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn) {
   return o >= 2 || (sk.ncls == 1 && min_nk >= 64 && sk.wall >= 48u * (unsigned)sk.G);
 }
 
+// row of g_sk_flags that belongs to workspace `ws` on the current device (first come, first served; -1: table full)
+static int sk_flag_slot(const void* ws) {
+  static std::mutex mu;
+  static const void* owner[UNFLOW_MAX_DEVICES][SK_FLAG_SLOTS];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= UNFLOW_MAX_DEVICES) return -1;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < SK_FLAG_SLOTS; i++) {
+    if (owner[dev][i] == ws) return i;
+    if (!owner[dev][i]) { owner[dev][i] = ws; return i; }
+  }
+  return -1;
+}
+
 int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st) {
   if (!ws || ws_bytes < pl_halo_sk_ws_bytes()) return UNFLOW_ERR_WORKSPACE;
   const int hp = pl_halo_pixels(p);
@@ -467,8 +499,13 @@ int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStr
   sk_plan_of(p, sk);
   if (!sk_fill(sk, unflow::options().streamk_groups)) return UNFLOW_ERR_UNSUPPORTED;
   sk.slabs = reinterpret_cast<float*>(ws);
-  sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)sk.G * SK_SLAB_BYTES);
-  if (hipMemsetAsync(sk.flags, 0, (size_t)sk.G * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  sk.slot = sk.G <= SK_MAX_G ? sk_flag_slot(ws) : -1;
+  sk.flags = nullptr;
+  if (sk.slot < 0) {                             // no row left for this workspace: flags behind the slabs, zeroed per launch
+    sk.slot = 0;
+    sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)sk.G * SK_SLAB_BYTES);
+    if (hipMemsetAsync(sk.flags, 0, (size_t)sk.G * sizeof(int), st) != hipSuccess) return UNFLOW_ERR_LAUNCH;
+  }
   if (p.acc) igemm_pl_halo_sk_kernel<3, false, true><<<sk.G, 512, smem, st>>>(q, sk, hp);
   else igemm_pl_halo_sk_kernel<3, false, false><<<sk.G, 512, smem, st>>>(q, sk, hp);
   return launch_status();
@@ -499,5 +536,10 @@ UNFLOW_API int unflow_debug_streamk_timeouts(void) {
   int v = 0, zero = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sk_timeouts), sizeof(int)) != hipSuccess) return -1;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_timeouts), &zero, sizeof(int));
+  if (v != 0) {                                  // a waiter gave up: its flag may still be raised (or be raised later)
+    static const int zeros[SK_FLAG_SLOTS * SK_MAX_G] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sk_flags), zeros, sizeof(zeros));
+  }
   return v;
 }

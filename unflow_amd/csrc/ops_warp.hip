@@ -1025,22 +1025,24 @@ UNFLOW_API int unflow_image_pyramid5(const float* images, float* const* levels, 
 // [oy*sy, (oy+1)*sy) x [ox*sx, (ox+1)*sx), sy = H / oh, sx = W / ow: a source pixel counts with the covered fraction of its
 // unit square; indices clamped to the image like TF's BOUND.  One thread per output element (channels fastest); the
 // reference calls it only for odd-sized tensors, once per pyramid level, off the training step.
-__global__ void resize_area_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H, int W, int C, int oh, int ow,
-                                   float sy, float sx) {
+__global__ void resize_area_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H, int W, int C, int oh, int ow) {
   const long n = (long)B * oh * ow * C;
-  const float inv = 1.0f / (sy * sx);
+  // source intervals in fp64 (TF's kernel forms x * scale in fp32: at x ~ 1200 that is 1e-4 of a pixel of coverage, 5e-5 of the
+  // result; the exact intervals are the definition, and this runs once per odd-sized level, off the step)
+  const double sy = (double)H / (double)oh, sx = (double)W / (double)ow;
+  const float inv = (float)(1.0 / (sy * sx));
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % C);
     const int ox = (int)((e / C) % ow), oy = (int)((e / C / ow) % oh);
     const long b = e / ((long)C * ow * oh);
-    const float y0 = oy * sy, y1 = (oy + 1) * sy, x0 = ox * sx, x1 = (ox + 1) * sx;
+    const double y0 = oy * sy, y1 = (oy + 1) * sy, x0 = ox * sx, x1 = (ox + 1) * sx;
     float s = 0.f;
-    for (int j = (int)floorf(y0); j < (int)ceilf(y1); j++) {
-      const float wy = (j < y0 ? (float)(j + 1) - y0 : ((float)(j + 1) > y1 ? y1 - (float)j : 1.0f));
+    for (int j = (int)floor(y0); j < (int)ceil(y1); j++) {
+      const float wy = (float)(fmin(y1, (double)(j + 1)) - fmax(y0, (double)j));
       const int jj = j < 0 ? 0 : (j > H - 1 ? H - 1 : j);
       float row = 0.f;
-      for (int i = (int)floorf(x0); i < (int)ceilf(x1); i++) {
-        const float wx = (i < x0 ? (float)(i + 1) - x0 : ((float)(i + 1) > x1 ? x1 - (float)i : 1.0f));
+      for (int i = (int)floor(x0); i < (int)ceil(x1); i++) {
+        const float wx = (float)(fmin(x1, (double)(i + 1)) - fmax(x0, (double)i));
         const int ii = i < 0 ? 0 : (i > W - 1 ? W - 1 : i);
         row += wx * img[((b * H + jj) * W + ii) * C + c];
       }
@@ -1055,8 +1057,7 @@ UNFLOW_API int unflow_resize_area(const float* images, float* out, int B, int H,
   if (!images || !out) return UNFLOW_ERR_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || out_h <= 0 || out_w <= 0) return UNFLOW_ERR_SHAPE;
   const long n = (long)B * out_h * out_w * C;
-  resize_area_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(images, out, B, H, W, C, out_h, out_w, (float)H / (float)out_h,
-                                                                    (float)W / (float)out_w);
+  resize_area_kernel<<<stream_grid(n), 256, 0, as_stream(stream)>>>(images, out, B, H, W, C, out_h, out_w);
   return launch_status();
 }
 
