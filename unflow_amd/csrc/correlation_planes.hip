@@ -62,6 +62,7 @@ struct CorrPlParams {
   int joff; // column-tile offset: 0, or -r in narrow-band mode
 };
 
+
 __global__ __launch_bounds__(256) void corr_fwd_pl_kernel(const CorrPlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int tid = threadIdx.x, lane = tid & 63, pg = tid >> 6;
@@ -554,13 +555,19 @@ __global__ __launch_bounds__(512, 1) void corr_fwd_ring_kernel(const CorrPlParam
     const unsigned d = f1_addr + (unsigned)(sl * RG_SLOT + hh * 1024);
     dma3(cc < nchunk ? d_off[k] + cc * 64 : OOB_MARK, f1_rs[0], f1_rs[1], f1_rs[2], d, d + 2048, d + 4096);
   };
-  u32x4 afn[2][3];                                     // f0 fragments of the NEXT chunk, in flight
-  auto request_a = [&](int cc) __attribute__((always_inline)) {
+  // f0 fragments: TWO register sets in turn (chunk c multiplies out of set c & 1 while the loads of chunk c + 1 land in the
+  // other).  Round 5 carried ONE in-flight set across the loop back-edge: the compiler's phi copy (`v_mov_b64 v[108:131] <-
+  // v[132:155]` at the END of the body) read the registers before any wait that covered the inline-asm loads — VGPR reads are
+  // not interlocked with VMEM returns, the compiler knows nothing about loads issued by inline asm.  With
+  // two named sets there is no loop-carried copy at all; each set still enters its chunk only through a wait tied to it.
+  // tools/isa_load_hazard.py scans the assembly for any touch of a register with a load in flight.
+  u32x4 fa[2][3], fb[2][3];
+  auto request_a = [&](u32x4 (&dst)[2][3], int cc) __attribute__((always_inline)) {
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
       const int off = cc < nchunk ? a_off[rt] + cc * 64 : OOB_MARK;
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) afn[rt][pl] = asm_ld16(f0_rs[pl], off);
+      for (int pl = 0; pl < 3; pl++) dst[rt][pl] = asm_ld16(f0_rs[pl], off);
     }
   };
   f32x4 acc[RG_GW][3];
@@ -575,34 +582,26 @@ __global__ __launch_bounds__(512, 1) void corr_fwd_ring_kernel(const CorrPlParam
 
   // chunk 0 in the steady state's order: rows 0..7, fragments, rows 8..11, rows 12..15
   request(0, 0, 0); request(1, 0, 0);
-  request_a(0);
+  request_a(fa, 0);
   request(2, 0, 0);
   request(3, 0, 0);
-  // The fragment registers are loop-carried and the compiler knows nothing about loads issued by inline asm: whatever copy it
-  // needs for the loop phi (it did place `v_mov_b64 v[108:131] <- v[132:155]` at the END of the body, before any covering
-  // wait: ADVICE round 5) must come AFTER the data has landed.  VGPR reads are not interlocked with VMEM returns, so the
-  // values enter the loop — here and at the end of the body — only through a wait that is tied to them: vmcnt(6) leaves the
-  // two youngest row requests (steps 4 and 8: 3 + 3 DMA loads) in flight.  tools/isa_load_hazard.py scans the assembly for it.
-#define RG_LAND_FRAGMENTS()                                                                                                     \
-  asm volatile("s_waitcnt vmcnt(6)"                                                                                              \
-               : "+v"(afn[0][0]), "+v"(afn[0][1]), "+v"(afn[0][2]), "+v"(afn[1][0]), "+v"(afn[1][1]), "+v"(afn[1][2])::"memory")
-  RG_LAND_FRAGMENTS();
   int cb = 0;                                          // (16 c) mod 24
-  for (int c = 0; c < nchunk; c++) {
+  // one chunk: multiply out of `cur` (requested a chunk ago), request chunk c + 1's fragments into `nxt`
+  auto chunk = [&](int c, u32x4 (&cur)[2][3], u32x4 (&nxt)[2][3]) __attribute__((always_inline)) {
     int cbn = cb + 16;
     cbn = cbn >= RG_NS ? cbn - RG_NS : cbn;
-    // ---- step 0
+    // ---- step 0: rows 0..11 of this chunk and its fragments have landed (the step-8 request of the last chunk may still be out)
     asm volatile("s_waitcnt vmcnt(3)"
-                 : "+v"(afn[0][0]), "+v"(afn[0][1]), "+v"(afn[0][2]), "+v"(afn[1][0]), "+v"(afn[1][1]), "+v"(afn[1][2])::"memory");
+                 : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[0][2]), "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[1][2])::"memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     s16x8 af[2][3];
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) af[rt][pl] = __builtin_bit_cast(s16x8, afn[rt][pl]);
+      for (int pl = 0; pl < 3; pl++) af[rt][pl] = __builtin_bit_cast(s16x8, cur[rt][pl]);
     request(0, c + 1, cbn); request(1, c + 1, cbn);
-    request_a(c + 1);
+    request_a(nxt, c + 1);
     s16x8 bf[2][2][3];                                 // [step parity][column tile][plane]
     auto rd = [&](int j, s16x8 (&f)[2][3]) __attribute__((always_inline)) {
       int sl = cb + wid + j;
@@ -630,10 +629,21 @@ __global__ __launch_bounds__(512, 1) void corr_fwd_ring_kernel(const CorrPlParam
                                                               __builtin_bit_cast(bf16x8, bf[j & 1][pct[pr]][tb[tt]]), acc[j][pr], 0, 0, 0);
     }
     cb = cbn;
-    RG_LAND_FRAGMENTS();                               // (issued at step 0, nine steps of products ago: this does not stall)
+  };
+  int c = 0;
+#pragma unroll 1
+  for (; c + 1 < nchunk; c += 2) {
+    chunk(c, fa, fb);
+    chunk(c + 1, fb, fa);
   }
-#undef RG_LAND_FRAGMENTS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the out-of-range requests past the last chunk write zeros: let them land
+  if (c < nchunk) chunk(c, fa, fb);
+  // The requests past the last chunk are out of range (zeros): let them land — the ring's rows before its LDS is reused, and
+  // the fragment loads before their registers are: a destination the compiler considers dead would be handed to the next
+  // value while the load is still in flight (it did: the scanner found the last chunk's B fragments in those registers), so
+  // both sets stay live up to this wait.
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fb[0][0]),
+                 "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2])::"memory");
   __syncthreads();                                     // the ring is dead: its LDS becomes the band staging
   // acc[j][pr][e] of lane (column l15, quarter q) is the product of f0 site s0 = 16 rt + 4 q + e and staged site s1 = 16 ct + l15
   // (x = i0 - 4 + s1): band offset index s1 - s0.  Staging [site][displacement row][offset], one area per wave.
