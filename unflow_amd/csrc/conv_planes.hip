@@ -1790,7 +1790,7 @@ inline PlPlan plan_pl_gather(const GatherGeom& p, int npl) {
     const double fill = (double)b / (double)(((b + 255) / 256) * 256);
     bool even = true;
     for (int c = 1; c < p.ncls; c++) even = even && p.cls[c].nty * p.cls[c].ntx == p.cls[0].nty * p.cls[0].ntx;
-    if (unflow::options().gather_pp >= 2 || (fill >= 0.85 && even)) { pl.pp = true; pl.nsplit = ns; }
+    if (unflow::options().gather_pp >= 2 || (fill >= 0.01 * unflow::options().gather_pp_fill && even)) { pl.pp = true; pl.nsplit = ns; }
   }
   return pl;
 }
@@ -1980,7 +1980,9 @@ inline bool pl_wgrad_pp_ok(const WgradGeom& p, int npl) {
   const int o = unflow::options().wgrad_pp;
   if (o <= 0 || npl != 3 || p.Cb <= 64 || p.KH * p.KW * p.Ca < 256) return false;
   if (o >= 3) return true;
-  return p.Cb > 128 && (long)p.B * p.Hg * p.Wg >= 6144;
+  // (round 6, per-layer A/B of wgrad_pp = 3 against this rule, profiles/r06_planner_per_layer_ab.txt: the 1028 -> 256
+  // conv_transpose at 1536 sites gains 17 us of 106, the layers at 384 sites lose 14-18 us, everything between is neutral)
+  return p.Cb > 128 && (long)p.B * p.Hg * p.Wg >= 1536;
 }
 inline int pl_wgrad_pp_bn(const WgradGeom& p) { return p.Cb > 128 ? 256 : 128; }
 
