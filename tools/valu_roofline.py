@@ -28,9 +28,10 @@ for r in csv.DictReader(open(f)):
     e = disp.setdefault(int(r['Dispatch_Id']), dict(name=n, us=(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, c={}))
     e['c'][r['Counter_Name']] = float(r['Counter_Value'])
 by = defaultdict(list)
-for i in sorted(disp):
-    by[disp[i]['name']].append(disp[i])
-print("%-44s %4s %9s %5s %8s %9s %9s" % ("kernel", "n", "us", "GHz", "valu/px", "trans/px", "pipe occ"))
+for i in sorted(disp):        # one row per (kernel, instruction count): a kernel launched with different template / run-time parameters
+    e = disp[i]               # (the census at max_distance 1 and 3) executes different instruction counts per pixel
+    by["%s [%d valu/px]" % (e['name'], round(e['c'].get('SQ_INSTS_VALU', 0.0) * 64 / npix))].append(e)
+print("%-56s %4s %9s %5s %8s %9s %9s" % ("kernel", "n", "us", "GHz", "valu/px", "trans/px", "pipe occ"))
 for n, v in by.items():
     v = v[1:] if len(v) > 1 else v
     avg = lambda k: sum(e['c'].get(k, 0.0) for e in v) / len(v)      # noqa: E731
@@ -38,4 +39,4 @@ for n, v in by.items():
     ghz = avg('GRBM_GUI_ACTIVE') / 8 / (us * 1e3)
     valu, trans = avg('SQ_INSTS_VALU'), avg('SQ_INSTS_VALU_TRANS_F32')
     occ = (valu * 2 + trans * 6) / (1024 * us * 1e3 * ghz) if ghz > 0 else float('nan')
-    print("%-44s %4d %9.1f %5.2f %8.1f %9.1f %8.0f%%" % (n[:44], len(v), us, ghz, valu * 64 / npix, trans * 64 / npix, occ * 100))
+    print("%-56s %4d %9.1f %5.2f %8.1f %9.1f %8.0f%%" % (n[:56], len(v), us, ghz, valu * 64 / npix, trans * 64 / npix, occ * 100))

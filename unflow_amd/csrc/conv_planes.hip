@@ -522,7 +522,8 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   constexpr int B_PLANE = BN * LDH;
   constexpr int NB = BN / 64;
   constexpr int NH = 4;                          // halo granules per thread and plane (covers 256 pixels)
-  constexpr int NT = NPL == 3 ? 6 : 1;
+  constexpr int NT = mfma_nt(NPL, F16);
+  constexpr int KCH = F16 ? NPL : 1;            // 32-channel chunks per K tile (fp16: the planes ARE consecutive chunks)
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   const int H_PLANE = HPmax * HPITCH;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   const TapClass tc = p.cls[c_first];           // (geometry of the pixel table; the first class to load / multiply)
   const int n0 = ntile * BN;
   const int Cg = p.Cs >> 3;
-  const int nchunk = (Cg + 3) >> 2;
+  const int nchunk = (((Cg + 3) >> 2) + KCH - 1) / KCH;        // chunks of 32 KCH channels
   const int ch_per = (nchunk + p.nsplit - 1) / p.nsplit;
   const int ch0 = split * ch_per, ch1 = min(nchunk, (split + 1) * ch_per);
   int sumtaps = 0, mtx = 0;
@@ -567,8 +568,9 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
 #pragma unroll
   for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2);
-    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2);
+    // (fp16 chunk planes: plane pl starts 64 pl bytes into the tensor — the range shrinks by as much)
+    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2 - (KCH > 1 ? pl * 64 : 0));
+    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2 - (KCH > 1 ? pl * 64 : 0));
   }
   const int kq = tid & 3;
   const int lds2 = p.lds * 2;
@@ -607,16 +609,20 @@ __global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherPar
   bool ld_live = T > 0;
   auto load_b = [&](int i) {
     const int widx = (ltc.ky0 + ld_ty * p.kstep) * p.KW + ltc.kx0 + ld_tx * p.kstep;
-    const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
-    const int voff = ok ? b_row[i] + widx * p.N * p.Cs * 2 + ld_chunk * 64 : OOB_MARK;
+    const int voff = b_row[i] + widx * p.N * p.Cs * 2 + ld_chunk * (64 * KCH);
 #pragma unroll
-    for (int pl = 0; pl < NPL; pl++) rb[i][pl] = buf_ld16(w_rs[pl], voff);
+    for (int pl = 0; pl < NPL; pl++) {
+      const bool ok = ld_live && (ld_chunk * KCH + (KCH > 1 ? pl : 0)) * 4 + kq < Cg;
+      rb[i][pl] = buf_ld16(w_rs[pl], ok ? voff : OOB_MARK);
+    }
   };
   auto load_h = [&](int j) {
-    const bool ok = ld_live && ld_chunk * 4 + kq < Cg;
-    const int voff = ok ? h_off[j] + ld_chunk * 64 : OOB_MARK;
+    const int voff = h_off[j] + ld_chunk * (64 * KCH);
 #pragma unroll
-    for (int pl = 0; pl < NPL; pl++) rh[j][pl] = buf_ld16(src_rs[pl], voff);
+    for (int pl = 0; pl < NPL; pl++) {
+      const bool ok = ld_live && (ld_chunk * KCH + (KCH > 1 ? pl : 0)) * 4 + kq < Cg;     // (h_off may be OOB_MARK itself: stays out of range)
+      rh[j][pl] = buf_ld16(src_rs[pl], ok ? voff : OOB_MARK);
+    }
   };
   auto ld_advance = [&](int kk_next) {     // the loads now target tile kk_next + 1... called after tile kk_next's loads
     ld_tx++;
@@ -1892,13 +1898,37 @@ inline bool pl_halo_acc_pays(const GatherGeom& a) {
 inline int pl_halo_smem(const GatherGeom& p, int bn, int npl) {
   return pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, npl, pl_halo_pixels(p)) + 128 * 4 + 16;
 }
+// fp16 launches of the halo kernel may run with two chunk planes: K tiles of 64 channels (mfma_terms, planes_shared.h)
+constexpr int F16_KCH = 2;
+inline int f16_kch(const GatherGeom& p, int npl) {
+  if (npl != 1) return 1;
+  const int o = unflow::options().f16_k64;
+  if (o >= 2) return F16_KCH;
+  if (o <= 0) return 1;
+  // Where it pays (per-layer A/B at B = 8, profiles/r06_f16_per_layer_ab.txt): SHORT items whose K loop is mostly loop overhead at 8
+  // MFMAs per tile — the conv_transpose forwards (four classes of exactly 2 x 2 taps: -9 .. -19 us) and the 3 x 3 stride-2 forwards
+  // (accumulating classes, 9 taps in all: conv4 -19 us).  Long items lose (the halo of a 64-channel chunk arrives in one burst:
+  // conv3_1 +22 us), and so do the uneven parity classes of the stride-2 data gradients (+11 us).
+  int sum = 0;
+  bool four = true;
+  for (int c = 0; c < p.ncls; c++) {
+    sum += p.cls[c].nty * p.cls[c].ntx;
+    four = four && p.cls[c].nty * p.cls[c].ntx == 4;
+  }
+  return (p.acc ? sum <= 9 : (p.ncls == 4 && four)) ? F16_KCH : 1;
+}
+// (fp16, round 6, measured and dropped: a 128 x 256 workgroup tile with 128 x 64 wave tiles — 6 LDS fragment reads per 8 MFMAs
+// instead of 8 — as an instantiation of this kernel: the 128-register accumulator tile went to scratch (3,000 basic blocks, 576
+// bytes of private segment per lane with one or two workgroups per CU alike) and the layers ran 8x slower; the wave-tile change
+// needs its own kernel, not a template argument.)
 inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
   const int bn = p.N <= 64 ? 64 : 128;
   *bn_out = bn;
-  const int smem = pl_halo_smem(p, bn, npl);
+  const int kch = f16_kch(p, npl);
+  const int smem = pl_halo_smem(p, bn, npl == 1 ? kch : npl);
   const int per_cu = min((160 * 1024) / smem, bn == 128 ? 2 : 3);
   const long blocks = (long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) * cdiv(p.N, bn) * pl_grid_classes(p);
-  const int nchunk = ((p.Cs >> 3) + 3) >> 2;
+  const int nchunk = ((((p.Cs >> 3) + 3) >> 2) + kch - 1) / kch;
   int maxtaps = 0, sumtaps = 0;
   for (int c = 0; c < p.ncls; c++) {
     maxtaps = max(maxtaps, p.cls[c].nty * p.cls[c].ntx);
@@ -1909,16 +1939,17 @@ inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
   return min(nchunk, fill_one_round(blocks, 256 * per_cu, max_by_k));
 }
 
-template <int BN, int WN, int NPL, bool F16>
+template <int BN, int WN, int NPL, bool F16, int WM = 64>
 int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   const int hp = pl_halo_pixels(p);
   const int smem = pl_halo_main_bytes(BN, WN, NPL, hp) + 128 * 4 + 16;
   static DynLdsBook book{};     // grow-only per device (the halo size depends on the layer)
-  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, 64, WN, NPL, F16>), smem, book);
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, WM, WN, NPL, F16>), smem, book);
   PlGatherParams q = p;
+  if (F16 && NPL > 1) q.src_ps = q.w_ps = 32;          // chunk planes: plane pl = channels 32 pl .. of the fp16 plane
   q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
   const int grid = pl_grid(q);
-  igemm_pl_halo_kernel<BN, 64, WN, NPL, F16><<<grid, 256, smem, st>>>(q, hp);
+  igemm_pl_halo_kernel<BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q, hp);
   return launch_status();
 }
 
@@ -1956,7 +1987,8 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   int code;
   if (halo) {
     if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
-    else code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
+    else if (f16_kch(p, npl) == 1) code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
+    else code = halo_bn == 128 ? launch_pl_halo<128, 64, F16_KCH, true>(p, st) : launch_pl_halo<64, 32, F16_KCH, true>(p, st);
   } else {
     code = pl.pp ? launch_pl_gather_pp(p, st) : npl == 3 ? run_pl_gather_mode<3, false>(p, pl.cfg, st) : run_pl_gather_mode<1, true>(p, pl.cfg, st);
   }

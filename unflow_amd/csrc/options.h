@@ -14,6 +14,7 @@
   X(wgrad_min_kt, 8)      /* split-K of the filter gradients: at least this many 32-site tiles per split */               \
   X(gather_pp, 1)         /* ping-pong gather kernel (two 128 x 128 tiles per 8-wave workgroup): 1 where it pays, 2 wherever eligible */ \
   X(gather_pp_fill, 60)   /* ... gather_pp = 1: taken when one round of 8-wave workgroups fills at least this % of the CUs (equal tap counts) */ \
+  X(f16_k64, 1)           /* fp16 halo launches with K tiles of 64 channels (two chunk planes): 0 never, 1 short items (conv_transpose forward, 3x3 stride-2 forward), 2 always */ \
   X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
   X(conv1_direct, 1)      /* FlowNetC's first layer on its own kernel (conv_first.hip: rows staged once per tile, filter resident) */ \
   X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \

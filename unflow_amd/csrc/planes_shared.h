@@ -82,10 +82,16 @@ __host__ __device__ __forceinline__ void work_decode(int v, int mt, int nt, int 
   s = v / ncls;
 }
 
+// F16 with NPL > 1 (round 6, BASELINE configs[4]): the "planes" of an fp16 launch are NPL CONSECUTIVE 32-channel chunks of the
+// one fp16 plane (plane stride = 32 elements): a K tile is then 32 NPL channels deep — NPL products (chunk t of A with chunk t
+// of B) per fragment pair instead of the six cross terms of the bf16 split — with the kernel's staging, LDS image and loop
+// unchanged: NPL x the MFMAs between two barriers (mfma_nt below is the term count of a (NPL, F16) pair).
+constexpr int mfma_nt(int npl, bool f16) { return f16 ? npl : (npl == 3 ? 6 : 1); }
 template <int NPL, bool F16>
 __device__ __forceinline__ void mfma_terms(const s16x8 (&av)[NPL], const s16x8 (&bv)[NPL], f32x16& acc, int t) {
   if constexpr (F16) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[0]), __builtin_bit_cast(f16x8, bv[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[NPL > 1 ? t : 0]), __builtin_bit_cast(f16x8, bv[NPL > 1 ? t : 0]),
+                                                 acc, 0, 0, 0);
   } else if constexpr (NPL == 1) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[0]), __builtin_bit_cast(bf16x8, bv[0]), acc, 0, 0, 0);
   } else {
