@@ -1064,9 +1064,15 @@ __global__ __launch_bounds__(256, (NPL == 3 && BM == 128 && BN == 128) ? 3 : 1) 
 // tile and combining through the stage buffers after the loop — a third of the 50 MB of partial sums per layer: neutral
 // where one round of such workgroups fills the chip (conv1 / conv2 / conv3 / deconv2), 8 % slower on conv3_1 at 80 % fill;
 // the shared per-stage barrier couples the 12 waves.  No MFMAs for sub-tiles beyond the last M / N tile: neutral.)
-template <int BN, int WN>
+// F16 (round 6, BASELINE configs[4]): the operands are ONE fp16 plane; the three "planes" of a stage are then three CONSECUTIVE
+// 16-site groups (a stage = 48 sites), each fetched with its own site offsets through the same descriptor, and a fragment set
+// takes three products (group t of A with group t of B: mfma_terms<3, true>) instead of the six cross terms — the staging, the
+// LDS image, the transposing reads and the loop are the bf16 kernel's.  (The register-staged fp16 kernel it replaces ran 8
+// MFMAs between two barriers around a ds_write pass.)
+template <int BN, int WN, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgradParams p) {
   constexpr int BM = 128, WM = 64, NPL = 3, KS = 16;
+  constexpr int GPS = F16 ? 3 : 1;                               // 16-site groups per stage
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves");
@@ -1091,8 +1097,9 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   const int split = v / p.nt;
   const int m0 = mtile * BM, n0 = ntile * BN;
   const int S = p.B * p.Hg * p.Wg;
-  const int KT = (S + KS - 1) / KS;
-  const int kt_per = (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;   // whole 32-site tiles per split, as the planner counts them
+  const int KT = ((S + KS - 1) / KS + GPS - 1) / GPS;            // stages
+  const int kt_per = F16 ? (KT + p.nsplit - 1) / p.nsplit
+                         : (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;   // whole 32-site tiles per split, as the planner counts them
   const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
 
   // buffer descriptors as plain dwords (the LDS-DMA loads are inline asm: hipcc would otherwise wait vmcnt(0) in front of
@@ -1100,8 +1107,8 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   u32x4 src_rs[NPL], dst_rs[NPL];
 #pragma unroll
   for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = raw_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
-    dst_rs[pl] = raw_rsrc(p.dst + pl * p.dst_ps, (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
+    src_rs[pl] = raw_rsrc(p.src + (F16 ? 0 : pl * p.src_ps), (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
+    dst_rs[pl] = raw_rsrc(p.dst + (F16 ? 0 : pl * p.dst_ps), (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
   }
 
   // gathered operand: lane -> (site row 4*wid + lane/16 of the stage, slot lane%16); the granule stored in that slot
@@ -1128,7 +1135,7 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   const unsigned magW = (unsigned)((0x100000000ull + p.Wg - 1) / p.Wg), magH = (unsigned)((0x100000000ull + p.Hg - 1) / p.Hg);
 
   const unsigned lds0 = lds_addr(smem16);
-  auto a_voff = [&](int kt) {
+  auto a_voff = [&](int kt) {                                    // kt: index of the 16-site group
     const unsigned sidx = (unsigned)(kt * KS + a_k);
     const unsigned q = fast_div(sidx, magW);
     const int xg = (int)(sidx - q * (unsigned)p.Wg);
@@ -1145,10 +1152,20 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
   auto issue = [&](int kt, int buf) {
     const unsigned st = lds0 + (unsigned)(buf * STAGE * 2);      // byte address of the stage in LDS
     const unsigned d = st + (unsigned)(4 * wid * BM * 2);
-    dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
+    if constexpr (F16) {
+#pragma unroll
+      for (int g = 0; g < 3; g++) dma1(a_voff(3 * kt + g), src_rs[0], d + g * A_PLANE * 2);
+    } else {
+      dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], d, d + A_PLANE * 2, d + 2 * A_PLANE * 2);
+    }
     if (wid < B_NI) {
       const unsigned e = st + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
-      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], e, e + B_PLANE * 2, e + 2 * B_PLANE * 2);
+      if constexpr (F16) {
+#pragma unroll
+        for (int g = 0; g < 3; g++) dma1(b_voff(3 * kt + g), dst_rs[0], e + g * B_PLANE * 2);
+      } else {
+        dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], e, e + B_PLANE * 2, e + 2 * B_PLANE * 2);
+      }
     }
   };
 
@@ -1212,36 +1229,59 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
     // stage kt+1: addresses while the reads return, then the six loads spread between the first MFMA groups
     const int ktn = kt + 1 < kt1 ? kt + 1 : KT + 1;
     const unsigned stn = lds0 + (unsigned)((cur ^ 1) * STAGE * 2);
-    const int voa = a_voff(ktn);
-    const int vob = b_voff(ktn);
     const unsigned da = stn + (unsigned)(4 * wid * BM * 2);
     const unsigned db = stn + (unsigned)((NPL * A_PLANE + B_RPI * wid * BN) * 2);
     auto group = [&](int t) {
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
+        for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], t);
     };
-    dma1(voa, src_rs[0], da);
-    dma1(voa, src_rs[1], da + A_PLANE * 2);
-    __builtin_amdgcn_sched_barrier(0);
-    PHASE_STAMP(0);
-    group(0);
-    __builtin_amdgcn_sched_barrier(0);
-    dma1(voa, src_rs[2], da + 2 * A_PLANE * 2);
-    if (wid < B_NI) dma1(vob, dst_rs[0], db);
-    __builtin_amdgcn_sched_barrier(0);
-    group(1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wid < B_NI) {
-      dma1(vob, dst_rs[1], db + B_PLANE * 2);
-      dma1(vob, dst_rs[2], db + 2 * B_PLANE * 2);
+    if constexpr (F16) {
+      // three 16-site groups per stage, each with its own site offsets; three products per fragment set
+      const int voa0 = a_voff(3 * ktn), voa1 = a_voff(3 * ktn + 1), voa2 = a_voff(3 * ktn + 2);
+      const int vob0 = b_voff(3 * ktn), vob1 = b_voff(3 * ktn + 1), vob2 = b_voff(3 * ktn + 2);
+      dma1(voa0, src_rs[0], da);
+      dma1(voa1, src_rs[0], da + A_PLANE * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE_STAMP(0);
+      group(0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma1(voa2, src_rs[0], da + 2 * A_PLANE * 2);
+      if (wid < B_NI) dma1(vob0, dst_rs[0], db);
+      __builtin_amdgcn_sched_barrier(0);
+      group(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (wid < B_NI) {
+        dma1(vob1, dst_rs[0], db + B_PLANE * 2);
+        dma1(vob2, dst_rs[0], db + 2 * B_PLANE * 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      group(2);
+    } else {
+      const int voa = a_voff(ktn);
+      const int vob = b_voff(ktn);
+      dma1(voa, src_rs[0], da);
+      dma1(voa, src_rs[1], da + A_PLANE * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      PHASE_STAMP(0);
+      group(0);
+      __builtin_amdgcn_sched_barrier(0);
+      dma1(voa, src_rs[2], da + 2 * A_PLANE * 2);
+      if (wid < B_NI) dma1(vob, dst_rs[0], db);
+      __builtin_amdgcn_sched_barrier(0);
+      group(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (wid < B_NI) {
+        dma1(vob, dst_rs[1], db + B_PLANE * 2);
+        dma1(vob, dst_rs[2], db + 2 * B_PLANE * 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      group(2);
+      group(3);
+      group(4);
+      group(5);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    group(2);
-    group(3);
-    group(4);
-    group(5);
     // own loads landed + own LDS reads retired, then the barrier: stage kt+1 is complete and buffer `cur` is free (the
     // scheduling fences keep the MFMAs above and the next stage's loads below it)
     __builtin_amdgcn_sched_barrier(0);
@@ -1288,9 +1328,11 @@ __global__ __launch_bounds__(256, 3) void igemm_pl_wgrad_dma_kernel(const PlWgra
 //         loads of stage x+2 still in flight)            B(x): 24 MFMAs at raised priority
 // BN = 128: wave tile 64 x 64 (4 x 2 waves); BN = 256: wave tile 128 x 64 (2 x 4 waves: 48 MFMAs against 36 fragment reads and
 // 6 loads per stage instead of 24 : 24 : 4.5)
-template <int BN>
+// F16: as in igemm_pl_wgrad_dma_kernel — one fp16 plane, a stage = three consecutive 16-site groups, three products per fragment set.
+template <int BN, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgradParams p, int grp_mode) {
-  constexpr int BM = 256, WM = BN == 256 ? 128 : 64, WN = 64, NPL = 3, NT = 6, KS = 16;
+  constexpr int BM = 256, WM = BN == 256 ? 128 : 64, WN = 64, NPL = 3, NT = F16 ? 3 : 6, KS = 16;
+  constexpr int GPS = F16 ? 3 : 1;                                 // 16-site groups per stage
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_HALF = KS * 128;                                 // one 128-row half of an operand plane (tr_swz<128> image)
   constexpr int A_PLANE = 2 * A_HALF, B_PLANE = KS * BN;           // elements
@@ -1315,16 +1357,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
   const int split = v / p.nt;
   const int m0 = mtile * BM, n0 = ntile * BN;
   const int S = p.B * p.Hg * p.Wg;
-  const int KT = (S + KS - 1) / KS;
-  const int kt_per = (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;
+  const int KT = ((S + KS - 1) / KS + GPS - 1) / GPS;              // stages
+  const int kt_per = F16 ? (KT + p.nsplit - 1) / p.nsplit : (((KT + 1) / 2 + p.nsplit - 1) / p.nsplit) * 2;
   const int kt0 = split * kt_per, kt1 = min(KT, kt0 + kt_per);
   const int n = max(kt1 - kt0, 0);
 
   u32x4 src_rs[NPL], dst_rs[NPL];
 #pragma unroll
   for (int pl = 0; pl < NPL; pl++) {
-    src_rs[pl] = raw_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
-    dst_rs[pl] = raw_rsrc(p.dst + pl * p.dst_ps, (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
+    src_rs[pl] = raw_rsrc(p.src + (F16 ? 0 : pl * p.src_ps), (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)(p.gpx ? p.lds : p.Ca)) * 2);
+    dst_rs[pl] = raw_rsrc(p.dst + (F16 ? 0 : pl * p.dst_ps), (((size_t)S - 1) * (size_t)p.ldd + (size_t)((p.Cb + 7) & ~7)) * 2);
   }
   // DMA roles (by wave id, independent of the groups): wave w loads site rows 4 (w & 3) .. + 3 of M half w >> 2 of the
   // gathered operand; waves 0 .. 3 also load the dense operand's site rows 4 w .. + 3
@@ -1363,14 +1405,31 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
     const int sidx = kt * KS + b_k;
     return (b_ok && sidx < S) ? sidx * ldd2 + b_lane_off : OOB_MARK;
   };
+  // the three loads of one operand of stage kt: three planes at the same site offsets, or (F16) three 16-site groups of the one plane
+  auto load_a = [&](int kt, unsigned da) {
+    if constexpr (F16) {
+#pragma unroll
+      for (int g = 0; g < 3; g++) dma1(a_voff(3 * kt + g), src_rs[0], da + g * A_PLANE * 2);
+    } else {
+      dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], da, da + A_PLANE * 2, da + 2 * A_PLANE * 2);
+    }
+  };
+  auto load_b = [&](int kt, unsigned db) {
+    if constexpr (F16) {
+#pragma unroll
+      for (int g = 0; g < 3; g++) dma1(b_voff(3 * kt + g), dst_rs[0], db + g * B_PLANE * 2);
+    } else {
+      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], db, db + B_PLANE * 2, db + 2 * B_PLANE * 2);
+    }
+  };
   auto issue = [&](int x) {                      // stage x of this block (kt0 + x) -> buffer x % 3; past the end: zeros
     const int kt = x < n ? kt0 + x : KT + 1;
     const unsigned st = lds0 + (unsigned)((x % NSTAGE) * STAGE * 2);
     const unsigned da = st + (unsigned)((dh * A_HALF + 4 * dq * 128) * 2);
-    dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], da, da + A_PLANE * 2, da + 2 * A_PLANE * 2);
+    load_a(kt, da);
     if (BN == 256 || wid < 4) {                  // (BN = 256: the dense operand is two 128-column halves like the gathered one)
       const unsigned db = st + (unsigned)((NPL * A_PLANE + (BN == 256 ? dh * A_HALF : 0) + 4 * dq * 128) * 2);
-      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], db, db + B_PLANE * 2, db + 2 * B_PLANE * 2);
+      load_b(kt, db);
     }
   };
   auto wait_older = [&]() {                      // everything but this wave's most recent issue() has landed
@@ -1435,11 +1494,11 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
     const unsigned st = lds0 + (unsigned)((x % NSTAGE) * STAGE * 2);
     if (part == 0 || HALVES == 1) {
       const unsigned da = st + (unsigned)((dh * A_HALF + 4 * dq * 128) * 2);
-      dma3(a_voff(kt), src_rs[0], src_rs[1], src_rs[2], da, da + A_PLANE * 2, da + 2 * A_PLANE * 2);
+      load_a(kt, da);
     }
     if ((part == HALVES - 1) && (BN == 256 || wid < 4)) {
       const unsigned db = st + (unsigned)((NPL * A_PLANE + (BN == 256 ? dh * A_HALF : 0) + 4 * dq * 128) * 2);
-      dma3(b_voff(kt), dst_rs[0], dst_rs[1], dst_rs[2], db, db + B_PLANE * 2, db + 2 * B_PLANE * 2);
+      load_b(kt, db);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1451,8 +1510,8 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_wgrad_pp_kernel(const PlWgrad
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) {
-          if (half == 0) mfma_terms<NPL, false>(av[i], bv[j], acc[i][j], t);
-          else mfma_terms<NPL, false>(av[i], bv[j], acc[(TM > 2 ? 2 : 0) + i][j], t);
+          if (half == 0) mfma_terms<NPL, F16>(av[i], bv[j], acc[i][j], t);
+          else mfma_terms<NPL, F16>(av[i], bv[j], acc[(TM > 2 ? 2 : 0) + i][j], t);
         }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -2010,7 +2069,7 @@ inline int pl_wgrad_cfg(const WgradGeom& p) { return p.Cb <= 64 ? 1 : 0; }   // 
 // Option wgrad_pp: 0 off, 1 on by this rule, 3 everywhere it can run (tests), 2 / 4 the same with waves 2k / 2k+1 paired.
 inline bool pl_wgrad_pp_ok(const WgradGeom& p, int npl) {
   const int o = unflow::options().wgrad_pp;
-  if (o <= 0 || npl != 3 || p.Cb <= 64 || p.KH * p.KW * p.Ca < 256) return false;
+  if (o <= 0 || !(npl == 3 || (npl == 1 && unflow::options().f16_wgrad_dma >= 2)) || p.Cb <= 64 || p.KH * p.KW * p.Ca < 256) return false;
   if (o >= 3) return true;
   // (round 6, per-layer A/B of wgrad_pp = 3 against this rule, profiles/r06_planner_per_layer_ab.txt: the 1028 -> 256
   // conv_transpose at 1536 sites gains 17 us of 106, the layers at 384 sites lose 14-18 us, everything between is neutral)
@@ -2060,27 +2119,27 @@ int launch_pl_wgrad(const PlWgradParams& p, hipStream_t st) {
   return launch_status();
 }
 
-template <int BN, int WN>
+template <int BN, int WN, bool F16 = false>
 int launch_pl_wgrad_dma(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = 2 * 3 * (128 + BN) * 16 * 2;
   static DynLdsBook attr_book{};
-  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN>), smem, attr_book);
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_dma_kernel<BN, WN, F16>), smem, attr_book);
   PlWgradParams q = p;
   q.mt = cdiv(Mp, 128); q.nt = cdiv(p.Cb, BN);
-  igemm_pl_wgrad_dma_kernel<BN, WN><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
+  igemm_pl_wgrad_dma_kernel<BN, WN, F16><<<q.mt * q.nt * p.nsplit, 256, smem, st>>>(q);
   return launch_status();
 }
 
-template <int BN>
+template <int BN, bool F16 = false>
 int launch_pl_wgrad_pp(const PlWgradParams& p, hipStream_t st) {
   const int Mp = p.KH * p.KW * p.Ca;
   const int smem = 3 * 3 * (256 + BN) * 16 * 2;
   static DynLdsBook attr_book{};
-  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_pp_kernel<BN>), smem, attr_book);
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_wgrad_pp_kernel<BN, F16>), smem, attr_book);
   PlWgradParams q = p;
   q.mt = cdiv(Mp, 256); q.nt = cdiv(p.Cb, BN);
-  igemm_pl_wgrad_pp_kernel<BN><<<q.mt * q.nt * p.nsplit, 512, smem, st>>>(q, (unflow::options().wgrad_pp & 1) ? 0 : 1);
+  igemm_pl_wgrad_pp_kernel<BN, F16><<<q.mt * q.nt * p.nsplit, 512, smem, st>>>(q, (unflow::options().wgrad_pp & 1) ? 0 : 1);
   return launch_status();
 }
 
@@ -2100,9 +2159,11 @@ int run_pl_wgrad(PlWgradParams& p, int npl, void* ws, size_t ws_bytes, size_t* u
   *used = pl_wgrad_partial_bytes(p, p.Ca_out, ns);
   const int cfg = pl_wgrad_cfg(p);
   int code;
-  if (pl_wgrad_pp_ok(p, npl)) code = pl_wgrad_pp_bn(p) == 256 ? launch_pl_wgrad_pp<256>(p, st) : launch_pl_wgrad_pp<128>(p, st);
+  if (pl_wgrad_pp_ok(p, npl) && npl == 1) code = pl_wgrad_pp_bn(p) == 256 ? launch_pl_wgrad_pp<256, true>(p, st) : launch_pl_wgrad_pp<128, true>(p, st);
+  else if (pl_wgrad_pp_ok(p, npl)) code = pl_wgrad_pp_bn(p) == 256 ? launch_pl_wgrad_pp<256>(p, st) : launch_pl_wgrad_pp<128>(p, st);
   else if (npl == 3 && opt.wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32>(p, st) : launch_pl_wgrad_dma<128, 64>(p, st);
   else if (npl == 3) code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 3, false>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 3, false>(p, st);
+  else if (opt.wgrad_dma && opt.f16_wgrad_dma) code = cfg == 1 ? launch_pl_wgrad_dma<64, 32, true>(p, st) : launch_pl_wgrad_dma<128, 64, true>(p, st);
   else code = cfg == 1 ? launch_pl_wgrad<128, 64, 64, 32, 1, true>(p, st) : launch_pl_wgrad<128, 128, 64, 64, 1, true>(p, st);
   if (code != UNFLOW_OK) return code;
   if (ns > 1) return reduce_partials(p.partial, p.partial + (size_t)ns * wsize, p.out, wsize, ns, st);

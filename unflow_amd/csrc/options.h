@@ -15,6 +15,7 @@
   X(gather_pp, 1)         /* ping-pong gather kernel (two 128 x 128 tiles per 8-wave workgroup): 1 where it pays, 2 wherever eligible */ \
   X(gather_pp_fill, 60)   /* ... gather_pp = 1: taken when one round of 8-wave workgroups fills at least this % of the CUs (equal tap counts) */ \
   X(f16_k64, 1)           /* fp16 halo launches with K tiles of 64 channels (two chunk planes): 0 never, 1 short items (conv_transpose forward, 3x3 stride-2 forward), 2 always */ \
+  X(f16_wgrad_dma, 1)     /* fp16 filter gradients on the LDS-DMA kernels (stages of three 16-site groups): 1 the 4-wave kernel, 2 also the 8-wave ping-pong one by wgrad_pp's rule (measured slower: 12-24 MFMAs per slot do not cover a barrier), 0 register-staged */ \
   X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
   X(conv1_direct, 1)      /* FlowNetC's first layer on its own kernel (conv_first.hip: rows staged once per tile, filter resident) */ \
   X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \
