@@ -21,3 +21,7 @@ python tools/pmc_traffic.py gpurun_out/rec_pmc/pass1 gpurun_out/rec_pmc/pass2 > 
 ( UNFLOW_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-alt --no-parity --no-roofline > gpurun_out/rec_2ranks.out 2> gpurun_out/rec_2ranks.err )
 grep '^{"metric"' gpurun_out/rec_2ranks.out > gpurun_out/rec_bench_2ranks_gloo_one_gpu.json; tail -c 700 gpurun_out/rec_bench_2ranks_gloo_one_gpu.json
 rm -rf gpurun_out/rec_prof gpurun_out/rec_pmc/pass*/ 2>/dev/null; ls gpurun_out | head -30
+# round 6: the single-stream rocprof record (roofline_check reproduces the class time from the tracked CSV), the step timeline, the census VALU roofline
+bash tools/serial_profile.sh rec > /dev/null 2>&1; tail -3 gpurun_out/rec_serial_roofline_check.txt
+bash tools/step_trace.sh rec > /dev/null 2>&1; python tools/step_timeline.py gpurun_out/rec_step_trace.csv > gpurun_out/rec_step_timeline.txt 2>&1; head -2 gpurun_out/rec_step_timeline.txt
+bash tools/census_valu.sh rec_census > /dev/null 2>&1
