@@ -2091,7 +2091,9 @@ inline int plan_pl_wgrad(const WgradGeom& p, int npl) {
   const long blocks = (long)cdiv(Mp, 128) * cdiv(p.Cb, bn);
   const long S = (long)p.B * p.Hg * p.Wg;
   const int KT = (int)((S + BK - 1) / BK);
-  const int min_kt = max(1, unflow::options().wgrad_min_kt);
+  // fp16 (one product per fragment pair: a stage is a third of the bf16 kernel's matrix-core time): four times the sites per split
+  // (per-layer A/B at B = 8, profiles/r06_f16_per_layer_ab.txt: the two deep conv_transpose filter gradients -30 us each)
+  const int min_kt = max(1, unflow::options().wgrad_min_kt) * (npl == 1 ? 4 : 1);
   const int max_by_k = min(256, KT / min_kt > 0 ? KT / min_kt : 1);
   const int per_cu = min((160 * 1024) / (npl * (128 + bn) * BK * 2), cfg == 1 ? 4 : 3);
   // (Fewer blocks to shrink the partial sums — blocks x 64 KB whatever the layer, 50 MB at 768 blocks — lose more than the
