@@ -122,6 +122,25 @@ def test_conv_planes_vs_fp64(case, P, dev, lib_option):
     _conv_case_vs_fp64(case, P, dev)
 
 
+@pytest.mark.parametrize("k64", [0, 2])
+@pytest.mark.parametrize("case", [(2, 48, 64, 128, 128, 3, 1), (1, 12, 16, 476, 256, 3, 1), (1, 16, 32, 388, 64, 3, 1), (2, 64, 64, 64, 128, 5, 2),
+                                  (1, 38, 70, 40, 96, 3, 2), (1, 10, 40, 128, 96, 3, 1), (2, 8, 32, 256, 256, 3, 1)])
+def test_conv_planes_f16_k64_vs_fp64(case, k64, dev, lib_option):
+    """fp16 halo launches with K tiles of 64 channels (f16_k64: two consecutive 32-channel chunks staged as two planes, round 6) forced
+    everywhere / off: forward and data gradient of halo-kernel cases incl. a half-filled last chunk (476 -> 480 = 7.5 x 64, 388, 40
+    channels), split over chunks, parity and accumulating classes — the same fp64 bound as the K32 form."""
+    lib_option("f16_k64", k64)
+    lib_option("halo_s2", 2)
+    _conv_case_vs_fp64(case, 1, dev)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 32, 772, 128), (1, 9, 40, 128, 72), (2, 24, 64, 388, 64)])
+def test_deconv_planes_f16_k64_vs_fp64(case, dev, lib_option):
+    """conv_transpose forward (the launches f16_k64's rule takes: four classes of 2 x 2 taps) and its data gradient in fp16 with K64 tiles."""
+    lib_option("f16_k64", 2)
+    _deconv_case_vs_fp64(case, 1, dev)
+
+
 # the persistent stream-K halo kernel (csrc/conv_streamk.hip) forced wherever it is eligible (source stride 1, N > 64, bf16 x 3):
 # forward and data gradient of the cases below run through it — single and multiple tap classes (even and uneven tap counts),
 # ragged tiles, an N tail, launches with far fewer chunk units than workgroups (empty ranges, items cut into up to 8 segments)
@@ -620,6 +639,55 @@ def test_wgrad_planes_vs_fp64(case, dev, lib_option):
         err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
         assert err < 2e-5, (dma, err)
         results[dma] = outs[0]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", [(8, 48, 64, 476, 256, 3, 1, False), (8, 96, 128, 128, 256, 5, 2, False), (2, 40, 56, 72, 40, 3, 1, False),
+                                  (8, 48, 64, 388, 64, 4, 2, True), (4, 24, 32, 1028, 256, 4, 2, True)])
+def test_wgrad_planes_f16_forms_vs_fp64(case, mode, dev, lib_option):
+    """fp16 filter gradients in their three forms (f16_wgrad_dma 0: register-staged; 1: the LDS-DMA kernel with stages of three
+    16-site groups — the default; 2: also its 8-wave ping-pong form) against fp64: ragged site counts (a last stage with one or two
+    empty groups), image-border taps, N tails; repeated launches bit-identical."""
+    from unflow_amd.core import layers as L
+    import torch.nn.functional as F
+    lib_option("f16_wgrad_dma", mode)
+    if mode == 2:
+        lib_option("wgrad_pp", 3)
+    B, H, W, Cin, Cout, k, stride, deconv = case
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    if deconv:
+        x = torch.randn(B, H // 2, W // 2, Cin, generator=g)
+        dz = torch.randn(B, H, W, Cout, generator=g)
+        xh, dzh = x.half().double(), dz.half().double()              # the operands the kernel sees: fp16-rounded
+        wz = torch.zeros(Cin, Cout, 4, 4, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose2d(xh.permute(0, 3, 1, 2), wz, stride=2, padding=1)
+        (y * dzh.permute(0, 3, 1, 2)).sum().backward()
+        ref = wz.grad.permute(2, 3, 1, 0).contiguous()
+        dw_shape = (4, 4, Cout, Cin)
+    else:
+        x = torch.randn(B, H, W, Cin, generator=g)
+        Ho, Wo = L.out_hw(H, W, stride)
+        dz = torch.randn(B, Ho, Wo, Cout, generator=g)
+        xh, dzh = x.half().double(), dz.half().double()
+        pt_, pl_ = max((Ho - 1) * stride + k - H, 0), max((Wo - 1) * stride + k - W, 0)
+        xp = F.pad(xh.permute(0, 3, 1, 2), (pl_ // 2, pl_ - pl_ // 2, pt_ // 2, pt_ - pt_ // 2))
+        wz = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xp, wz, stride=stride)
+        (y * dzh.permute(0, 3, 1, 2)).sum().backward()
+        ref = wz.grad.permute(2, 3, 1, 0).contiguous()
+        dw_shape = (k, k, Cin, Cout)
+    X, DZ = make_pt(x, dev, 1), make_pt(dz, dev, 1)
+    outs = []
+    for _ in range(3):
+        dw = torch.full(dw_shape, float('nan'), device=dev)
+        if deconv:
+            L.deconv_bwd_filter(X, DZ, dw)
+        else:
+            L.conv_bwd_filter(X, DZ, dw, stride)
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = (outs[0].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, (mode, err)                                   # fp16 operands are exact inputs here: only the fp32 accumulation differs
 
 
 @pytest.mark.parametrize("case", [(2, 64, 12, 16, 20, 2), (1, 256, 24, 32, 20, 2), (2, 128, 9, 21, 4, 1),
