@@ -74,6 +74,44 @@ def test_correlation_identities_full(dev):
     assert (c2 - (2.0 * cab + ops.correlation(b, b, **attrs))).abs().max().item() < 2e-4
 
 
+def test_ring_correlation_bit_identical_under_a_bandwidth_hog(dev):
+    """The north star's +-4 / 81-channel cost volume at full size (16 x 96 x 128 x 256: corr_fwd_ring_kernel, whose f0 fragments are
+    fetched by inline-asm loads the compiler keeps no book for) replayed while a second stream saturates HBM with a streaming
+    kernel: every replay bit-identical to the quiet result.  Round 5's form copied the fragment registers before the covering wait
+    (ADVICE r5): correct only as long as ~1 us of MFMAs hid the load latency — memory contention is what would have exposed it.
+    The static guard is tools/isa_load_hazard.py (CPU suite); this is the dynamic one."""
+    from unflow_amd import _lib
+    from unflow_amd._lib import check, ptr, planes_of, stream
+    from unflow_amd.core import layers as L
+    g = torch.Generator().manual_seed(11)
+    N, h, w, C = 16, 96, 128, 256
+    F = L.PT.alloc((N, h, w, C), dev, 3)
+    F.t.copy_(torch.randn(N, h, w, C, generator=g).to(dev))
+    L.planes_from_f32(F.t, F.pl)
+    lib = _lib.lib()
+
+    def corr(out):
+        check(lib.unflow_correlation_nhwc_fwd_pl(ptr(F.t), ptr(F.t), C, planes_of(F.pl), planes_of(F.pl), N // 2, ptr(out), 84, N, C, h, w, 1, 4, 4,
+                                                 1, 1, stream()), "correlation")
+    quiet = torch.zeros(N, h, w, 84, device=dev)
+    corr(quiet)
+    torch.cuda.synchronize()
+    assert quiet.abs().max().item() > 0
+    # the hog: 1.2 GB of streaming copies per pass on a second stream, kept running across the replays
+    n = 150_000_000
+    src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            dst.copy_(src)
+    for _ in range(20):
+        out = torch.zeros(N, h, w, 84, device=dev)
+        corr(out)
+        assert torch.equal(out, quiet)
+    torch.cuda.synchronize()
+
+
 def _images(B, H, W, seed):
     g = torch.Generator().manual_seed(seed)
     im1 = torch.rand(B, H, W, 3, generator=g) * 255
