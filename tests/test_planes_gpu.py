@@ -141,6 +141,46 @@ def test_deconv_planes_f16_k64_vs_fp64(case, dev, lib_option):
     _deconv_case_vs_fp64(case, 1, dev)
 
 
+@pytest.mark.parametrize("case", [(2, 48, 64, 128, 256, 3, 1), (1, 12, 16, 476, 256, 3, 1), (2, 8, 32, 256, 256, 3, 1), (4, 48, 64, 256, 512, 3, 2),
+                                  (1, 10, 40, 388, 160, 3, 1), (1, 38, 70, 136, 264, 3, 2)])
+@pytest.mark.parametrize("db", [0, 1])
+def test_conv_planes_f16_tall_tile_vs_fp64(case, db, dev, lib_option):
+    """fp16 halo launches on the 256-site x 128 workgroup tile (csrc/conv_halo_tall.hip, option f16_tall forced wherever it can run): forward
+    and data gradient incl. N tails (160, 264, 388, 476 columns), split K, ragged site grids (heights 10, 12, 38: partial 8-row tiles),
+    parity and accumulating classes — the same fp64 bound as the 128 x 128 tile."""
+    lib_option("f16_tall", 2)
+    lib_option("f16_db", db)
+    lib_option("f16_k64", 0)
+    lib_option("halo_s2", 2)
+    _conv_case_vs_fp64(case, 1, dev)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 32, 772, 256), (1, 9, 40, 264, 136)])
+def test_deconv_planes_f16_tall_tile_vs_fp64(case, dev, lib_option):
+    lib_option("f16_tall", 2)
+    lib_option("f16_k64", 0)
+    _deconv_case_vs_fp64(case, 1, dev)
+
+
+@pytest.mark.parametrize("case", [(2, 48, 64, 128, 128, 3, 1), (1, 12, 16, 476, 256, 3, 1), (1, 16, 32, 388, 64, 3, 1), (2, 64, 64, 64, 128, 5, 2),
+                                  (1, 38, 70, 40, 96, 3, 2), (1, 10, 40, 128, 96, 3, 1), (2, 8, 32, 256, 256, 1, 1)])
+def test_conv_planes_f16_double_buffered_vs_fp64(case, dev, lib_option):
+    """fp16 halo launches with the weight tile double-buffered in LDS (option f16_db: the next tile's loads issued at the end of the
+    previous iteration, one barrier per K tile, two where a chunk's halo is replaced): 128- and 64-wide tiles, one tap per chunk (1 x 1:
+    a new halo every tile), parity and accumulating classes, split K."""
+    lib_option("f16_db", 1)
+    lib_option("f16_k64", 0)
+    lib_option("halo_s2", 2)
+    _conv_case_vs_fp64(case, 1, dev)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 32, 772, 128), (2, 24, 64, 388, 64)])
+def test_deconv_planes_f16_double_buffered_vs_fp64(case, dev, lib_option):
+    lib_option("f16_db", 1)
+    lib_option("f16_k64", 0)
+    _deconv_case_vs_fp64(case, 1, dev)
+
+
 # the persistent stream-K halo kernel (csrc/conv_streamk.hip) forced wherever it is eligible (source stride 1, N > 64, bf16 x 3):
 # forward and data gradient of the cases below run through it — single and multiple tap classes (even and uneven tap counts),
 # ragged tiles, an N tail, launches with far fewer chunk units than workgroups (empty ranges, items cut into up to 8 segments)

@@ -86,7 +86,7 @@ def build_all():
     procs = []
     for src in B.sources():
         s = os.path.join(tmp, os.path.basename(src)[:-4] + '.s')
-        procs.append((s, subprocess.Popen([B.HIPCC] + [f for f in B.FLAGS if f != '-fPIC'] + ['--cuda-device-only', '-S', src, '-o', s])))
+        procs.append((s, subprocess.Popen([B.HIPCC] + [f for f in B.flags_for(src) if f != '-fPIC'] + ['--cuda-device-only', '-S', src, '-o', s])))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc -S failed for %s" % s)

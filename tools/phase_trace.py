@@ -25,21 +25,24 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dev = torch.device("cuda:0")
     B, H, W, Cin, Cout, k = 8, 48, 64, 476, 256, 3          # conv3_1 forward of the benchmarked step
+    P = 1 if os.environ.get("PHASE_TRACE_F16") else 3      # PHASE_TRACE_F16=1: the fp16 mode (8 MFMAs per wave and tile), B = 16 images
+    if P == 1:
+        B = 16
     g = torch.Generator().manual_seed(1)
-    X = L.PT.alloc((B, H, W, Cin), dev, 3)
+    X = L.PT.alloc((B, H, W, Cin), dev, P)
     X.t.copy_(torch.randn(B, H, W, Cin, generator=g))
     L.planes_from_f32(X.t, X.pl)
     w = (torch.randn(k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5).to(dev)
     r8 = lambda c: (c + 7) // 8 * 8                        # noqa: E731
-    d = torch.zeros(3, k * k, Cin, r8(Cout), dtype=torch.int16, device=dev)
-    t = torch.zeros(3, k * k, Cout, r8(Cin), dtype=torch.int16, device=dev)
+    d = torch.zeros(P, k * k, Cin, r8(Cout), dtype=torch.int16, device=dev)
+    t = torch.zeros(P, k * k, Cout, r8(Cin), dtype=torch.int16, device=dev)
     _lib.check(_lib.lib().unflow_weight_planes_batched(1, (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_int * 1)(k * k),
                                                       (ctypes.c_int * 1)(Cin), (ctypes.c_int * 1)(Cout),
-                                                      (ctypes.c_void_p * 1)(d.data_ptr()), (ctypes.c_void_p * 1)(t.data_ptr()), 3,
+                                                      (ctypes.c_void_p * 1)(d.data_ptr()), (ctypes.c_void_p * 1)(t.data_ptr()), P,
                                                       _lib.stream()), "wp")
-    Y = L.PT.alloc((B, H, W, Cout), dev, 3)
+    Y = L.PT.alloc((B, H, W, Cout), dev, P)
     bias = torch.zeros(Cout, device=dev)
-    DZ = L.PT.alloc((B, H, W, Cout), dev, 3)
+    DZ = L.PT.alloc((B, H, W, Cout), dev, P)
     DZ.t.copy_(torch.randn(B, H, W, Cout, generator=g))
     L.planes_from_f32(DZ.t, DZ.pl)
     dw = torch.zeros(k, k, Cin, Cout, device=dev)
@@ -81,6 +84,10 @@ def main():
         Yd = L.PT.alloc((Bd, Hd, Wd, Cd), dev, 3)
         bd = torch.zeros(Cd, device=dev)
         trace("gather kernel, conv6_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(Xd, wd, td, bd, Yd, 1, True),
+              ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
+        return
+    if P == 1:
+        trace("halo kernel, conv3_1 forward, fp16 (8 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),
               ["mfma phase", "barrier 1", "wait loads", "lds stores", "barrier 2", "loop tail"])
         return
     trace("halo kernel, conv3_1 forward (48 MFMAs per wave and tile):", lambda: L.conv_fwd(X, w, t, bias, Y, 1, True),

@@ -27,6 +27,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # step is faster with them, and a compiler bump is guarded by the replay stress test, not by this comment.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-fno-vectorize", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# Per-file additions.  conv_halo_tall.hip: the epilogue's `#pragma unroll` sub-tile loops must really unroll at TM = 4, or the
+# 128-register accumulator tile is indexed dynamically and lives in scratch (csrc/conv_halo_tall.hip).
+EXTRA_FLAGS = {"conv_halo_tall.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
+
+
+def flags_for(src):
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
 
 
 def sources():
@@ -45,7 +52,7 @@ def build(force=False, verbose=False):
         obj = src[:-4] + ".o"
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + flags_for(src) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

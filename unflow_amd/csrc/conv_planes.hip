@@ -22,34 +22,10 @@
 //        gfx950 transposing read (semantics probed in tools/microbench/probe_semantics.hip): no per-lane dword gathers.
 #include "igemm_shared.h"
 #include "planes_shared.h"
+#include "halo_kernel.h"
 
 namespace {
 using namespace igemm;
-
-// Phase trace (diagnostic builds only: -DUNFLOW_PHASE_TRACE, tools/phase_trace.py): the waves of workgroup 0 stamp
-// s_memtime at the phase boundaries of their first 64 K tiles; never compiled into the shipped library.
-#ifdef UNFLOW_PHASE_TRACE
-__device__ unsigned long long g_phase_trace[8 * 8];          // [wave][phase 0..5 cycle sums, 6 = tiles]
-#define PHASE_DECL unsigned long long ph_prev = 0, ph_acc[7] = {0, 0, 0, 0, 0, 0, 0}
-// cycles since the previous stamp go to phase `slot` (slot 6: the start of a tile — counts it and takes what is left of the
-// loop tail into phase 5); sums stay in registers (a store per stamp would sit in every s_waitcnt vmcnt that follows)
-#define PHASE_STAMP(slot)                                                  \
-  do {                                                                     \
-    const unsigned long long ph_now = __builtin_readcyclecounter();        \
-    if ((slot) == 6) { if (ph_prev) ph_acc[5] += ph_now - ph_prev; ph_acc[6]++; } \
-    else ph_acc[slot] += ph_now - ph_prev;                                 \
-    ph_prev = ph_now;                                                      \
-  } while (0)
-#define PHASE_FLUSH                                                                                            \
-  do {                                                                                                         \
-    if (blockIdx.x == UNFLOW_PHASE_TRACE && (threadIdx.x & 63) == 0)                                           \
-      for (int ph_i = 0; ph_i < 7; ph_i++) g_phase_trace[(threadIdx.x >> 6) * 8 + ph_i] = ph_acc[ph_i];        \
-  } while (0)
-#else
-#define PHASE_DECL do { } while (0)
-#define PHASE_STAMP(slot) do { } while (0)
-#define PHASE_FLUSH do { } while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------------ gather kernel
 // 256 threads = 4 waves.  Loads: thread (kq = tid & 3, r = tid >> 2) fetches granule kq (8 consecutive k) of rows r, r + 64
@@ -500,290 +476,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pl_gather_pp_kernel(const PlGath
   pl_gather_epilogue<WM, WN>(p, acc, pix, smem16 + inst * 2 * A_TILE, wm, wn, wid, lane, n0, split);
 }
 
-// ------------------------------------------------------------------------------------------------ halo gather kernel
-// Source stride 1 (3x3 / 1x1 stride-1 convs, every conv data gradient incl. the 4 parity classes of stride 2, conv_transpose
-// forward): the taps of a site are its neighbours, so a spatially compact tile re-reads almost the same pixels for every
-// tap.  igemm_pl_gather_kernel fetches them once PER TAP (its 128-site tiles are image rows; the re-reads miss L1 and,
-// with ~100 resident tiles per XCD, L2 too: conv2's data gradient moved 1.9 GB for 0.6 GB of operands and ran at the
-// Infinity-Cache rate, 64 TFLOP/s).  Here a block owns a 4 x 32-site tile and walks K chunk-major: for every 32-channel
-// chunk the (4 + nty - 1) x (32 + ntx - 1) halo of source pixels is loaded ONCE into LDS ([pixel][32 ch], 80-byte pitch:
-// conflict-free b128 reads of consecutive pixels) and serves all taps through a per-tap address offset; only the weight
-// tile streams per tap.  A-operand loads drop by taps * 128 / halo (6.4x for 3x3), all loads by ~1.7x.
-// Tile = 4 rows x 32 sites: an MFMA sub-tile (32 lanes) is 32 CONSECUTIVE halo pixels, which with the 80-byte pitch makes
-// every 16-lane group of a ds_read_b128 hit 16 distinct 16-byte bank slots (an 8 x 16 tile puts two image rows into one
-// sub-tile: SQ_LDS_BANK_CONFLICT was 85 % of the LDS-active cycles).
-
-template <int BN, int WM, int WN, int NPL, bool F16>
-__global__ __launch_bounds__(256, 2) void igemm_pl_halo_kernel(const PlGatherParams p, int HPmax) {
-  constexpr int BM = 128;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * WAVES_N == 4, "4 waves");
-  constexpr int B_PLANE = BN * LDH;
-  constexpr int NB = BN / 64;
-  constexpr int NH = 4;                          // halo granules per thread and plane (covers 256 pixels)
-  constexpr int NT = mfma_nt(NPL, F16);
-  constexpr int KCH = F16 ? NPL : 1;            // 32-channel chunks per K tile (fp16: the planes ARE consecutive chunks)
-
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  const int H_PLANE = HPmax * HPITCH;
-  unsigned short* Hh = smem16;
-  unsigned short* Bh = Hh + NPL * H_PLANE;
-  int* pix = reinterpret_cast<int*>(reinterpret_cast<char*>(smem16) + pl_halo_main_bytes(BN, WN, NPL, HPmax));
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  int t, ntile, cls_id, split;
-  work_decode(xcd_remap(blockIdx.x, gridDim.x, p.xcd), p.mt, p.nt, p.acc ? 1 : p.ncls, p.nsplit, p.order, p.mgroup, t, ntile, cls_id,
-              split);
-  if (t < 0) return;
-  // Tap classes of this block.  Output-parity classes (data gradient of a stride-2 conv, conv_transpose forward) write
-  // different pixels: one class per block (cls_id).  ACCUMULATING classes (p.acc: forward of a stride-2 conv, data gradient
-  // of a conv_transpose — source stride 2) all add into the same output tile: on the four parity sub-lattices of the source
-  // (pixel pitch p.sp = 2) a stride-2 k x k conv is the sum of four stride-1 convs with ceil / floor (k/2)^2 taps, each
-  // served by its own halo; the block walks class after class (class-major, then chunk, then tap).
-  const int c_first = p.acc ? 0 : cls_id, c_last = p.acc ? p.ncls : cls_id + 1;
-  const TapClass tc = p.cls[c_first];           // (geometry of the pixel table; the first class to load / multiply)
-  const int n0 = ntile * BN;
-  const int Cg = p.Cs >> 3;
-  const int nchunk = (((Cg + 3) >> 2) + KCH - 1) / KCH;        // chunks of 32 KCH channels
-  const int ch_per = (nchunk + p.nsplit - 1) / p.nsplit;
-  const int ch0 = split * ch_per, ch1 = min(nchunk, (split + 1) * ch_per);
-  int sumtaps = 0, mtx = 0;
-  for (int c = c_first; c < c_last; c++) {
-    sumtaps += p.cls[c].nty * p.cls[c].ntx;
-    mtx = max(mtx, p.cls[c].ntx);
-  }
-  const int T = max(ch1 - ch0, 0) * sumtaps;    // K tiles of this block
-
-  // tile -> (image, tile row, tile column)
-  const int txi = t % p.tiles_x; t /= p.tiles_x;
-  const int tyi = t % p.tiles_y;
-  const int b = t / p.tiles_y;
-  const int y0 = tyi * TH, x0 = txi * TW;
-  // halo image in LDS: HC pixels per row for every class of the block (the widest class's); halo pixel (hy, hx) = source
-  // pixel ((y0 + hy) * sp + dmin_y, (x0 + hx) * sp + dmin_x) of the class being loaded
-  const int HC = TW + mtx - 1;
-
-  __amdgpu_buffer_rsrc_t src_rs[NPL], w_rs[NPL];
-#pragma unroll
-  for (int pl = 0; pl < NPL; pl++) {
-    // (fp16 chunk planes: plane pl starts 64 pl bytes into the tensor — the range shrinks by as much)
-    src_rs[pl] = make_rsrc(p.src + pl * p.src_ps, (((size_t)p.B * p.Hs * p.Ws - 1) * (size_t)p.lds + (size_t)p.Cs) * 2 - (KCH > 1 ? pl * 64 : 0));
-    w_rs[pl] = make_rsrc(p.w + pl * p.w_ps, (size_t)p.wtaps * p.N * p.Cs * 2 - (KCH > 1 ? pl * 64 : 0));
-  }
-  const int kq = tid & 3;
-  const int lds2 = p.lds * 2;
-  // this thread's halo granules: pixel hp = (tid >> 2) + 64 j, granule kq of the chunk — for the class being LOADED
-  int h_off[NH];
-  TapClass ltc = tc;                            // load-side class
-  auto set_load_class = [&]() {
-    const int dmy = p.dstep > 0 ? ltc.dy0 : ltc.dy0 - (ltc.nty - 1);     // source offset of halo pixel (0, 0)
-    const int dmx = p.dstep > 0 ? ltc.dx0 : ltc.dx0 - (ltc.ntx - 1);
-    const int HRc = TH + ltc.nty - 1, HCc = TW + ltc.ntx - 1;
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-      const int hp = (tid >> 2) + 64 * j;
-      const int hy = hp / HC, hx = hp - hy * HC;
-      const int y = (y0 + hy) * p.sp + dmy, x = (x0 + hx) * p.sp + dmx;
-      const bool ok = hy < HRc && hx < HCc && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
-      h_off[j] = ok ? ((b * p.Hs + y) * p.Ws + x) * lds2 + kq * 16 : OOB_MARK;
-    }
-  };
-  set_load_class();
-  if (tid < BM) {
-    const int yg = y0 + (tid >> TWL), xg = x0 + (tid & (TW - 1));
-    pix[tid] = (yg < p.Hg && xg < p.Wg) ? (b * p.Hd + yg * p.so + tc.py) * p.Wd + xg * p.so + tc.px : -1;
-  }
-  int b_row[NB];
-#pragma unroll
-  for (int i = 0; i < NB; i++) {
-    const int n = n0 + (tid >> 2) + 64 * i;
-    b_row[i] = n < p.N ? n * p.Cs * 2 + kq * 16 : OOB_MARK;
-  }
-
-  u32x4 rh[NH][NPL], rb[NB][NPL];
-  // loads of the NEXT K tile (chunk ld_chunk, tap (ld_ty, ld_tx); advanced once per tile, no divisions in the loop):
-  // weights always, the halo when the tile opens a chunk
-  int ld_c = c_first, ld_chunk = ch0, ld_ty = 0, ld_tx = 0;
-  bool ld_live = T > 0;
-  auto load_b = [&](int i) {
-    const int widx = (ltc.ky0 + ld_ty * p.kstep) * p.KW + ltc.kx0 + ld_tx * p.kstep;
-    const int voff = b_row[i] + widx * p.N * p.Cs * 2 + ld_chunk * (64 * KCH);
-#pragma unroll
-    for (int pl = 0; pl < NPL; pl++) {
-      const bool ok = ld_live && (ld_chunk * KCH + (KCH > 1 ? pl : 0)) * 4 + kq < Cg;
-      rb[i][pl] = buf_ld16(w_rs[pl], ok ? voff : OOB_MARK);
-    }
-  };
-  auto load_h = [&](int j) {
-    const int voff = h_off[j] + ld_chunk * (64 * KCH);
-#pragma unroll
-    for (int pl = 0; pl < NPL; pl++) {
-      const bool ok = ld_live && (ld_chunk * KCH + (KCH > 1 ? pl : 0)) * 4 + kq < Cg;     // (h_off may be OOB_MARK itself: stays out of range)
-      rh[j][pl] = buf_ld16(src_rs[pl], ok ? voff : OOB_MARK);
-    }
-  };
-  auto ld_advance = [&](int kk_next) {     // the loads now target tile kk_next + 1... called after tile kk_next's loads
-    ld_tx++;
-    if (ld_tx == ltc.ntx) { ld_tx = 0; ld_ty++; }
-    if (ld_ty == ltc.nty) { ld_ty = 0; ld_chunk++; }
-    if (ld_chunk == ch1 && ld_c + 1 < c_last) {          // next class (accumulating classes only)
-      ld_chunk = ch0;
-      ld_c++;
-      ltc = p.cls[ld_c];
-      set_load_class();
-    }
-    ld_live = kk_next + 1 < T;
-  };
-  auto swz = [](int row, int g) { return row * LDH + 8 * (g ^ ((row >> 2) & 3)); };
-  auto store_b = [&]() {
-#pragma unroll
-    for (int i = 0; i < NB; i++)
-#pragma unroll
-      for (int pl = 0; pl < NPL; pl++)
-        *reinterpret_cast<u32x4*>(Bh + pl * B_PLANE + swz((tid >> 2) + 64 * i, kq)) = rb[i][pl];
-  };
-  auto store_h = [&]() {
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-      const int hp = (tid >> 2) + 64 * j;
-      if (hp < HPmax) {
-#pragma unroll
-        for (int pl = 0; pl < NPL; pl++)
-          *reinterpret_cast<u32x4*>(Hh + pl * H_PLANE + hp * HPITCH + kq * 8) = rh[j][pl];
-      }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  // A fragment of sub-tile i: site s = wm*WM + i*32 + l31 -> halo pixel (s / TW) * HC + s % TW (+ the tap's offset)
-  int a_rd[TM];
-#pragma unroll
-  for (int i = 0; i < TM; i++) {
-    const int sidx = wm * WM + i * 32 + l31;
-    a_rd[i] = ((sidx >> TWL) * HC + (sidx & (TW - 1))) * HPITCH + lh * 8;
-  }
-  const unsigned short* bh_rd = Bh + (wn * WN + l31) * LDH;
-  const int gsw = lh ^ ((l31 >> 2) & 3);
-
-#pragma unroll
-  for (int j = 0; j < NH; j++) load_h(j);
-#pragma unroll
-  for (int i = 0; i < NB; i++) load_b(i);
-  ld_advance(0);
-  store_h();
-  store_b();
-  __syncthreads();
-  constexpr int NGROUP = 2 * TM * NT;
-  constexpr int NPIECE = NB + NH;
-  constexpr int PPG = (NPIECE + NGROUP - 1) / NGROUP;
-  int ty = 0, tx = 0;                            // tap of the tile being multiplied, and the halo position of its class's tap (0, 0)
-  int c_hy0 = p.dstep > 0 ? 0 : tc.nty - 1, c_hx0 = p.dstep > 0 ? 0 : tc.ntx - 1;
-  PHASE_DECL;
-  for (int kk = 0; kk < T; kk++) {
-    PHASE_STAMP(6);
-    const int hyi = c_hy0 + ty * p.dstep, hxi = c_hx0 + tx * p.dstep;
-    const int tapoff = (hyi * HC + hxi) * HPITCH;
-    const bool new_chunk = ld_ty == 0 && ld_tx == 0;   // the next tile opens a chunk: its halo is loaded during this tile
-    auto piece = [&](int step) {
-      if (step < NB) load_b(step);
-      else if (step < NB + NH && new_chunk) load_h(step - NB);
-    };
-    if constexpr (BN == 128) {
-      // software-pipelined over the 2 x TM (slab, sub-tile) steps: the fragments of step s+1 are read from LDS while the
-      // MFMAs of step s run (two waves per SIMD are not enough to hide a ds_read round trip in front of every step)
-      s16x8 bv[2][TN][NPL], av[2][NPL];
-      auto read_b = [&](int slab) {
-  #pragma unroll
-        for (int pl = 0; pl < NPL; pl++)
-  #pragma unroll
-          for (int j = 0; j < TN; j++)
-            bv[slab & 1][j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-      };
-      auto read_a = [&](int step) {
-        const int slab = step / TM, i = step % TM;
-  #pragma unroll
-        for (int pl = 0; pl < NPL; pl++)
-          av[step & 1][pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
-      };
-      read_b(0);
-      read_a(0);
-  #pragma unroll
-      for (int step = 0; step < 2 * TM; step++) {
-        const int slab = step / TM, i = step % TM;
-        if (step + 1 < 2 * TM) {
-          if ((step + 1) / TM != slab) read_b(slab + 1);
-          read_a(step + 1);
-        }
-  #pragma unroll
-        for (int t2 = 0; t2 < NT; t2++) {
-  #pragma unroll
-          for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av[step & 1], bv[slab & 1][j], acc[i][j], t2);
-  #pragma unroll
-          for (int q = 0; q < PPG; q++) piece((step * NT + t2) * PPG + q);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-      // N = 64 tile: 6 MFMAs per step and three waves per SIMD — occupancy hides the LDS latency, the second fragment set
-      // would cost a wave
-#pragma unroll
-      for (int slab = 0; slab < 2; slab++) {
-        s16x8 bv[TN][NPL];
-#pragma unroll
-        for (int pl = 0; pl < NPL; pl++)
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-            bv[j][pl] = *reinterpret_cast<const s16x8*>(bh_rd + pl * B_PLANE + j * 32 * LDH + 8 * (gsw ^ (2 * slab)));
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-          s16x8 av[NPL];
-#pragma unroll
-          for (int pl = 0; pl < NPL; pl++)
-            av[pl] = *reinterpret_cast<const s16x8*>(Hh + pl * H_PLANE + a_rd[i] + tapoff + 16 * slab);
-#pragma unroll
-          for (int t2 = 0; t2 < NT; t2++) {
-#pragma unroll
-            for (int j = 0; j < TN; j++) mfma_terms<NPL, F16>(av, bv[j], acc[i][j], t2);
-#pragma unroll
-            for (int q = 0; q < PPG; q++) piece(((slab * TM + i) * NT + t2) * PPG + q);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    PHASE_STAMP(0);    // MFMA phase (fragment reads, 48 MFMAs, the next tile's loads issued)
-    __syncthreads();   // every wave is done with this tile's weights (and, at a chunk end, with the halo)
-    PHASE_STAMP(1);    // barrier 1
-#ifdef UNFLOW_PHASE_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PHASE_STAMP(2);    // the next tile's loads landed
-#endif
-    store_b();
-    if (new_chunk) store_h();
-#ifdef UNFLOW_PHASE_TRACE
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-    PHASE_STAMP(3);    // LDS stores
-    __syncthreads();
-    PHASE_STAMP(4);    // barrier 2
-    ty = ld_ty; tx = ld_tx;          // the tile just stored is the next one multiplied: its tap, its class's halo origin
-    c_hy0 = p.dstep > 0 ? 0 : ltc.nty - 1;
-    c_hx0 = p.dstep > 0 ? 0 : ltc.ntx - 1;
-    ld_advance(kk + 1);
-  }
-  PHASE_FLUSH;
-  pl_gather_epilogue<WM, WN>(p, acc, pix, smem16, wm, wn, wid, lane, n0, split);
-}
+// (the halo gather kernel: halo_kernel.h)
 
 // (Round 3 measured and dropped, profiles/r03_halo_tall_ab.txt: a 256-site (8 x 32) form of this kernel with 8 waves per
 // workgroup, the weight tile double-buffered (one barrier per tap) and half the weight bytes per MFMA — passes the same
@@ -1867,17 +1560,7 @@ inline size_t pl_gather_partial_bytes(const GatherGeom& p, int nsplit) {
   return nsplit > 1 ? pl_gather_slab_bytes(p, nsplit) : 0;
 }
 
-// workgroups of a launch (q.mt, q.nt set): order 2 pads the M tiles to whole groups
-inline int pl_grid_classes(const GatherGeom& q) { return q.acc ? 1 : q.ncls; }   // accumulating classes share a block
-
-inline int pl_grid(PlGatherParams& q) {
-  int mt = q.mt;
-  if (q.order == 2) {
-    q.mgroup = q.mt >= 16 ? cdiv(q.mt, 8) : q.mt;
-    mt = cdiv(q.mt, q.mgroup) * q.mgroup;
-  }
-  return mt * q.nt * pl_grid_classes(q) * q.nsplit;
-}
+// (pl_grid, pl_grid_classes: planes_shared.h)
 
 // 2-D site tiles of the plain gather kernels when they divide the site grid exactly (TW = min(32, Wg) sites wide)
 template <int BM>
@@ -1954,9 +1637,6 @@ inline bool pl_halo_acc_pays(const GatherGeom& a) {
   return tiles >= 384 || unflow::options().halo_s2 >= 2;      // (halo_s2 = 2: wherever the kernel applies — tests)
 }
 
-inline int pl_halo_smem(const GatherGeom& p, int bn, int npl) {
-  return pl_halo_main_bytes(bn, bn == 128 ? 64 : 32, npl, pl_halo_pixels(p)) + 128 * 4 + 16;
-}
 // fp16 launches of the halo kernel may run with two chunk planes: K tiles of 64 channels (mfma_terms, planes_shared.h)
 constexpr int F16_KCH = 2;
 inline int f16_kch(const GatherGeom& p, int npl) {
@@ -1976,17 +1656,25 @@ inline int f16_kch(const GatherGeom& p, int npl) {
   }
   return (p.acc ? sum <= 9 : (p.ncls == 4 && four)) ? F16_KCH : 1;
 }
-// (fp16, round 6, measured and dropped: a 128 x 256 workgroup tile with 128 x 64 wave tiles — 6 LDS fragment reads per 8 MFMAs
-// instead of 8 — as an instantiation of this kernel: the 128-register accumulator tile went to scratch (3,000 basic blocks, 576
-// bytes of private segment per lane with one or two workgroups per CU alike) and the layers ran 8x slower; the wave-tile change
-// needs its own kernel, not a template argument.)
-inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
+// fp16 layers may run on the 256-site x 128 tile of conv_halo_tall.hip (option f16_tall)
+inline bool f16_tall(const GatherGeom& p, int npl) {
+  const int o = unflow::options().f16_tall;
+  if (npl != 1 || o <= 0 || f16_kch(p, npl) != 1 || p.N <= 64 || p.Hg < TALL_TH || pl_halo_pixels(p, TALL_TH) > 384) return false;
+  if (o >= 2) return true;
+  const long tiles = (long)p.B * cdiv(p.Hg, TALL_TH) * cdiv(p.Wg, TW) * cdiv(p.N, 128) * pl_grid_classes(p);
+  return tiles >= 512;
+}
+inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out, bool* tall_out = nullptr) {
   const int bn = p.N <= 64 ? 64 : 128;
+  const bool tall = f16_tall(p, npl);
+  if (tall_out) *tall_out = tall;
+  const int th = tall ? TALL_TH : TH;
   *bn_out = bn;
   const int kch = f16_kch(p, npl);
-  const int smem = pl_halo_smem(p, bn, npl == 1 ? kch : npl);
-  const int per_cu = min((160 * 1024) / smem, bn == 128 ? 2 : 3);
-  const long blocks = (long)p.B * cdiv(p.Hg, TH) * cdiv(p.Wg, TW) * cdiv(p.N, bn) * pl_grid_classes(p);
+  const int nbuf = (npl == 1 && kch == 1 && unflow::options().f16_db > 0) ? 2 : 1;
+  const int smem = pl_halo_main_bytes(bn, bn >= 128 ? 64 : 32, npl == 1 ? kch : npl, pl_halo_pixels(p, th), nbuf) + th * 32 * 4 + 16;
+  const int per_cu = min((160 * 1024) / smem, bn >= 128 ? 2 : 3);
+  const long blocks = (long)p.B * cdiv(p.Hg, th) * cdiv(p.Wg, TW) * cdiv(p.N, bn) * pl_grid_classes(p);
   const int nchunk = ((((p.Cs >> 3) + 3) >> 2) + kch - 1) / kch;
   int maxtaps = 0, sumtaps = 0;
   for (int c = 0; c < p.ncls; c++) {
@@ -1998,17 +1686,17 @@ inline int plan_pl_halo(const GatherGeom& p, int npl, int* bn_out) {
   return min(nchunk, fill_one_round(blocks, 256 * per_cu, max_by_k));
 }
 
-template <int BN, int WN, int NPL, bool F16, int WM = 64>
+template <int BN, int WN, int NPL, bool F16, int WM = 64, bool DB = false>
 int launch_pl_halo(const PlGatherParams& p, hipStream_t st) {
   const int hp = pl_halo_pixels(p);
-  const int smem = pl_halo_main_bytes(BN, WN, NPL, hp) + 128 * 4 + 16;
+  const int smem = pl_halo_main_bytes(BN, WN, NPL, hp, DB ? 2 : 1) + 128 * 4 + 16;
   static DynLdsBook book{};     // grow-only per device (the halo size depends on the layer)
-  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, WM, WN, NPL, F16>), smem, book);
+  (void)ensure_dyn_lds(reinterpret_cast<const void*>(&igemm_pl_halo_kernel<BN, WM, WN, NPL, F16, DB>), smem, book);
   PlGatherParams q = p;
   if (F16 && NPL > 1) q.src_ps = q.w_ps = 32;          // chunk planes: plane pl = channels 32 pl .. of the fp16 plane
   q.mt = p.B * p.tiles_y * p.tiles_x; q.nt = cdiv(p.N, BN);
   const int grid = pl_grid(q);
-  igemm_pl_halo_kernel<BN, WM, WN, NPL, F16><<<grid, 256, smem, st>>>(q, hp);
+  igemm_pl_halo_kernel<BN, WM, WN, NPL, F16, DB><<<grid, 256, smem, st>>>(q, hp);
   return launch_status();
 }
 
@@ -2021,9 +1709,10 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   p.order = 2;
   const bool halo = pl_halo_ok(p);
   int halo_bn = 128;
+  bool tall = false;
   PlPlan pl = plan_pl_gather(p, npl);
   if (halo) {
-    pl.nsplit = plan_pl_halo(p, npl, &halo_bn);
+    pl.nsplit = plan_pl_halo(p, npl, &halo_bn, &tall);
     p.tiles_y = cdiv(p.Hg, TH);
     p.tiles_x = cdiv(p.Wg, TW);
   }
@@ -2046,6 +1735,9 @@ int run_pl_gather(PlGatherParams& p, int npl, void* ws, size_t ws_bytes, hipStre
   int code;
   if (halo) {
     if (npl == 3) code = halo_bn == 128 ? launch_pl_halo<128, 64, 3, false>(p, st) : launch_pl_halo<64, 32, 3, false>(p, st);
+    else if (tall) code = launch_pl_halo_f16_tall(p, st);
+    else if (f16_kch(p, npl) == 1 && opt.f16_db > 0)
+      code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true, 64, true>(p, st) : launch_pl_halo<64, 32, 1, true, 64, true>(p, st);
     else if (f16_kch(p, npl) == 1) code = halo_bn == 128 ? launch_pl_halo<128, 64, 1, true>(p, st) : launch_pl_halo<64, 32, 1, true>(p, st);
     else code = halo_bn == 128 ? launch_pl_halo<128, 64, F16_KCH, true>(p, st) : launch_pl_halo<64, 32, F16_KCH, true>(p, st);
   } else {

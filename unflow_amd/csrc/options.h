@@ -16,6 +16,8 @@
   X(gather_pp_fill, 60)   /* ... gather_pp = 1: taken when one round of 8-wave workgroups fills at least this % of the CUs (equal tap counts) */ \
   X(f16_k64, 1)           /* fp16 halo launches with K tiles of 64 channels (two chunk planes): 0 never, 1 short items (conv_transpose forward, 3x3 stride-2 forward), 2 always */ \
   X(f16_wgrad_dma, 1)     /* fp16 filter gradients on the LDS-DMA kernels (stages of three 16-site groups): 1 the 4-wave kernel, 2 also the 8-wave ping-pong one by wgrad_pp's rule (measured slower: 12-24 MFMAs per slot do not cover a barrier), 0 register-staged */ \
+  X(f16_tall, 0)          /* fp16 halo layers with N > 64 on the 256-site x 128 tile of conv_halo_tall.hip (a third of the operand bytes per MFMA): 1 by rule, 2 wherever it can run, 0 off */ \
+  X(f16_db, 0)            /* fp16 one-plane halo launches with the weight tile double-buffered in LDS (halo_kernel.h, DB): loads issued a whole K tile ahead, one barrier per tile (measured neutral, profiles/r06_f16_knockouts.txt); 0 the single-buffer loop */ \
   X(gather_tile2d, 1)     /* 2-D site tiles for the plain gather kernel */                                                \
   X(conv1_direct, 1)      /* FlowNetC's first layer on its own kernel (conv_first.hip: rows staged once per tile, filter resident) */ \
   X(halo, 1)              /* halo kernel for source-stride-1 layers (0: plain gather everywhere) */                       \

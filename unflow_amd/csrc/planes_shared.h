@@ -241,24 +241,40 @@ constexpr int TH = 4, TW = 32, TWL = 5;     // tile = TH x TW = 128 sites
 constexpr int HPITCH = 40;                  // 16-bit elements per halo pixel row: 32 channels + 8 pad (80 bytes)
 
 // LDS bytes of a 4-wave halo block before its pixel table: the operand tiles, or the epilogue's four wave-private staging areas
-constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp) {
-  const int tiles = npl * (hp * HPITCH + bn * LDH) * 2, stage = 4 * 32 * (wn + 4) * 4;
+// (nbuf = 2: the fp16 double-buffered weight tile, halo_kernel.h)
+constexpr int pl_halo_main_bytes(int bn, int wn, int npl, int hp, int nbuf = 1) {
+  const int tiles = npl * (hp * HPITCH + nbuf * bn * LDH) * 2, stage = 4 * 32 * (wn + 4) * 4;
   return tiles > stage ? tiles : stage;
 }
 
 // source pixels of a block's halo image (largest class; accumulating classes share one image at the widest row pitch)
-inline int pl_halo_pixels(const GatherGeom& p) {
+inline int pl_halo_pixels(const GatherGeom& p, int th = TH) {      // th: tile rows (8: the fp16 tall tile)
   int hp = 0, mty = 0, mtx = 0;
   for (int c = 0; c < p.ncls; c++) {
-    hp = max(hp, (TH + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1));
+    hp = max(hp, (th + p.cls[c].nty - 1) * (TW + p.cls[c].ntx - 1));
     mty = max(mty, p.cls[c].nty); mtx = max(mtx, p.cls[c].ntx);
   }
-  return p.acc ? (TH + mty - 1) * (TW + mtx - 1) : hp;      // accumulating classes share one halo image (widest row pitch)
+  return p.acc ? (th + mty - 1) * (TW + mtx - 1) : hp;      // accumulating classes share one halo image (widest row pitch)
+}
+
+// workgroups of a launch (q.mt, q.nt set): order 2 pads the M tiles to whole groups
+inline int pl_grid_classes(const GatherGeom& q) { return q.acc ? 1 : q.ncls; }   // accumulating classes share a block
+
+inline int pl_grid(PlGatherParams& q) {
+  int mt = q.mt;
+  if (q.order == 2) {
+    q.mgroup = q.mt >= 16 ? cdiv(q.mt, 8) : q.mt;
+    mt = cdiv(q.mt, q.mgroup) * q.mgroup;
+  }
+  return mt * q.nt * pl_grid_classes(q) * q.nsplit;
 }
 
 // ---- persistent stream-K halo kernel (conv_streamk.hip)
 bool pl_halo_sk_ok(const GatherGeom& p, int npl, int bn);      // eligible and expected to pay (option streamk)
 size_t pl_halo_sk_ws_bytes();                                   // slabs + arrival flags
 int launch_pl_halo_sk(const PlGatherParams& p, void* ws, size_t ws_bytes, hipStream_t st);      // p.tiles_y / tiles_x set
+// ---- fp16 halo kernel with the 256-site x 128 tile (conv_halo_tall.hip): p.tiles_x / nsplit / partial set (tiles_y is its own)
+constexpr int TALL_TH = 8;
+int launch_pl_halo_f16_tall(const PlGatherParams& p, hipStream_t st);
 
 }  // namespace igemm
