@@ -106,6 +106,62 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+class ClockSampler:
+    """Polls `rocm-smi --showpower --showclocks --json` from a thread while the sustained pass runs: the shader clock and board power the
+    step actually gets (profiles/r06_clock_power_under_load.txt: ~2.1 GHz of the 2.4 GHz the MFMA peak is quoted at).  Context only — `peak`
+    and `frac` stay the nominal ones; every failure (no rocm-smi, no permission, no samples) yields None."""
+
+    SMI = "/opt/rocm/bin/rocm-smi"
+
+    def __init__(self, period=0.4):
+        import threading
+        self.rows, self.period, self._stop = [], period, threading.Event()
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    @staticmethod
+    def parse(txt):
+        """(board power W, sclk MHz) of the busiest card in rocm-smi's JSON, or None."""
+        import re
+        best = None
+        for card, c in json.loads(txt[txt.index("{"):]).items():
+            if not isinstance(c, dict):
+                continue
+
+            def num(pat):
+                for k, v in c.items():
+                    if re.search(pat, k, re.I):
+                        m = re.search(r"\d+(\.\d+)?", str(v))
+                        if m:
+                            return float(m.group(0))
+                return None
+            row = (num(r"power"), num(r"sclk clock speed"))
+            if row[0] is not None and row[1] is not None and (best is None or row[0] > best[0]):
+                best = row                              # the busiest card (N > 1: any rank's)
+        return best
+
+    def _run(self):
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                row = self.parse(subprocess.run([self.SMI, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout)
+                if row is not None:
+                    self.rows.append(row)
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def stop(self):
+        self._stop.set()
+        self.th.join(timeout=10)
+        rows = self.rows[1:] if len(self.rows) > 2 else self.rows        # (the first sample may precede the ramp)
+        if not rows:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]                           # noqa: E731
+        return {"sclk_mhz_median": med([r[1] for r in rows]), "power_w_median": med([r[0] for r in rows]), "samples": len(rows),
+                "source": "rocm-smi --showpower --showclocks polled every %.1f s beside the sustained pass" % self.period}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,16 +311,18 @@ def main():
         # sustains: same step, >= sustain_seconds of it (step count from the all-reduced time: identical on every rank)
         n_sus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
         barrier()
+        sampler = ClockSampler() if rank == 0 else None      # sclk / board power beside the run (rocm-smi; context for roofline.frac)
         t0 = time.perf_counter()
         for _ in range(n_sus):
             step()
         barrier()
         ds = time.perf_counter() - t0
+        clock = sampler.stop() if sampler is not None else None
         if world > 1:
             tmax = torch.tensor([ds], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             ds = tmax.item()
-        sustained = {"value": round(world * B * n_sus / ds, 3), "steps": n_sus, "seconds": round(ds, 2)}
+        sustained = {"value": round(world * B * n_sus / ds, 3), "steps": n_sus, "seconds": round(ds, 2), "clock": clock}
 
     out = {
         "metric": "image-pairs/s (fwd+bwd) FlowNet%s %dx%d" % (args.flownet, H, W), "value": round(pairs_per_s, 3), "unit": "image-pairs/s",
@@ -291,6 +349,13 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = measure_roofline(eng, args)
+        clk = (sustained or {}).get("clock")
+        if clk and out["roofline"].get("frac") and clk["sclk_mhz_median"] > 0:
+            # context, never the judged fraction: `peak` is quoted at the 2400 MHz peak engine clock; under this step the part holds less
+            out["roofline"]["clock_context"] = {
+                "nominal_mhz": 2400, "sampled_sclk_mhz": clk["sclk_mhz_median"], "sampled_power_w": clk["power_w_median"],
+                "frac_at_sampled_clock": round(out["roofline"]["frac"] * 2400.0 / clk["sclk_mhz_median"], 4),
+                "note": "frac x 2400 / sclk sampled beside the sustained pass (profiles/r06_clock_power_under_load.txt); `peak` and `frac` are the nominal ones"}
     if rank == 0 and world == 1 and not args.no_alt and args.flownet == 'C' and eng.math == "bf16x3":
         out["value_fp32_mfma_only"] = measure_alt_fp32(args)      # same step with every conv kernel on the fp32 MFMA
     if rank == 0 and world == 1 and not args.no_secondary and (args.flownet, args.dtype, H, W) == ('C', 'f32', 384, 512):

@@ -8,6 +8,8 @@
 """
 import os
 import socket
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -260,3 +262,22 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus():
     assert r.returncode != 0
     assert "needs 2 visible GPUs" in (r.stdout + r.stderr)
     assert '{"metric"' not in r.stdout
+
+
+def test_bench_clock_sampler_parses_rocm_smi_json_and_degrades_to_none():
+    """bench.py's ClockSampler (sclk / board power beside the sustained pass; context for roofline.frac): the parser on rocm-smi's JSON as
+    the MI355X boxes print it (a warning line in front, values like "(2117Mhz)"), the busiest card of several, and no samples -> None."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    txt = ('WARNING: AMD GPU device(s) is/are in a low-power state.\n'
+           '{"card0": {"Temperature (Sensor junction) (C)": "46.0", "fclk clock speed:": "(1250Mhz)", "mclk clock speed:": "(2000Mhz)", '
+           '"sclk clock speed:": "(115Mhz)", "sclk clock level:": "S", "Current Socket Graphics Package Power (W)": "243.0"}, '
+           '"card1": {"sclk clock speed:": "(2117Mhz)", "sclk clock level:": "S", "Current Socket Graphics Package Power (W)": "1265.0"}, '
+           '"system": "x"}')
+    assert bench.ClockSampler.parse(txt) == (1265.0, 2117.0)
+    assert bench.ClockSampler.parse('{"card0": {"mclk clock speed:": "(2000Mhz)"}}') is None
+    s = bench.ClockSampler(period=0.05)
+    s.SMI = "/nonexistent/rocm-smi"
+    time.sleep(0.2)
+    assert s.stop() is None
