@@ -2,7 +2,7 @@
 // 32768 flop, v_mfma_f32_16x16x32_bf16 2 KB per 16384 — half the accumulator traffic per flop, twice the operand traffic.  Pure MFMA loops on
 // pseudo-random operands (what real data looks like to the multiplier array; tools/microbench/mfma_scaling.hip), 2 waves per SIMD on all 256 CUs,
 // SUSTAINED for ~3 s per shape (short bursts ride on banked power headroom).  Prints TFLOP/s; run under tools/power_trace.sh for clock / power.
-//   hipcc --offload-arch=gfx950 -O3 mfma_shape_power.hip -o mfma_shape_power && ./mfma_shape_power <shape 0|1|2|3> [seconds]
+//   hipcc --offload-arch=gfx950 -O3 mfma_shape_power.hip -o mfma_shape_power && ./mfma_shape_power <shape 0|1|2|3> [seconds] [blocks]
 //   shape 0: 32x32x16 bf16   1: 16x16x32 bf16   2: 32x32x16 f16   3: 16x16x32 f16
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
 }
 
 template <int SHAPE>
-static void run(float* out, double seconds, const char* name) {
-  const int iters = 4000, blocks = 512;                           // 2 waves per SIMD on 256 CUs; 32 x 32768 flop per wave and iteration
+static void run(float* out, double seconds, const char* name, int blocks) {
+  const int iters = 4000;                           // 2 waves per SIMD on 256 CUs; 32 x 32768 flop per wave and iteration
   const double flop_per_launch = (double)blocks * 4 * iters * 32 * 32768.0;
   for (int i = 0; i < 3; i++) k<SHAPE><<<blocks, 256>>>(out, iters);
   CK(hipDeviceSynchronize());
@@ -79,19 +79,20 @@ static void run(float* out, double seconds, const char* name) {
     launches += 20;
     el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  printf("%-18s %6.2f s  %ld launches  %8.1f TFLOP/s  (%.1f %% of 2500)\n", name, el, launches, flop_per_launch * launches / el * 1e-12,
-         flop_per_launch * launches / el * 1e-12 / 25.0);
+  printf("%-18s %6.2f s  %ld launches  %8.1f TFLOP/s  (%.1f %% of 2500 x blocks / 512)\n", name, el, launches, flop_per_launch * launches / el * 1e-12,
+         flop_per_launch * launches / el * 1e-12 / 25.0 * 512.0 / blocks);
 }
 
 int main(int argc, char** argv) {
   const int shape = argc > 1 ? atoi(argv[1]) : 0;
   const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
+  const int blocks = argc > 3 ? atoi(argv[3]) : 512;              // 512 = 2 waves per SIMD on all 256 CUs; 48 = 24 CUs (no power limit in sight)
   float* out; CK(hipMalloc(&out, 64));
   switch (shape) {
-    case 0: run<0>(out, seconds, "32x32x16 bf16"); break;
-    case 1: run<1>(out, seconds, "16x16x32 bf16"); break;
-    case 2: run<2>(out, seconds, "32x32x16 f16"); break;
-    default: run<3>(out, seconds, "16x16x32 f16"); break;
+    case 0: run<0>(out, seconds, "32x32x16 bf16", blocks); break;
+    case 1: run<1>(out, seconds, "16x16x32 bf16", blocks); break;
+    case 2: run<2>(out, seconds, "32x32x16 f16", blocks); break;
+    default: run<3>(out, seconds, "16x16x32 f16", blocks); break;
   }
   return 0;
 }
